@@ -1,0 +1,179 @@
+/*
+ * sstts_hip.h -- C ABI of the MI355X-native Tacotron inference hot path.
+ *
+ * One shared library (libsstts_hip.so, hand-written HIP for gfx950), plain pointers and
+ * sizes, no C++/torch types.  The reference (yweweler/single-speaker-tts) has no FFI: its
+ * boundary is the Python module surface of tacotron.model / tacotron.inference /
+ * audio.synthesis / audio.conversion / audio.features.  Each entry point below names the
+ * reference interface (file:line under the reference tree) whose arithmetic it replaces; the
+ * ctypes binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - All tensor pointers are DEVICE pointers (HIP), float32 row-major, batch-major,
+ *     channels-last unless stated; ids are int32.  The caller owns every in/out buffer;
+ *     the library owns weights and scratch inside the handle.  tts_malloc/tts_memcpy_* let
+ *     a host without any other GPU runtime (plain ctypes + numpy) drive the library.
+ *   - Every function returns 0 on success or a negative tts_status code and never throws.
+ *     tts_last_error(handle) returns a human-readable description of the last failure.
+ *   - A handle is bound to one device and one stream; calls on one handle must be
+ *     serialised by the caller.  Distinct handles (one per GPU / process) are independent.
+ *   - Calls are asynchronous on the handle's stream unless stated; tts_synchronize waits.
+ *   - Same inputs (and the same init_phase / seed) give bit-identical outputs run to run:
+ *     every reduction has a fixed order, no float atomics are used.
+ */
+#ifndef SSTTS_HIP_H
+#define SSTTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tts_handle_s* tts_handle_t;
+
+enum tts_status {
+    TTS_OK = 0,
+    TTS_ERR_INVALID = -1,      /* bad argument / shape */
+    TTS_ERR_NOT_LOADED = -2,   /* weights missing or not finalised */
+    TTS_ERR_HIP = -3,          /* HIP runtime error */
+    TTS_ERR_DB_RANGE = -4,     /* dB < -100: reference audio/conversion.py:47-49 AssertionError */
+    TTS_ERR_UNSUPPORTED = -5   /* configuration outside what the kernels implement */
+};
+
+/* Architecture hyper-parameters; field names and defaults follow the reference's
+ * model_params (tacotron/params/model.py:8-153).  tts_default_config fills the defaults. */
+typedef struct tts_config {
+    int32_t vocabulary_size;     /* 39  */
+    int32_t embedding_size;      /* 256 */
+    int32_t enc_prenet_units[2]; /* 256, 128 */
+    int32_t enc_n_banks;         /* 16  */
+    int32_t enc_n_filters;       /* 128 */
+    int32_t enc_proj_filters[2]; /* 128, 128 (kernel size 3; relu, linear) */
+    int32_t post_n_banks;        /* 8   */
+    int32_t post_n_filters;      /* 128 */
+    int32_t post_proj_filters[2];/* 256, 80 */
+    int32_t n_highway_layers;    /* 4   */
+    int32_t n_highway_units;     /* 128 */
+    int32_t n_gru_units;         /* 128 (CBHG bi-GRU, both encoder and post-net) */
+    int32_t dec_prenet_units[2]; /* 256, 128 */
+    int32_t n_attention_units;   /* 256 */
+    int32_t n_decoder_gru_units; /* 256 */
+    int32_t n_decoder_gru_layers;/* 2   */
+    int32_t n_mels;              /* 80  */
+    int32_t reduction;           /* 5   */
+    int32_t n_fft;               /* 2048 */
+    int32_t force_cudnn;         /* 0: tf GRUCell (TF-CPU parity target); 1: CudnnCompatibleGRUCell */
+} tts_config_t;
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+const char* tts_version(void);
+int tts_default_config(tts_config_t* cfg);
+/* Replaces graph construction `Tacotron(inputs, Mode.PREDICT)` (tacotron/model.py:35-112). */
+int tts_create(const tts_config_t* cfg, int device_id, tts_handle_t* out);
+int tts_destroy(tts_handle_t h);
+const char* tts_last_error(tts_handle_t h);        /* h may be NULL: last create-time error */
+/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+int tts_set_stream(tts_handle_t h, void* hip_stream);
+/* Options: "use_graph" (decoder loop replayed from a hipGraph, default 1), "profile"
+ * (record per-stage HIP events, default 0). */
+int tts_set_option(tts_handle_t h, const char* key, int value);
+int tts_synchronize(tts_handle_t h);
+
+/* ---- weights: replaces tf.train.Saver().restore (tacotron/inference.py:55,71) ---------- */
+/* Manifest: names follow the TF variable scopes (see single-speaker-tts_amd/tacotron/weights.py). */
+int tts_manifest_size(tts_handle_t h);
+int tts_manifest_entry(tts_handle_t h, int index, const char** name, int64_t shape[4], int* ndim);
+/* host_data: HOST pointer, TensorFlow layout (Dense (in,out); conv (k,in,out); GRU gates
+ * (in+units, 2*units) = rows [input;state], columns [r|u]). */
+int tts_set_weight(tts_handle_t h, const char* name, const float* host_data, const int64_t* shape, int ndim);
+/* All tensors of the manifest, concatenated in manifest order (the RCCL broadcast unit). */
+int tts_load_weights_blob(tts_handle_t h, const float* host_blob, size_t n_floats);
+/* Validates completeness, folds batch-norm, packs device layouts.  Synchronous. */
+int tts_finalize_weights(tts_handle_t h);
+
+/* ---- device memory helpers ---------------------------------------------------------- */
+int tts_malloc(void** dptr, size_t bytes);
+int tts_free(void* dptr);
+int tts_memcpy_h2d(tts_handle_t h, void* dst, const void* src, size_t bytes);  /* synchronous */
+int tts_memcpy_d2h(tts_handle_t h, void* dst, const void* src, size_t bytes);  /* synchronous */
+int tts_memset(tts_handle_t h, void* dst, int value, size_t bytes);
+
+/* ---- network stages -------------------------------------------------------------------- */
+/* Tacotron.encoder (tacotron/model.py:124-173): embedding + pre-net + CBHG.
+ * ids int32 [B*Ts] -> memory float [B*Ts*2*n_gru_units]. */
+int tts_encoder_forward(tts_handle_t h, const int32_t* ids, int B, int Ts, float* memory);
+/* Tacotron.decoder in Mode.PREDICT (tacotron/model.py:175-334; wrappers.py:94-124;
+ * helpers.py:83-110,161-205): n_steps strictly sequential steps (reference: 1000//5 = 200).
+ * memory [B*Ts*256] -> reduced mel [B * n_steps * (reduction*n_mels)] (== output_mel_spec
+ * reshaped, model.py:383) and alignment_history [n_steps * B * Ts] (may be NULL). */
+int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int n_steps,
+                        float* mel, float* alignments);
+/* Tacotron.post_process + final Dense (tacotron/model.py:336-363, 394-398).
+ * mel [B*T*n_mels] -> output_linear_spec [B*T*(1+n_fft/2)]. */
+int tts_postnet_forward(tts_handle_t h, const float* mel, int B, int T, float* linear);
+
+/* ---- spectrogram de-normalisation ------------------------------------------------------ */
+/* inference() post-step + synthesize() power (tacotron/inference.py:93-101,175;
+ * audio/conversion.py:81-102, 32-53): per utterance transpose to (F,T),
+ * db = (clip(x,0,1)-1)*(|ref|+|max|)+ref, mag = 10^(db/20), mag ** power.
+ * linear [B*T*F] -> mag [B*F*T].  Returns TTS_ERR_DB_RANGE when ref - |ref| - |max| < -100. */
+int tts_denorm_power(tts_handle_t h, const float* linear, int B, int T, int F,
+                     float ref_db, float max_db, float power, float* mag);
+
+/* ---- Griffin-Lim ------------------------------------------------------------------------ */
+/* griffin_lim_v2 / spectrogram_to_wav (audio/synthesis.py:5-125), batched.
+ * mag [B*F*T] (F = 1+n_fft/2, reference layout (F,T) per utterance);
+ * init_phase [B*F*T] of U[0,1) numbers = what np.random.rand returns at synthesis.py:85,
+ * or NULL to draw them on device from `seed`;  wav [B * hop*(T-1)];  mse [B] or NULL
+ * (mean squared magnitude error of the last iteration, synthesis.py:112). */
+int tts_griffin_lim(tts_handle_t h, const float* mag, const float* init_phase, uint64_t seed,
+                    int B, int T, int n_iter, int win_length, int hop_length, int n_fft,
+                    float* wav, float* mse);
+/* librosa.output.write_wav(norm=True) scaling (audio/io.py:53): wav /= max|wav| per
+ * utterance unless the peak is below FLT_MIN.  In place, wav [B*n]. */
+int tts_peak_normalize(tts_handle_t h, float* wav, int B, int n);
+
+/* ---- analysis features (audio/features.py:5-86,116-145) ------------------------------- */
+/* |librosa.stft(wav)| ** power, centre/reflect, hann.  wav [B*n] -> lin [B*F*n_frames],
+ * n_frames = 1 + n/hop. */
+int tts_stft_magnitude(tts_handle_t h, const float* wav, int B, int n, int n_fft, int win_length,
+                       int hop_length, float power, float* lin);
+/* librosa.filters.mel(htk=True) applied: lin [B*F*n_frames] -> mel [B*n_mels*n_frames]. */
+int tts_mel_spectrogram(tts_handle_t h, const float* lin, int B, int n_frames, int n_fft,
+                        int sampling_rate, int n_mels, float fmin, float fmax, float* mel);
+
+/* ---- end to end -------------------------------------------------------------------------- */
+/* ids -> waveform: encoder, decoder (n_steps), post-net, de-normalise, ** power, Griffin-Lim,
+ * optional peak normalisation; replaces tacotron/inference.py:162-200 minus file IO.
+ * Optional outputs (NULL to skip): mel [B*n_steps*r*n_mels], alignments [n_steps*B*Ts],
+ * linear [B*T*F].  wav [B * hop*(T-1)], T = n_steps*reduction. */
+typedef struct tts_synth_params {
+    int32_t n_steps;        /* 200 */
+    float ref_db, max_db;   /* 6.02, 99.89 (mel constants, as the reference uses them) */
+    float power;            /* 1.3 */
+    int32_t n_iter;         /* 50 */
+    int32_t win_length, hop_length;  /* 1102, 275 */
+    uint64_t seed;          /* random initial phase when init_phase == NULL */
+    int32_t peak_normalize; /* save_wav(norm=True) */
+} tts_synth_params_t;
+int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_synth_params_t* p,
+                   const float* init_phase /* [B*F*T] or NULL */, float* wav, float* mel,
+                   float* alignments, float* linear);
+
+/* ---- profiling -------------------------------------------------------------------------- */
+/* With option "profile"=1 the library brackets its stages with HIP events on the handle's
+ * stream.  Stages: "encoder", "decoder", "postnet", "denorm", "gl_iter", "gl_final".
+ * Returns accumulated milliseconds and the number of kernel launches covered since the last
+ * tts_profile_reset.  Synchronises the stream. */
+int tts_profile_reset(tts_handle_t h);
+/* Test hook: device pointer and size of a named internal scratch buffer of the last call
+ * ("enc.bank", "enc.p1", "post.xproj", ...); contents are only valid until the next call. */
+int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* bytes);
+int tts_profile_get(tts_handle_t h, const char* stage, float* ms_total, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSTTS_HIP_H */

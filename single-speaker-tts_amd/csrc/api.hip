@@ -1,0 +1,1217 @@
+// C ABI of libsstts_hip.so (see include/sstts_hip.h): handle, weights, workspace, stage drivers.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "decoder.h"
+#include "griffin_lim.h"
+#include "tts_common.h"
+
+using namespace tts;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ManifestEntry {
+    std::string name;
+    std::vector<int64_t> shape;
+    size_t numel() const {
+        size_t n = 1;
+        for (auto d : shape) n *= (size_t)d;
+        return n;
+    }
+};
+
+struct CbhgWeights {
+    int n_banks = 0, n_filters = 0, c_in = 0, proj_filters[2] = {0, 0};
+    // device pointers into the arena
+    std::vector<const float*> bank_wt, bank_b, bank_scale, bank_shift;
+    const float* proj_wt[2];
+    const float* proj_b[2];
+    const float* proj_scale[2];
+    const float* proj_shift[2];
+    const float* lifter_wt;
+    const float* lifter_b;
+    std::vector<const float*> hw_wt, hw_b;
+    const float* gru_in_wt;   // [2*3H][units]
+    const float* gru_in_b;    // [2*3H]
+    const float* gru_rec;     // packed recurrent weights, both directions
+};
+
+enum Stage { ST_ENCODER = 0, ST_DECODER, ST_POSTNET, ST_DENORM, ST_GL_ITER, ST_GL_FINAL, ST_COUNT };
+const char* kStageNames[ST_COUNT] = {"encoder", "decoder", "postnet", "denorm", "gl_iter", "gl_final"};
+
+struct ProfSpan {
+    hipEvent_t a, b;
+    int stage;
+    int64_t launches;
+};
+
+}  // namespace
+
+struct tts_handle_s {
+    tts_config_t cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int use_graph = 1;
+    int profile = 0;
+
+    std::vector<ManifestEntry> manifest;
+    std::map<std::string, std::vector<float>> host_w;
+    bool finalized = false;
+
+    // device weight arena
+    float* arena = nullptr;
+    size_t arena_floats = 0;
+
+    const float* embedding = nullptr;
+    const float* enc_pre_wt[2];
+    const float* enc_pre_b[2];
+    CbhgWeights enc, post;
+    const float* mem_wt = nullptr;
+    DecoderWeights dec;
+    const float* dense_wt = nullptr;
+    const float* dense_b = nullptr;
+    const float* zeros = nullptr;   // 1024 zero floats inside the arena
+
+    // workspace (grow-only)
+    std::map<std::string, DevBuf> ws;
+
+    // decoder graph cache
+    hipGraphExec_t dec_graph = nullptr;
+    struct {
+        const void* memory = nullptr;
+        void* mel = nullptr;
+        void* align = nullptr;
+        int B = 0, Ts = 0, n_steps = 0;
+    } dec_key;
+
+    // Griffin-Lim tables
+    struct {
+        int win = 0, hop = 0, T = 0;
+        float* window = nullptr;
+        float* wss = nullptr;
+        float2* tw1024 = nullptr;
+        float2* tw2048 = nullptr;
+        bool configured = false;
+    } gl;
+
+    // profiling
+    std::vector<ProfSpan> spans;
+    double prof_ms[ST_COUNT] = {0};
+    int64_t prof_launches[ST_COUNT] = {0};
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+            return TTS_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+int fail(tts_handle_t h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+// ------------------------------------------------------------------------------------ manifest
+const char* kAtt = "decoder2/decoder/output_projection_wrapper/multi_rnn_cell/cell_0/attention_wrapper";
+const char* kMrc = "decoder2/decoder/output_projection_wrapper/multi_rnn_cell";
+
+std::string bn_name(int i) {
+    return i == 0 ? std::string("batch_normalization") : "batch_normalization_" + std::to_string(i);
+}
+
+void add(std::vector<ManifestEntry>& m, const std::string& name, std::vector<int64_t> shape) {
+    m.push_back({name, std::move(shape)});
+}
+
+void gru_entries(std::vector<ManifestEntry>& m, const std::string& scope, int n_in, int units, bool cudnn) {
+    add(m, scope + "/gates/kernel", {n_in + units, 2 * units});
+    add(m, scope + "/gates/bias", {2 * units});
+    if (cudnn) {
+        add(m, scope + "/candidate/input_projection/kernel", {n_in, units});
+        add(m, scope + "/candidate/input_projection/bias", {units});
+        add(m, scope + "/candidate/hidden_projection/kernel", {units, units});
+        add(m, scope + "/candidate/hidden_projection/bias", {units});
+    } else {
+        add(m, scope + "/candidate/kernel", {n_in + units, units});
+        add(m, scope + "/candidate/bias", {units});
+    }
+}
+
+void cbhg_entries(std::vector<ManifestEntry>& m, const std::string& scope, int n_in, int n_banks, int n_filters,
+                  const int proj[2], int hw_layers, int hw_units, int gru_units, bool cudnn) {
+    for (int k = 1; k <= n_banks; ++k) {
+        const std::string cs = scope + "/convolution_banks/conv-" + std::to_string(k) + "-" + std::to_string(n_filters);
+        add(m, cs + "/kernel", {k, n_in, n_filters});
+        add(m, cs + "/bias", {n_filters});
+    }
+    for (int i = 0; i < n_banks; ++i)
+        for (const char* v : {"beta", "moving_mean", "moving_variance"})
+            add(m, scope + "/convolution_banks/" + bn_name(i) + "/" + v, {n_filters});
+    int c_in = n_banks * n_filters;
+    for (int i = 0; i < 2; ++i) {
+        const std::string ps =
+            scope + "/projections/" + std::to_string(i + 1) + "-conv-3-" + std::to_string(proj[i]);
+        add(m, ps + "/conv1d/kernel", {3, c_in, proj[i]});
+        add(m, ps + "/conv1d/bias", {proj[i]});
+        for (const char* v : {"gamma", "beta", "moving_mean", "moving_variance"})
+            add(m, ps + "/batch_normalization/" + v, {proj[i]});
+        c_in = proj[i];
+    }
+    add(m, scope + "/lifter/kernel", {c_in, hw_units});
+    add(m, scope + "/lifter/bias", {hw_units});
+    for (int l = 0; l < hw_layers; ++l)
+        for (const char* g : {"H", "T"}) {
+            const std::string hs = scope + "/highway_network/highway_layer_" + std::to_string(l) + "/" + g;
+            add(m, hs + "/kernel", {hw_units, hw_units});
+            add(m, hs + "/bias", {hw_units});
+        }
+    for (const char* d : {"fw", "bw"})
+        gru_entries(m, scope + "/gru/" + d + "/gru_cell_" + d, hw_units, gru_units, cudnn);
+}
+
+void build_manifest(tts_handle_t h) {
+    const tts_config_t& c = h->cfg;
+    const bool cudnn = c.force_cudnn != 0;
+    auto& m = h->manifest;
+    m.clear();
+    add(m, "encoder/embedding", {c.vocabulary_size, c.embedding_size});
+    int n_in = c.embedding_size;
+    for (int i = 0; i < 2; ++i) {
+        const std::string s = "encoder/pre_net/" + std::to_string(i + 1) + "-FC-" + std::to_string(c.enc_prenet_units[i]);
+        add(m, s + "/kernel", {n_in, c.enc_prenet_units[i]});
+        add(m, s + "/bias", {c.enc_prenet_units[i]});
+        n_in = c.enc_prenet_units[i];
+    }
+    cbhg_entries(m, "encoder", n_in, c.enc_n_banks, c.enc_n_filters, c.enc_proj_filters, c.n_highway_layers,
+                 c.n_highway_units, c.n_gru_units, cudnn);
+    const int mem = 2 * c.n_gru_units, att = c.n_attention_units;
+    add(m, "decoder2/memory_layer/kernel", {mem, att});
+    n_in = c.n_mels + att;
+    for (int i = 0; i < 2; ++i) {
+        const std::string s = std::string(kAtt) + "/pre_net/" + std::to_string(i + 1) + "-FC-" +
+                              std::to_string(c.dec_prenet_units[i]);
+        add(m, s + "/kernel", {n_in, c.dec_prenet_units[i]});
+        add(m, s + "/bias", {c.dec_prenet_units[i]});
+        n_in = c.dec_prenet_units[i];
+    }
+    gru_entries(m, std::string(kAtt) + "/gru_cell", n_in, att, cudnn);
+    add(m, std::string(kAtt) + "/attention_layer/kernel", {att + mem, att});
+    for (int i = 0; i < c.n_decoder_gru_layers; ++i)
+        gru_entries(m, std::string(kMrc) + "/cell_" + std::to_string(i + 1) + "/gru_cell",
+                    i == 0 ? att : c.n_decoder_gru_units, c.n_decoder_gru_units, cudnn);
+    add(m, "decoder2/decoder/output_projection_wrapper/kernel", {c.n_decoder_gru_units, c.n_mels * c.reduction});
+    add(m, "decoder2/decoder/output_projection_wrapper/bias", {c.n_mels * c.reduction});
+    cbhg_entries(m, "post_process", c.n_mels, c.post_n_banks, c.post_n_filters, c.post_proj_filters,
+                 c.n_highway_layers, c.n_highway_units, c.n_gru_units, cudnn);
+    add(m, "dense/kernel", {2 * c.n_gru_units, 1 + c.n_fft / 2});
+    add(m, "dense/bias", {1 + c.n_fft / 2});
+}
+
+// ------------------------------------------------------------------------------------ packing
+struct Packer {
+    std::vector<float> host;   // staging for the whole arena
+    size_t alloc(size_t n) {
+        const size_t off = (host.size() + 63) & ~size_t(63);   // 256-byte aligned segments
+        host.resize(off + n, 0.f);
+        return off;
+    }
+};
+
+const std::vector<float>& W(tts_handle_t h, const std::string& name) { return h->host_w.at(name); }
+
+// [K][N] row-major (TF (in,out)) -> [N][K]
+size_t pack_transposed(Packer& p, const float* src, int K, int N) {
+    const size_t off = p.alloc((size_t)K * N);
+    float* dst = p.host.data() + off;
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) dst[(size_t)n * K + k] = src[(size_t)k * N + n];
+    return off;
+}
+size_t pack_copy(Packer& p, const float* src, size_t n) {
+    const size_t off = p.alloc(n);
+    std::memcpy(p.host.data() + off, src, n * sizeof(float));
+    return off;
+}
+
+struct CbhgOffsets {
+    std::vector<size_t> bank_wt, bank_b, bank_scale, bank_shift;
+    size_t proj_wt[2], proj_b[2], proj_scale[2], proj_shift[2], lifter_wt, lifter_b;
+    std::vector<size_t> hw_wt, hw_b;
+    size_t gru_in_wt, gru_in_b, gru_rec;
+};
+
+const float kBnEps = 1e-3f;   // tf.layers.batch_normalization default epsilon
+
+CbhgOffsets pack_cbhg(tts_handle_t h, Packer& p, const std::string& scope, int n_in, int n_banks, int n_filters,
+                      const int proj[2], bool cudnn) {
+    const tts_config_t& c = h->cfg;
+    CbhgOffsets o;
+    for (int k = 1; k <= n_banks; ++k) {
+        const std::string cs = scope + "/convolution_banks/conv-" + std::to_string(k) + "-" + std::to_string(n_filters);
+        // (k, in, out) is already [K = k*in][N = out] row-major
+        o.bank_wt.push_back(pack_transposed(p, W(h, cs + "/kernel").data(), k * n_in, n_filters));
+        o.bank_b.push_back(pack_copy(p, W(h, cs + "/bias").data(), n_filters));
+        const std::string bs = scope + "/convolution_banks/" + bn_name(k - 1);
+        std::vector<float> sc(n_filters), sh(n_filters);
+        for (int i = 0; i < n_filters; ++i) {
+            const double inv = 1.0 / std::sqrt((double)W(h, bs + "/moving_variance")[i] + (double)kBnEps);
+            sc[i] = (float)inv;
+            sh[i] = (float)((double)W(h, bs + "/beta")[i] - (double)W(h, bs + "/moving_mean")[i] * inv);
+        }
+        o.bank_scale.push_back(pack_copy(p, sc.data(), n_filters));
+        o.bank_shift.push_back(pack_copy(p, sh.data(), n_filters));
+    }
+    int c_in = n_banks * n_filters;
+    for (int i = 0; i < 2; ++i) {
+        const std::string ps = scope + "/projections/" + std::to_string(i + 1) + "-conv-3-" + std::to_string(proj[i]);
+        o.proj_wt[i] = pack_transposed(p, W(h, ps + "/conv1d/kernel").data(), 3 * c_in, proj[i]);
+        o.proj_b[i] = pack_copy(p, W(h, ps + "/conv1d/bias").data(), proj[i]);
+        std::vector<float> sc(proj[i]), sh(proj[i]);
+        const std::string bs = ps + "/batch_normalization";
+        for (int j = 0; j < proj[i]; ++j) {
+            const double inv = (double)W(h, bs + "/gamma")[j] /
+                               std::sqrt((double)W(h, bs + "/moving_variance")[j] + (double)kBnEps);
+            sc[j] = (float)inv;
+            sh[j] = (float)((double)W(h, bs + "/beta")[j] - (double)W(h, bs + "/moving_mean")[j] * inv);
+        }
+        o.proj_scale[i] = pack_copy(p, sc.data(), proj[i]);
+        o.proj_shift[i] = pack_copy(p, sh.data(), proj[i]);
+        c_in = proj[i];
+    }
+    const int U = c.n_highway_units;
+    o.lifter_wt = pack_transposed(p, W(h, scope + "/lifter/kernel").data(), c_in, U);
+    o.lifter_b = pack_copy(p, W(h, scope + "/lifter/bias").data(), U);
+    for (int l = 0; l < c.n_highway_layers; ++l) {
+        const std::string hs = scope + "/highway_network/highway_layer_" + std::to_string(l);
+        const auto& kh = W(h, hs + "/H/kernel");
+        const auto& kt = W(h, hs + "/T/kernel");
+        const auto& bh = W(h, hs + "/H/bias");
+        const auto& bt = W(h, hs + "/T/bias");
+        // packed rows: span s (32 units): rows 64s + w = H unit 32s+w ; rows 64s + 32 + w = T unit 32s+w
+        const size_t ow = p.alloc((size_t)2 * U * U);
+        const size_t ob = p.alloc((size_t)2 * U);
+        for (int u = 0; u < U; ++u) {
+            const int s = u / 32, w = u % 32;
+            const int rh = 64 * s + w, rt = 64 * s + 32 + w;
+            for (int k = 0; k < U; ++k) {
+                p.host[ow + (size_t)rh * U + k] = kh[(size_t)k * U + u];
+                p.host[ow + (size_t)rt * U + k] = kt[(size_t)k * U + u];
+            }
+            p.host[ob + rh] = bh[u];
+            p.host[ob + rt] = bt[u];
+        }
+        o.hw_wt.push_back(ow);
+        o.hw_b.push_back(ob);
+    }
+    // bi-GRU: input projections [2][r|u|c] and recurrent blocks
+    const int H = c.n_gru_units;
+    o.gru_in_wt = p.alloc((size_t)6 * H * U);
+    o.gru_in_b = p.alloc((size_t)6 * H);
+    o.gru_rec = p.alloc(bigru_wrec_floats(H, cudnn));
+    const size_t rec_stride = bigru_wrec_floats(H, cudnn) / 2;
+    const char* dirs[2] = {"fw", "bw"};
+    for (int d = 0; d < 2; ++d) {
+        const std::string gs = scope + "/gru/" + dirs[d] + "/gru_cell_" + dirs[d];
+        const auto& gk = W(h, gs + "/gates/kernel");   // [U + H][2H]
+        const auto& gb = W(h, gs + "/gates/bias");
+        const float* ck_in;    // [U][H] input part of the candidate
+        int ck_in_ld;
+        const float* ck_h;     // [H][H] recurrent part
+        const float* cb;
+        if (cudnn) {
+            ck_in = W(h, gs + "/candidate/input_projection/kernel").data();
+            ck_h = W(h, gs + "/candidate/hidden_projection/kernel").data();
+            cb = W(h, gs + "/candidate/input_projection/bias").data();
+        } else {
+            ck_in = W(h, gs + "/candidate/kernel").data();
+            ck_h = ck_in + (size_t)U * H;
+            cb = W(h, gs + "/candidate/bias").data();
+        }
+        ck_in_ld = H;
+        float* wt = p.host.data() + o.gru_in_wt + (size_t)d * 3 * H * U;
+        float* bb = p.host.data() + o.gru_in_b + (size_t)d * 3 * H;
+        for (int n = 0; n < 2 * H; ++n) {
+            for (int k = 0; k < U; ++k) wt[(size_t)n * U + k] = gk[(size_t)k * 2 * H + n];
+            bb[n] = gb[n];
+        }
+        for (int n = 0; n < H; ++n) {
+            for (int k = 0; k < U; ++k) wt[(size_t)(2 * H + n) * U + k] = ck_in[(size_t)k * ck_in_ld + n];
+            bb[2 * H + n] = cb[n];
+        }
+        float* rec = p.host.data() + o.gru_rec + (size_t)d * rec_stride;
+        for (int k = 0; k < H; ++k)
+            for (int n = 0; n < 2 * H; ++n) rec[(size_t)k * 2 * H + n] = gk[(size_t)(U + k) * 2 * H + n];
+        float* rc = rec + (size_t)H * 2 * H;
+        for (int k = 0; k < H; ++k)
+            for (int n = 0; n < H; ++n) rc[(size_t)k * H + n] = ck_h[(size_t)k * H + n];
+        if (cudnn) {
+            const auto& hb = W(h, gs + "/candidate/hidden_projection/bias");
+            for (int n = 0; n < H; ++n) rc[(size_t)H * H + n] = hb[n];
+        }
+    }
+    return o;
+}
+
+void bind_cbhg(CbhgWeights& w, const CbhgOffsets& o, const float* base, int n_in, int n_banks, int n_filters,
+               const int proj[2]) {
+    w.n_banks = n_banks;
+    w.n_filters = n_filters;
+    w.c_in = n_in;
+    w.proj_filters[0] = proj[0];
+    w.proj_filters[1] = proj[1];
+    for (int k = 0; k < n_banks; ++k) {
+        w.bank_wt.push_back(base + o.bank_wt[k]);
+        w.bank_b.push_back(base + o.bank_b[k]);
+        w.bank_scale.push_back(base + o.bank_scale[k]);
+        w.bank_shift.push_back(base + o.bank_shift[k]);
+    }
+    for (int i = 0; i < 2; ++i) {
+        w.proj_wt[i] = base + o.proj_wt[i];
+        w.proj_b[i] = base + o.proj_b[i];
+        w.proj_scale[i] = base + o.proj_scale[i];
+        w.proj_shift[i] = base + o.proj_shift[i];
+    }
+    w.lifter_wt = base + o.lifter_wt;
+    w.lifter_b = base + o.lifter_b;
+    for (size_t l = 0; l < o.hw_wt.size(); ++l) {
+        w.hw_wt.push_back(base + o.hw_wt[l]);
+        w.hw_b.push_back(base + o.hw_b[l]);
+    }
+    w.gru_in_wt = base + o.gru_in_wt;
+    w.gru_in_b = base + o.gru_in_b;
+    w.gru_rec = base + o.gru_rec;
+}
+
+struct GruOffsets {
+    size_t gates_wt, gates_b, cand_wt, cand_b;
+};
+
+GruOffsets pack_dec_gru(tts_handle_t h, Packer& p, const std::string& scope, int n_in, int U, bool cudnn) {
+    GruOffsets o{};
+    const auto& gk = W(h, scope + "/gates/kernel");   // [n_in + U][2U]
+    const auto& gb = W(h, scope + "/gates/bias");
+    const int K = n_in + U;
+    if (!cudnn) {
+        o.gates_wt = pack_transposed(p, gk.data(), K, 2 * U);
+        o.gates_b = pack_copy(p, gb.data(), 2 * U);
+        o.cand_wt = pack_transposed(p, W(h, scope + "/candidate/kernel").data(), K, U);
+        o.cand_b = pack_copy(p, W(h, scope + "/candidate/bias").data(), U);
+        return o;
+    }
+    // [4U][K]: r | u | hh (h Wch, zero over the input rows) | xi (x Wci, zero over the state rows)
+    const auto& ik = W(h, scope + "/candidate/input_projection/kernel");   // [n_in][U]
+    const auto& ib = W(h, scope + "/candidate/input_projection/bias");
+    const auto& hk = W(h, scope + "/candidate/hidden_projection/kernel");  // [U][U]
+    const auto& hb = W(h, scope + "/candidate/hidden_projection/bias");
+    o.gates_wt = p.alloc((size_t)4 * U * K);
+    o.gates_b = p.alloc((size_t)4 * U);
+    float* wt = p.host.data() + o.gates_wt;
+    float* bb = p.host.data() + o.gates_b;
+    for (int n = 0; n < 2 * U; ++n) {
+        for (int k = 0; k < K; ++k) wt[(size_t)n * K + k] = gk[(size_t)k * 2 * U + n];
+        bb[n] = gb[n];
+    }
+    for (int n = 0; n < U; ++n) {
+        for (int k = 0; k < U; ++k) wt[(size_t)(2 * U + n) * K + n_in + k] = hk[(size_t)k * U + n];
+        bb[2 * U + n] = hb[n];
+        for (int k = 0; k < n_in; ++k) wt[(size_t)(3 * U + n) * K + k] = ik[(size_t)k * U + n];
+        bb[3 * U + n] = ib[n];
+    }
+    o.cand_wt = o.gates_wt;
+    o.cand_b = o.gates_b;
+    return o;
+}
+
+// ------------------------------------------------------------------------------------ workspace
+int ws_get(tts_handle_t h, const char* name, size_t bytes, void** out) {
+    DevBuf& b = h->ws[name];
+    if (b.bytes < bytes) {
+        if (b.p) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipFree(b.p));
+            b.p = nullptr;
+            b.bytes = 0;
+            // pointers baked into the decoder graph may have changed
+            if (h->dec_graph) {
+                hipGraphExecDestroy(h->dec_graph);
+                h->dec_graph = nullptr;
+            }
+        }
+        HIPCHK(h, hipMalloc(&b.p, bytes));
+        b.bytes = bytes;
+    }
+    *out = b.p;
+    return TTS_OK;
+}
+#define WS(h, name, type, count, var)                                             \
+    type* var = nullptr;                                                          \
+    {                                                                             \
+        void* _p = nullptr;                                                       \
+        int _rc = ws_get(h, name, (size_t)(count) * sizeof(type), &_p);           \
+        if (_rc != TTS_OK) return _rc;                                            \
+        var = reinterpret_cast<type*>(_p);                                        \
+    }
+
+// ------------------------------------------------------------------------------------ profiling
+struct ProfScope {
+    tts_handle_t h;
+    int idx = -1;
+    ProfScope(tts_handle_t h_, int stage, int64_t launches) : h(h_) {
+        if (!h->profile) return;
+        ProfSpan s{};
+        if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+        s.stage = stage;
+        s.launches = launches;
+        hipEventRecord(s.a, h->stream);
+        h->spans.push_back(s);
+        idx = (int)h->spans.size() - 1;
+    }
+    ~ProfScope() {
+        if (idx >= 0) hipEventRecord(h->spans[idx].b, h->stream);
+    }
+};
+
+void prof_collect(tts_handle_t h) {
+    hipStreamSynchronize(h->stream);
+    for (auto& s : h->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            h->prof_ms[s.stage] += ms;
+            h->prof_launches[s.stage] += s.launches;
+        }
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
+    }
+    h->spans.clear();
+}
+
+// ------------------------------------------------------------------------------------ GEMM helpers
+GemmGroup dense_group(const float* A, int lda, const float* Wt, const float* bias, float* C, int ldc, int M, int N,
+                      int K, int act) {
+    GemmGroup g;
+    std::memset(&g, 0, sizeof(g));
+    g.A = A; g.Wt = Wt; g.bias = bias; g.C = C;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.T = M; g.Cin = K; g.padl = 0; g.pool = 0;
+    g.ldc = ldc; g.coff = 0; g.act = act; g.epi = EPI_STD;
+    return g;
+}
+
+GemmGroup conv_group(const float* A, int Cin, int ktaps, int T, const float* Wt, const float* bias,
+                     const float* scale, const float* shift, float* C, int ldc, int coff, int M, int N, int act,
+                     int pool) {
+    GemmGroup g;
+    std::memset(&g, 0, sizeof(g));
+    g.A = A; g.Wt = Wt; g.bias = bias; g.scale = scale; g.shift = shift; g.C = C;
+    g.M = M; g.N = N; g.K = ktaps * Cin;
+    g.lda = Cin; g.T = T; g.Cin = Cin; g.padl = (ktaps - 1) / 2; g.pool = pool;
+    g.ldc = ldc; g.coff = coff; g.act = act; g.epi = EPI_STD;
+    return g;
+}
+
+int run_single(tts_handle_t h, const GemmGroup& g) {
+    GemmBatch b;
+    std::memset(&b, 0, sizeof(b));
+    b.g[0] = g;
+    HIPCHK(h, launch_gemm(h->stream, b, 1));
+    return TTS_OK;
+}
+
+// CBHG (reference tacotron/layers.py:448-594) on x [B*T][c_in] -> out [B*T][2H].  Returns launches.
+int run_cbhg(tts_handle_t h, const CbhgWeights& w, const char* tag, const float* x, int B, int T, float* out,
+             int64_t* launches) {
+    const tts_config_t& c = h->cfg;
+    const int M = B * T;
+    const int NB = w.n_banks, NF = w.n_filters;
+    const int U = c.n_highway_units, H = c.n_gru_units;
+    const std::string t(tag);
+    WS(h, (t + ".bank").c_str(), float, (size_t)M * NB * NF, bank);
+    WS(h, (t + ".p1").c_str(), float, (size_t)M * w.proj_filters[0], p1);
+    WS(h, (t + ".p2").c_str(), float, (size_t)M * w.proj_filters[1], p2);
+    WS(h, (t + ".hw0").c_str(), float, (size_t)M * U, hw0);
+    WS(h, (t + ".hw1").c_str(), float, (size_t)M * U, hw1);
+    WS(h, (t + ".xproj").c_str(), float, (size_t)M * 6 * H, xproj);
+
+    // conv bank: one grouped launch, bank k writes channels [k*NF, (k+1)*NF)
+    for (int k0 = 0; k0 < NB; k0 += TTS_GEMM_MAX_GROUPS) {
+        GemmBatch b;
+        std::memset(&b, 0, sizeof(b));
+        const int ng = std::min(TTS_GEMM_MAX_GROUPS, NB - k0);
+        for (int i = 0; i < ng; ++i) {
+            const int k = k0 + i;
+            b.g[i] = conv_group(x, w.c_in, k + 1, T, w.bank_wt[k], w.bank_b[k], w.bank_scale[k], w.bank_shift[k], bank,
+                                NB * NF, k * NF, M, NF, ACT_RELU, 0);
+        }
+        HIPCHK(h, launch_gemm(h->stream, b, ng));
+        ++*launches;
+    }
+    // projection 1: max-pool(2,1,SAME) fused into the loader, conv3 + relu + BN
+    {
+        GemmGroup g = conv_group(bank, NB * NF, 3, T, w.proj_wt[0], w.proj_b[0], w.proj_scale[0], w.proj_shift[0], p1,
+                                 w.proj_filters[0], 0, M, w.proj_filters[0], ACT_RELU, 1);
+        int rc = run_single(h, g);
+        if (rc) return rc;
+        ++*launches;
+    }
+    // projection 2: conv3 + BN (linear) + residual with the CBHG input
+    {
+        GemmGroup g = conv_group(p1, w.proj_filters[0], 3, T, w.proj_wt[1], w.proj_b[1], w.proj_scale[1],
+                                 w.proj_shift[1], p2, w.proj_filters[1], 0, M, w.proj_filters[1], ACT_NONE, 0);
+        g.R = x;
+        g.ldr = w.c_in;
+        int rc = run_single(h, g);
+        if (rc) return rc;
+        ++*launches;
+    }
+    // lifter
+    {
+        int rc = run_single(h, dense_group(p2, w.proj_filters[1], w.lifter_wt, w.lifter_b, hw0, U, M, U,
+                                           w.proj_filters[1], ACT_RELU));
+        if (rc) return rc;
+        ++*launches;
+    }
+    // highway layers (H|T in one GEMM, gate mix in the epilogue), ping-pong buffers
+    float* cur = hw0;
+    float* nxt = hw1;
+    for (size_t l = 0; l < w.hw_wt.size(); ++l) {
+        GemmGroup g = dense_group(cur, U, w.hw_wt[l], w.hw_b[l], nxt, U, M, 2 * U, U, ACT_NONE);
+        g.epi = EPI_HIGHWAY;
+        int rc = run_single(h, g);
+        if (rc) return rc;
+        ++*launches;
+        std::swap(cur, nxt);
+    }
+    // GRU input projections for both directions, then the recurrent kernel
+    {
+        int rc = run_single(h, dense_group(cur, U, w.gru_in_wt, w.gru_in_b, xproj, 6 * H, M, 6 * H, U, ACT_NONE));
+        if (rc) return rc;
+        ++*launches;
+    }
+    HIPCHK(h, launch_bigru(h->stream, xproj, 6 * H, w.gru_rec, out, B, T, H, c.force_cudnn));
+    ++*launches;
+    return TTS_OK;
+}
+
+int check_ready(tts_handle_t h) {
+    if (!h) return TTS_ERR_INVALID;
+    if (!h->finalized) return fail(h, TTS_ERR_NOT_LOADED, "weights not loaded: call tts_finalize_weights first");
+    return TTS_OK;
+}
+
+// ------------------------------------------------------------------------------------ Griffin-Lim
+int gl_prepare(tts_handle_t h, int T, int win, int hop, int n_fft) {
+    if (n_fft != TTS_GL_NFFT) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: only n_fft == 2048 is implemented");
+    if (win < 2 || win > n_fft || hop < 1 || T < 1)
+        return fail(h, TTS_ERR_INVALID, "griffin_lim: need 2 <= win_length <= n_fft, hop_length >= 1, T >= 1");
+    const int ncol = (win + hop - 1) / hop;
+    if (ncol > 8) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: win_length / hop_length > 8 not supported");
+    if ((long long)hop * (T - 1) <= n_fft / 2)
+        return fail(h, TTS_ERR_INVALID, "griffin_lim: signal shorter than n_fft/2 (reflect padding undefined)");
+    auto& g = h->gl;
+    if (!g.configured) {
+        HIPCHK(h, gl_configure());
+        std::vector<float2> t1(1024), t2(1024);
+        for (int k = 0; k < 1024; ++k) {
+            const double a1 = -2.0 * M_PI * k / 1024.0, a2 = -2.0 * M_PI * k / 2048.0;
+            t1[k] = make_float2((float)std::cos(a1), (float)std::sin(a1));
+            t2[k] = make_float2((float)std::cos(a2), (float)std::sin(a2));
+        }
+        HIPCHK(h, hipMalloc(&g.tw1024, 1024 * sizeof(float2)));
+        HIPCHK(h, hipMalloc(&g.tw2048, 1024 * sizeof(float2)));
+        HIPCHK(h, hipMemcpy(g.tw1024, t1.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(g.tw2048, t2.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
+        g.configured = true;
+    }
+    if (g.win == win && g.hop == hop && g.T == T) return TTS_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (g.window) hipFree(g.window);
+    if (g.wss) hipFree(g.wss);
+    g.window = g.wss = nullptr;
+    // periodic hann (scipy get_window('hann', win, fftbins=True)), float64 then float32
+    std::vector<double> wd(win);
+    std::vector<float> wf(win);
+    for (int i = 0; i < win; ++i) {
+        wd[i] = 0.5 - 0.5 * std::cos(2.0 * M_PI * i / win);
+        wf[i] = (float)wd[i];
+    }
+    // librosa window_sumsquare: float32 buffer, sequential += of the padded squared window
+    const size_t n = (size_t)n_fft + (size_t)hop * (T - 1);
+    std::vector<float> wss(n, 0.f);
+    const int lpad = (n_fft - win) / 2;
+    for (int i = 0; i < T; ++i) {
+        const size_t s = (size_t)i * hop;
+        for (int j = 0; j < win; ++j) {
+            const size_t idx = s + lpad + j;
+            if (idx < n) wss[idx] = (float)((double)wss[idx] + wd[j] * wd[j]);
+        }
+    }
+    HIPCHK(h, hipMalloc(&g.window, win * sizeof(float)));
+    HIPCHK(h, hipMalloc(&g.wss, n * sizeof(float)));
+    HIPCHK(h, hipMemcpy(g.window, wf.data(), win * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(g.wss, wss.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    g.win = win;
+    g.hop = hop;
+    g.T = T;
+    return TTS_OK;
+}
+
+// mag_int: internal [B][T][FP]; init_ft: reference-layout U[0,1) numbers or null.
+int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t seed, int B, int T, int n_iter,
+           int win, int hop, int n_fft, float* wav, float* mse) {
+    int rc = gl_prepare(h, T, win, hop, n_fft);
+    if (rc) return rc;
+    const int F = 1 + n_fft / 2, FP = TTS_GL_FP;
+    WS(h, "gl.phase0", float2, (size_t)B * T * FP, ph0);
+    WS(h, "gl.phase1", float2, (size_t)B * T * FP, ph1);
+    GlParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.mag = mag_int;
+    p.window = h->gl.window;
+    p.wss = h->gl.wss;
+    p.tw1024 = h->gl.tw1024;
+    p.tw2048 = h->gl.tw2048;
+    p.T = T; p.FP = FP; p.win = win; p.hop = hop;
+    p.ncol = (win + hop - 1) / hop;
+    p.C = 8 * p.ncol - 2 * (p.ncol - 1);
+    if (p.C > 32) p.C = 32;
+    if (gl_lds_bytes(p) > 160 * 1024) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: chunk does not fit in LDS");
+    const int nchunks = (T + p.C - 1) / p.C;
+    WS(h, "gl.mse_partial", float, (size_t)B * nchunks, msep);
+    HIPCHK(h, launch_phase_init(h->stream, init_ft, seed, ph0, B, F, T, FP));
+    float2* cur = ph0;
+    float2* nxt = ph1;
+    {
+        ProfScope ps(h, ST_GL_ITER, n_iter);
+        for (int it = 0; it < n_iter; ++it) {
+            p.phase_in = cur;
+            p.phase_out = nxt;
+            p.mse_partial = (mse && it == n_iter - 1) ? msep : nullptr;
+            HIPCHK(h, launch_gl_iter(h->stream, p, B, 0));
+            std::swap(cur, nxt);
+        }
+    }
+    if (mse) {
+        if (n_iter > 0) {
+            HIPCHK(h, launch_gl_mse_reduce(h->stream, msep, B, nchunks, (float)((double)F * T), mse));
+        } else {
+            HIPCHK(h, hipMemsetAsync(mse, 0, B * sizeof(float), h->stream));
+        }
+    }
+    {
+        ProfScope ps(h, ST_GL_FINAL, 1);
+        p.phase_in = cur;
+        p.phase_out = nullptr;
+        p.mse_partial = nullptr;
+        p.wav = wav;
+        HIPCHK(h, launch_gl_iter(h->stream, p, B, 1));
+    }
+    return TTS_OK;
+}
+
+}  // namespace
+
+// ======================================================================================== C ABI
+extern "C" {
+
+const char* tts_version(void) { return "sstts_hip 0.1.0 (gfx950)"; }
+
+int tts_default_config(tts_config_t* c) {
+    if (!c) return TTS_ERR_INVALID;
+    std::memset(c, 0, sizeof(*c));
+    c->vocabulary_size = 39;
+    c->embedding_size = 256;
+    c->enc_prenet_units[0] = 256; c->enc_prenet_units[1] = 128;
+    c->enc_n_banks = 16; c->enc_n_filters = 128;
+    c->enc_proj_filters[0] = 128; c->enc_proj_filters[1] = 128;
+    c->post_n_banks = 8; c->post_n_filters = 128;
+    c->post_proj_filters[0] = 256; c->post_proj_filters[1] = 80;
+    c->n_highway_layers = 4; c->n_highway_units = 128; c->n_gru_units = 128;
+    c->dec_prenet_units[0] = 256; c->dec_prenet_units[1] = 128;
+    c->n_attention_units = 256; c->n_decoder_gru_units = 256; c->n_decoder_gru_layers = 2;
+    c->n_mels = 80; c->reduction = 5; c->n_fft = 2048; c->force_cudnn = 0;
+    return TTS_OK;
+}
+
+int tts_create(const tts_config_t* cfg, int device_id, tts_handle_t* out) {
+    if (!cfg || !out) return fail(nullptr, TTS_ERR_INVALID, "tts_create: null argument");
+    const tts_config_t& c = *cfg;
+    // constraints of the kernels
+    auto mult = [](int v, int m) { return v > 0 && v % m == 0; };
+    if (c.n_gru_units != 128 || c.n_highway_units != 128)
+        return fail(nullptr, TTS_ERR_UNSUPPORTED, "n_gru_units and n_highway_units must be 128");
+    if (c.n_attention_units != 256 || c.n_decoder_gru_units != 256 || 2 * c.n_gru_units != 256)
+        return fail(nullptr, TTS_ERR_UNSUPPORTED, "attention/decoder units must be 256");
+    if (c.n_decoder_gru_layers < 1 || c.n_decoder_gru_layers > 4)
+        return fail(nullptr, TTS_ERR_UNSUPPORTED, "1..4 decoder GRU layers supported");
+    if (!mult(c.n_mels, 16) || !mult(c.embedding_size, 16) || !mult(c.enc_prenet_units[0], 16) ||
+        !mult(c.enc_prenet_units[1], 16) || !mult(c.dec_prenet_units[0], 16) || !mult(c.dec_prenet_units[1], 16) ||
+        !mult(c.enc_n_filters, 32) || !mult(c.post_n_filters, 32) || !mult(c.enc_proj_filters[0], 4) ||
+        !mult(c.post_proj_filters[0], 4))
+        return fail(nullptr, TTS_ERR_UNSUPPORTED, "layer widths must be multiples of 16 (filters: 32)");
+    if (c.enc_proj_filters[1] != c.enc_prenet_units[1] || c.post_proj_filters[1] != c.n_mels)
+        return fail(nullptr, TTS_ERR_INVALID, "last projection must match the CBHG input width (residual)");
+    if (c.enc_n_banks < 1 || c.post_n_banks < 1 || c.reduction < 1 || c.vocabulary_size < 1 || c.n_highway_layers < 0)
+        return fail(nullptr, TTS_ERR_INVALID, "bad counts");
+    if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, TTS_ERR_HIP, "hipSetDevice failed");
+    auto h = new tts_handle_s();
+    h->cfg = c;
+    h->device = device_id;
+    if (hipStreamCreate(&h->stream) != hipSuccess) {
+        delete h;
+        return fail(nullptr, TTS_ERR_HIP, "hipStreamCreate failed");
+    }
+    h->own_stream = true;
+    build_manifest(h);
+    *out = h;
+    return TTS_OK;
+}
+
+int tts_destroy(tts_handle_t h) {
+    if (!h) return TTS_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    for (auto& s : h->spans) {
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
+    }
+    if (h->dec_graph) hipGraphExecDestroy(h->dec_graph);
+    for (auto& kv : h->ws)
+        if (kv.second.p) hipFree(kv.second.p);
+    if (h->arena) hipFree(h->arena);
+    if (h->gl.window) hipFree(h->gl.window);
+    if (h->gl.wss) hipFree(h->gl.wss);
+    if (h->gl.tw1024) hipFree(h->gl.tw1024);
+    if (h->gl.tw2048) hipFree(h->gl.tw2048);
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    delete h;
+    return TTS_OK;
+}
+
+const char* tts_last_error(tts_handle_t h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int tts_set_stream(tts_handle_t h, void* s) {
+    if (!h) return TTS_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->dec_graph) {
+        hipGraphExecDestroy(h->dec_graph);
+        h->dec_graph = nullptr;
+    }
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    if (s) {
+        h->stream = reinterpret_cast<hipStream_t>(s);
+        h->own_stream = false;
+    } else {
+        HIPCHK(h, hipStreamCreate(&h->stream));
+        h->own_stream = true;
+    }
+    return TTS_OK;
+}
+
+int tts_set_option(tts_handle_t h, const char* key, int value) {
+    if (!h || !key) return TTS_ERR_INVALID;
+    if (!std::strcmp(key, "use_graph")) h->use_graph = value;
+    else if (!std::strcmp(key, "profile")) h->profile = value;
+    else return fail(h, TTS_ERR_INVALID, std::string("unknown option ") + key);
+    return TTS_OK;
+}
+
+int tts_synchronize(tts_handle_t h) {
+    if (!h) return TTS_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TTS_OK;
+}
+
+int tts_manifest_size(tts_handle_t h) { return h ? (int)h->manifest.size() : TTS_ERR_INVALID; }
+
+int tts_manifest_entry(tts_handle_t h, int i, const char** name, int64_t shape[4], int* ndim) {
+    if (!h || i < 0 || i >= (int)h->manifest.size()) return TTS_ERR_INVALID;
+    const auto& e = h->manifest[i];
+    if (name) *name = e.name.c_str();
+    if (ndim) *ndim = (int)e.shape.size();
+    if (shape)
+        for (size_t d = 0; d < 4; ++d) shape[d] = d < e.shape.size() ? e.shape[d] : 1;
+    return TTS_OK;
+}
+
+int tts_set_weight(tts_handle_t h, const char* name, const float* data, const int64_t* shape, int ndim) {
+    if (!h || !name || !data || !shape) return TTS_ERR_INVALID;
+    for (const auto& e : h->manifest) {
+        if (e.name != name) continue;
+        if ((int)e.shape.size() != ndim) return fail(h, TTS_ERR_INVALID, std::string("rank mismatch for ") + name);
+        for (int d = 0; d < ndim; ++d)
+            if (e.shape[d] != shape[d]) return fail(h, TTS_ERR_INVALID, std::string("shape mismatch for ") + name);
+        h->host_w[e.name].assign(data, data + e.numel());
+        h->finalized = false;
+        return TTS_OK;
+    }
+    return fail(h, TTS_ERR_INVALID, std::string("unknown weight ") + name);
+}
+
+int tts_load_weights_blob(tts_handle_t h, const float* blob, size_t n) {
+    if (!h || !blob) return TTS_ERR_INVALID;
+    size_t total = 0;
+    for (const auto& e : h->manifest) total += e.numel();
+    if (total != n)
+        return fail(h, TTS_ERR_INVALID,
+                    "blob has " + std::to_string(n) + " floats, manifest needs " + std::to_string(total));
+    size_t off = 0;
+    for (const auto& e : h->manifest) {
+        h->host_w[e.name].assign(blob + off, blob + off + e.numel());
+        off += e.numel();
+    }
+    h->finalized = false;
+    return TTS_OK;
+}
+
+int tts_finalize_weights(tts_handle_t h) {
+    if (!h) return TTS_ERR_INVALID;
+    for (const auto& e : h->manifest)
+        if (!h->host_w.count(e.name)) return fail(h, TTS_ERR_NOT_LOADED, "missing weight " + e.name);
+    HIPCHK(h, hipSetDevice(h->device));
+    const tts_config_t& c = h->cfg;
+    const bool cudnn = c.force_cudnn != 0;
+    Packer p;
+    const size_t o_emb = pack_copy(p, W(h, "encoder/embedding").data(), (size_t)c.vocabulary_size * c.embedding_size);
+    size_t o_epw[2], o_epb[2];
+    int n_in = c.embedding_size;
+    for (int i = 0; i < 2; ++i) {
+        const std::string s = "encoder/pre_net/" + std::to_string(i + 1) + "-FC-" + std::to_string(c.enc_prenet_units[i]);
+        o_epw[i] = pack_transposed(p, W(h, s + "/kernel").data(), n_in, c.enc_prenet_units[i]);
+        o_epb[i] = pack_copy(p, W(h, s + "/bias").data(), c.enc_prenet_units[i]);
+        n_in = c.enc_prenet_units[i];
+    }
+    const CbhgOffsets o_enc =
+        pack_cbhg(h, p, "encoder", n_in, c.enc_n_banks, c.enc_n_filters, c.enc_proj_filters, cudnn);
+    const int mem = 2 * c.n_gru_units, att = c.n_attention_units, U = c.n_decoder_gru_units;
+    const size_t o_mem = pack_transposed(p, W(h, "decoder2/memory_layer/kernel").data(), mem, att);
+    size_t o_dpw[2], o_dpb[2];
+    n_in = c.n_mels + att;
+    for (int i = 0; i < 2; ++i) {
+        const std::string s = std::string(kAtt) + "/pre_net/" + std::to_string(i + 1) + "-FC-" +
+                              std::to_string(c.dec_prenet_units[i]);
+        o_dpw[i] = pack_transposed(p, W(h, s + "/kernel").data(), n_in, c.dec_prenet_units[i]);
+        o_dpb[i] = pack_copy(p, W(h, s + "/bias").data(), c.dec_prenet_units[i]);
+        n_in = c.dec_prenet_units[i];
+    }
+    const GruOffsets o_ag = pack_dec_gru(h, p, std::string(kAtt) + "/gru_cell", n_in, att, cudnn);
+    const size_t o_al = pack_transposed(p, W(h, std::string(kAtt) + "/attention_layer/kernel").data(), att + mem, att);
+    GruOffsets o_dg[4];
+    for (int i = 0; i < c.n_decoder_gru_layers; ++i)
+        o_dg[i] = pack_dec_gru(h, p, std::string(kMrc) + "/cell_" + std::to_string(i + 1) + "/gru_cell",
+                               i == 0 ? att : U, U, cudnn);
+    const int OUT = c.n_mels * c.reduction;
+    const size_t o_ow = pack_transposed(p, W(h, "decoder2/decoder/output_projection_wrapper/kernel").data(), U, OUT);
+    const size_t o_ob = pack_copy(p, W(h, "decoder2/decoder/output_projection_wrapper/bias").data(), OUT);
+    const CbhgOffsets o_post =
+        pack_cbhg(h, p, "post_process", c.n_mels, c.post_n_banks, c.post_n_filters, c.post_proj_filters, cudnn);
+    const int F = 1 + c.n_fft / 2;
+    const size_t o_dw = pack_transposed(p, W(h, "dense/kernel").data(), mem, F);
+    const size_t o_db = pack_copy(p, W(h, "dense/bias").data(), F);
+    const size_t o_zero = p.alloc(1024);
+
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->dec_graph) {
+        hipGraphExecDestroy(h->dec_graph);
+        h->dec_graph = nullptr;
+    }
+    if (h->arena) hipFree(h->arena);
+    h->arena = nullptr;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->arena), p.host.size() * sizeof(float)));
+    h->arena_floats = p.host.size();
+    HIPCHK(h, hipMemcpy(h->arena, p.host.data(), p.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    const float* base = h->arena;
+    h->embedding = base + o_emb;
+    for (int i = 0; i < 2; ++i) {
+        h->enc_pre_wt[i] = base + o_epw[i];
+        h->enc_pre_b[i] = base + o_epb[i];
+    }
+    h->enc = CbhgWeights();
+    h->post = CbhgWeights();
+    bind_cbhg(h->enc, o_enc, base, c.enc_prenet_units[1], c.enc_n_banks, c.enc_n_filters, c.enc_proj_filters);
+    bind_cbhg(h->post, o_post, base, c.n_mels, c.post_n_banks, c.post_n_filters, c.post_proj_filters);
+    h->mem_wt = base + o_mem;
+    DecoderWeights& d = h->dec;
+    std::memset(&d, 0, sizeof(d));
+    d.prenet1_wt = base + o_dpw[0]; d.prenet1_b = base + o_dpb[0];
+    d.prenet2_wt = base + o_dpw[1]; d.prenet2_b = base + o_dpb[1];
+    d.att_gru = {base + o_ag.gates_wt, base + o_ag.gates_b, base + o_ag.cand_wt, base + o_ag.cand_b};
+    d.attn_layer_wt = base + o_al;
+    for (int i = 0; i < c.n_decoder_gru_layers; ++i)
+        d.gru[i] = {base + o_dg[i].gates_wt, base + o_dg[i].gates_b, base + o_dg[i].cand_wt, base + o_dg[i].cand_b};
+    d.out_wt = base + o_ow; d.out_b = base + o_ob;
+    d.n_layers = c.n_decoder_gru_layers; d.att_units = att; d.dec_units = U; d.mem_units = mem;
+    d.n_mels = c.n_mels; d.reduction = c.reduction;
+    d.prenet1_units = c.dec_prenet_units[0]; d.prenet2_units = c.dec_prenet_units[1];
+    h->dense_wt = base + o_dw;
+    h->dense_b = base + o_db;
+    h->zeros = base + o_zero;
+    h->dec_key = {};
+    h->host_w.clear();   // the packed copy on device is the only one kept
+    h->finalized = true;
+    return TTS_OK;
+}
+
+int tts_malloc(void** dptr, size_t bytes) {
+    if (!dptr) return TTS_ERR_INVALID;
+    return hipMalloc(dptr, bytes ? bytes : 4) == hipSuccess ? TTS_OK : TTS_ERR_HIP;
+}
+int tts_free(void* dptr) { return hipFree(dptr) == hipSuccess ? TTS_OK : TTS_ERR_HIP; }
+int tts_memcpy_h2d(tts_handle_t h, void* dst, const void* src, size_t bytes) {
+    if (!h) return TTS_ERR_INVALID;
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TTS_OK;
+}
+int tts_memcpy_d2h(tts_handle_t h, void* dst, const void* src, size_t bytes) {
+    if (!h) return TTS_ERR_INVALID;
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TTS_OK;
+}
+int tts_memset(tts_handle_t h, void* dst, int value, size_t bytes) {
+    if (!h) return TTS_ERR_INVALID;
+    HIPCHK(h, hipMemsetAsync(dst, value, bytes, h->stream));
+    return TTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------- stages
+int tts_encoder_forward(tts_handle_t h, const int32_t* ids, int B, int Ts, float* memory) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!ids || !memory || B < 1 || Ts < 1) return fail(h, TTS_ERR_INVALID, "encoder_forward: bad arguments");
+    const tts_config_t& c = h->cfg;
+    const int M = B * Ts;
+    WS(h, "enc.pre1", float, (size_t)M * c.enc_prenet_units[0], pre1);
+    WS(h, "enc.pre2", float, (size_t)M * c.enc_prenet_units[1], pre2);
+    int64_t launches = 0;
+    ProfScope ps(h, ST_ENCODER, 0);
+    {   // embedding lookup fused into the first pre-net GEMM (row gather)
+        GemmGroup g = dense_group(h->embedding, c.embedding_size, h->enc_pre_wt[0], h->enc_pre_b[0], pre1,
+                                  c.enc_prenet_units[0], M, c.enc_prenet_units[0], c.embedding_size, ACT_RELU);
+        g.gather = ids;
+        if ((rc = run_single(h, g))) return rc;
+    }
+    if ((rc = run_single(h, dense_group(pre1, c.enc_prenet_units[0], h->enc_pre_wt[1], h->enc_pre_b[1], pre2,
+                                        c.enc_prenet_units[1], M, c.enc_prenet_units[1], c.enc_prenet_units[0],
+                                        ACT_RELU))))
+        return rc;
+    launches += 2;
+    if ((rc = run_cbhg(h, h->enc, "enc", pre2, B, Ts, memory, &launches))) return rc;
+    if (ps.idx >= 0) h->spans[ps.idx].launches = launches;
+    return TTS_OK;
+}
+
+int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int n_steps, float* mel,
+                        float* alignments) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!memory || !mel || B < 1 || Ts < 1 || n_steps < 1) return fail(h, TTS_ERR_INVALID, "decoder_forward: bad arguments");
+    const tts_config_t& c = h->cfg;
+    const int A = c.n_attention_units, U = c.n_decoder_gru_units, mem = 2 * c.n_gru_units;
+    const int NL = c.n_decoder_gru_layers;
+    WS(h, "dec.keys", float, (size_t)B * Ts * A, keys);
+    const size_t state_floats = (size_t)B * (A + A + (size_t)NL * U);
+    WS(h, "dec.state", float, state_floats, state);
+    WS(h, "dec.tmp", float, (size_t)B * (c.dec_prenet_units[0] + c.dec_prenet_units[1] + 8 * (size_t)U), tmp);
+    DecoderScratch sc;
+    std::memset(&sc, 0, sizeof(sc));
+    sc.state = state;
+    sc.state_bytes = state_floats * sizeof(float);
+    sc.att = state;
+    sc.h_att = state + (size_t)B * A;
+    for (int l = 0; l < NL; ++l) sc.h_dec[l] = state + (size_t)B * (2 * A + (size_t)l * U);
+    float* t = tmp;
+    sc.p1 = t; t += (size_t)B * c.dec_prenet_units[0];
+    sc.p2 = t; t += (size_t)B * c.dec_prenet_units[1];
+    sc.rh = t; t += (size_t)B * U;
+    sc.u = t; t += (size_t)B * U;
+    sc.hh = t; t += (size_t)B * U;
+    sc.xi = t; t += (size_t)B * U;
+    sc.ctx = t; t += (size_t)B * U;
+    sc.y0 = t; t += (size_t)B * U;
+    sc.y1 = t; t += (size_t)B * U;
+    sc.zeros = h->zeros;
+
+    const int64_t per_step = 2 + 2 + 1 + 1 + 2 * NL + 1;
+    ProfScope ps(h, ST_DECODER, 1 + per_step * n_steps);
+    // keys = memory_layer(memory), no bias (LuongAttention; values stay the raw memory)
+    if ((rc = run_single(h, dense_group(memory, mem, h->mem_wt, nullptr, keys, A, B * Ts, A, mem, ACT_NONE)))) return rc;
+
+    if (!h->use_graph) {
+        HIPCHK(h, decoder_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, mel, alignments, c.force_cudnn));
+        return TTS_OK;
+    }
+    auto& k = h->dec_key;
+    if (!h->dec_graph || k.memory != memory || k.mel != mel || k.align != alignments || k.B != B || k.Ts != Ts ||
+        k.n_steps != n_steps) {
+        if (h->dec_graph) {
+            hipGraphExecDestroy(h->dec_graph);
+            h->dec_graph = nullptr;
+        }
+        hipGraph_t graph = nullptr;
+        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e = decoder_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, mel, alignments, c.force_cudnn);
+        hipError_t e2 = hipStreamEndCapture(h->stream, &graph);
+        if (e != hipSuccess || e2 != hipSuccess) {
+            if (graph) hipGraphDestroy(graph);
+            h->err = std::string("decoder graph capture failed: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+            return TTS_ERR_HIP;
+        }
+        e = hipGraphInstantiate(&h->dec_graph, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+            h->dec_graph = nullptr;
+            h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
+            return TTS_ERR_HIP;
+        }
+        k.memory = memory; k.mel = mel; k.align = alignments; k.B = B; k.Ts = Ts; k.n_steps = n_steps;
+    }
+    HIPCHK(h, hipGraphLaunch(h->dec_graph, h->stream));
+    return TTS_OK;
+}
+
+int tts_postnet_forward(tts_handle_t h, const float* mel, int B, int T, float* linear) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!mel || !linear || B < 1 || T < 1) return fail(h, TTS_ERR_INVALID, "postnet_forward: bad arguments");
+    const tts_config_t& c = h->cfg;
+    const int M = B * T, H2 = 2 * c.n_gru_units, F = 1 + c.n_fft / 2;
+    WS(h, "post.gru", float, (size_t)M * H2, gru);
+    int64_t launches = 0;
+    ProfScope ps(h, ST_POSTNET, 0);
+    if ((rc = run_cbhg(h, h->post, "post", mel, B, T, gru, &launches))) return rc;
+    if ((rc = run_single(h, dense_group(gru, H2, h->dense_wt, h->dense_b, linear, F, M, F, H2, ACT_NONE)))) return rc;
+    ++launches;
+    if (ps.idx >= 0) h->spans[ps.idx].launches = launches;
+    return TTS_OK;
+}
+
+static int denorm_check(tts_handle_t h, float ref_db, float max_db) {
+    // reference audio/conversion.py:47-49: AssertionError when any dB value < -100.  The lowest
+    // value inv_normalize_decibel can produce is ref - (|ref| + |max|) (clip(x) == 0).
+    if (ref_db - (std::fabs(ref_db) + std::fabs(max_db)) < -100.0f)
+        return fail(h, TTS_ERR_DB_RANGE,
+                    "\"conversion.decibel_to_magnitude\" was asked to convert a dB value smaller -100 dB.");
+    return TTS_OK;
+}
+
+int tts_denorm_power(tts_handle_t h, const float* linear, int B, int T, int F, float ref_db, float max_db, float power,
+                     float* mag) {
+    if (!h || !linear || !mag || B < 1 || T < 1 || F < 1) return fail(h, TTS_ERR_INVALID, "denorm_power: bad arguments");
+    int rc = denorm_check(h, ref_db, max_db);
+    if (rc) return rc;
+    const int FP = (F + 3) & ~3;
+    WS(h, "denorm.tmp", float, (size_t)B * T * FP, tmp);
+    ProfScope ps(h, ST_DENORM, 2);
+    HIPCHK(h, launch_denorm_power(h->stream, linear, tmp, (size_t)B * T, F, FP, ref_db, max_db, power));
+    HIPCHK(h, launch_tf_to_ft(h->stream, tmp, mag, B, F, T, FP));
+    return TTS_OK;
+}
+
+int tts_griffin_lim(tts_handle_t h, const float* mag, const float* init_phase, uint64_t seed, int B, int T, int n_iter,
+                    int win_length, int hop_length, int n_fft, float* wav, float* mse) {
+    if (!h || !mag || !wav || B < 1 || n_iter < 0) return fail(h, TTS_ERR_INVALID, "griffin_lim: bad arguments");
+    int rc = gl_prepare(h, T, win_length, hop_length, n_fft);
+    if (rc) return rc;
+    const int F = 1 + n_fft / 2, FP = TTS_GL_FP;
+    WS(h, "gl.mag", float, (size_t)B * T * FP, magi);
+    HIPCHK(h, launch_mag_ft_to_tf(h->stream, mag, magi, B, F, T, FP));
+    return gl_run(h, magi, init_phase, seed, B, T, n_iter, win_length, hop_length, n_fft, wav, mse);
+}
+
+int tts_peak_normalize(tts_handle_t h, float* wav, int B, int n) {
+    if (!h || !wav || B < 1 || n < 1) return fail(h, TTS_ERR_INVALID, "peak_normalize: bad arguments");
+    HIPCHK(h, launch_peak_normalize(h->stream, wav, B, n));
+    return TTS_OK;
+}
+
+int tts_stft_magnitude(tts_handle_t h, const float*, int, int, int, int, int, float, float*) {
+    return fail(h, TTS_ERR_UNSUPPORTED, "stft_magnitude: not implemented yet");
+}
+int tts_mel_spectrogram(tts_handle_t h, const float*, int, int, int, int, int, float, float, float*) {
+    return fail(h, TTS_ERR_UNSUPPORTED, "mel_spectrogram: not implemented yet");
+}
+
+int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_synth_params_t* sp,
+                   const float* init_phase, float* wav, float* mel_out, float* align_out, float* linear_out) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!ids || !sp || !wav) return fail(h, TTS_ERR_INVALID, "synthesize: bad arguments");
+    const tts_config_t& c = h->cfg;
+    const int T = sp->n_steps * c.reduction;
+    const int F = 1 + c.n_fft / 2, FP = TTS_GL_FP;
+    if ((rc = denorm_check(h, sp->ref_db, sp->max_db))) return rc;
+    if ((rc = gl_prepare(h, T, sp->win_length, sp->hop_length, c.n_fft))) return rc;
+    WS(h, "syn.memory", float, (size_t)B * Ts * 2 * c.n_gru_units, memory);
+    float* mel = mel_out;
+    if (!mel) {
+        WS(h, "syn.mel", float, (size_t)B * T * c.n_mels, melb);
+        mel = melb;
+    }
+    float* linear = linear_out;
+    if (!linear) {
+        WS(h, "syn.linear", float, (size_t)B * T * F, linb);
+        linear = linb;
+    }
+    WS(h, "gl.mag", float, (size_t)B * T * FP, magi);
+    if ((rc = tts_encoder_forward(h, ids, B, Ts, memory))) return rc;
+    if ((rc = tts_decoder_forward(h, memory, B, Ts, sp->n_steps, mel, align_out))) return rc;
+    if ((rc = tts_postnet_forward(h, mel, B, T, linear))) return rc;
+    {
+        ProfScope ps(h, ST_DENORM, 1);
+        HIPCHK(h, launch_denorm_power(h->stream, linear, magi, (size_t)B * T, F, FP, sp->ref_db, sp->max_db, sp->power));
+    }
+    if ((rc = gl_run(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav,
+                     nullptr)))
+        return rc;
+    if (sp->peak_normalize) HIPCHK(h, launch_peak_normalize(h->stream, wav, B, sp->hop_length * (T - 1)));
+    return TTS_OK;
+}
+
+int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* bytes) {
+    if (!h || !name) return TTS_ERR_INVALID;
+    auto it = h->ws.find(name);
+    if (it == h->ws.end()) return fail(h, TTS_ERR_INVALID, std::string("no workspace buffer ") + name);
+    if (dptr) *dptr = it->second.p;
+    if (bytes) *bytes = it->second.bytes;
+    return TTS_OK;
+}
+
+int tts_profile_reset(tts_handle_t h) {
+    if (!h) return TTS_ERR_INVALID;
+    prof_collect(h);
+    for (int i = 0; i < ST_COUNT; ++i) {
+        h->prof_ms[i] = 0;
+        h->prof_launches[i] = 0;
+    }
+    return TTS_OK;
+}
+
+int tts_profile_get(tts_handle_t h, const char* stage, float* ms_total, int64_t* launches) {
+    if (!h || !stage) return TTS_ERR_INVALID;
+    prof_collect(h);
+    for (int i = 0; i < ST_COUNT; ++i)
+        if (!std::strcmp(stage, kStageNames[i])) {
+            if (ms_total) *ms_total = (float)h->prof_ms[i];
+            if (launches) *launches = h->prof_launches[i];
+            return TTS_OK;
+        }
+    return fail(h, TTS_ERR_INVALID, std::string("unknown stage ") + stage);
+}
+
+}  // extern "C"

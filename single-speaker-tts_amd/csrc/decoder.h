@@ -1,0 +1,57 @@
+// Decoder-loop internals shared between decoder.hip and api.hip.
+#pragma once
+#include "tts_common.h"
+
+namespace tts {
+
+enum DecEpi { DEC_EPI_ACT = 0, DEC_EPI_GRU_GATES = 1, DEC_EPI_GRU_CAND = 2, DEC_EPI_GRU_CUDNN_PRE = 3 };
+
+// out[B][N] = epi( [a0 | a1][B][K] . Wt[N][K]^T + bias ); the A operand is the concatenation of
+// two row-major segments: columns [0,k0) from a0 (row stride lda0), [k0,K) from a1 (lda1).
+struct DecGemm {
+    const float* a0;
+    const float* a1;
+    const float* Wt;
+    const float* bias;
+    float* out;
+    float* h;            // GRU state [B][U]
+    float* rh;           // r*h (GRUCell) or r (cudnn)
+    float* u;
+    float* hh;
+    float* xi;
+    const float* resid;
+    int lda0, lda1, k0;
+    int B, N, K;
+    int ldo, U, act, epi;
+};
+
+struct DecoderWeights {
+    struct Gru {
+        const float* gates_wt;  // [2U][in+U]  (cudnn: [4U][in+U] = r|u|hh|xi zero-padded)
+        const float* gates_b;
+        const float* cand_wt;   // [U][in+U]   (GRUCell only)
+        const float* cand_b;
+    };
+    const float* prenet1_wt; const float* prenet1_b;   // [P1][n_mels + A]
+    const float* prenet2_wt; const float* prenet2_b;   // [P2][P1]
+    Gru att_gru;
+    const float* attn_layer_wt;                        // [A][A + mem]
+    Gru gru[4];
+    const float* out_wt; const float* out_b;           // [r*n_mels][U]
+    int n_layers, att_units, dec_units, mem_units, n_mels, reduction, prenet1_units, prenet2_units;
+};
+
+struct DecoderScratch {
+    float* state;        // att | h_att | h_dec[0..n_layers) contiguous, zeroed per call
+    size_t state_bytes;
+    float* att; float* h_att; float* h_dec[4];
+    float* p1; float* p2; float* rh; float* u; float* hh; float* xi; float* ctx; float* y0; float* y1;
+    const float* zeros;  // >= n_mels zero floats
+};
+
+// Enqueues the whole n_steps loop on stream s (capturable: no syncs, no allocations).
+hipError_t decoder_enqueue(hipStream_t s, const DecoderWeights& w, const DecoderScratch& sc,
+                           const float* memory, const float* keys, int B, int Ts, int n_steps,
+                           float* mel, float* align, int cudnn);
+
+}  // namespace tts

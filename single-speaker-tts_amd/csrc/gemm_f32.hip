@@ -1,0 +1,186 @@
+// fp32 MFMA GEMM with an implicit-im2col A loader and fused epilogues (gfx950).
+//
+// Covers every dense contraction of the two CBHG stacks: reference tacotron/layers.py
+//   wrapped_dense  :96-111   (pre-net, lifter, highway H|T, final Dense; GRU input projections)
+//   conv1d 'SAME'  :361-367, :432-437 (conv bank k=1..K and the two k=3 projections)
+//   batch_norm     :380-383, :440-443 (folded to a per-channel affine, applied AFTER the relu)
+//   max_pooling1d  :518-521  (fused into the A loader of the first projection: pool=1)
+//   highway        :241-258  (H|T share one GEMM; gate mix in the epilogue)
+//
+// Tile 128x128x32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x2_f32
+// accumulators.  Operands are staged global -> registers -> LDS ([row][32+4] floats, b128
+// conflict-free) with the next tile's global loads in flight during the MFMAs.
+// The k index inside a tile is permuted (lane half h of MFMA step (q,j) uses k = 8q+4h+j) so
+// that each lane fetches its 4 consecutive k values with one ds_read_b128 for both operands.
+#include "tts_common.h"
+
+namespace tts {
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LDS_LD (BK + 4)
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
+    const GemmGroup& g = batch.g[blockIdx.z];
+    const int M = g.M, N = g.N, K = g.K;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    if (n0 >= N) return;
+
+    __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- staging assignment: 4 float4 of A and 4 of B per thread per tile
+    // idx = tid + 256*i -> row = idx >> 3 (0..127), kq = idx & 7 (float4 column)
+    const float* a_row[4];
+    int a_t[4];         // time index of the row inside its sequence (conv masking)
+    bool a_ok[4];
+    const float* b_row[4];
+    bool b_ok[4];
+    const int kq = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const int m = m0 + row;
+        a_ok[i] = m < M;
+        const int mm = a_ok[i] ? m : 0;
+        a_t[i] = mm % g.T;
+        if (g.gather) {
+            a_row[i] = g.A + (size_t)g.gather[mm] * g.lda;
+        } else {
+            a_row[i] = g.A + ((ptrdiff_t)mm - g.padl) * (ptrdiff_t)g.lda;
+        }
+        const int n = n0 + row;
+        b_ok[i] = n < N;
+        b_row[i] = g.Wt + (size_t)(b_ok[i] ? n : 0) * K;
+    }
+
+    float4 ra[4], rb[4];
+    auto load_tile = [&](int kt) {
+        const int kk = kt + 4 * kq;
+        const bool kin = kk < K;
+        const int tap = kk / g.Cin;  // all four floats share the tap (Cin % 4 == 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int ts = a_t[i] - g.padl + tap;
+            if (a_ok[i] && kin && ts >= 0 && ts < g.T) {
+                v = ld4(a_row[i] + kk);
+                if (g.pool && ts + 1 < g.T) v = max4(v, ld4(a_row[i] + kk + g.lda));
+            }
+            ra[i] = v;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_ok[i] && kin) w = ld4(b_row[i] + kk);
+            rb[i] = w;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            *reinterpret_cast<float4*>(&As[row * LDS_LD + 4 * kq]) = ra[i];
+            *reinterpret_cast<float4*>(&Bs[row * LDS_LD + 4 * kq]) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    for (int kt = 0; kt < K; kt += BK) {
+        store_tile();
+        __syncthreads();
+        if (kt + BK < K) load_tile(kt + BK);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *reinterpret_cast<const float4*>(&As[(wm * 64 + t * 32 + li) * LDS_LD + 8 * q + 4 * lh]);
+                b[t] = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + t * 32 + li) * LDS_LD + 8 * q + 4 * lh]);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D map of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (g.epi == EPI_HIGHWAY) {
+        // Packed columns: every 64-column span holds 32 H units then the same 32 T units, so a
+        // lane owns H (tn=0) and T (tn=1) of one unit.  out = relu(h)*sig(t) + x*(1-sig(t)).
+        const int span = (n0 + wn * 64) >> 6;
+        const int unit = span * 32 + li;
+        const int nh = n0 + wn * 64 + li;
+        // N (= 2 * units) is a multiple of 64 by construction of the packing.
+        const float bh = g.bias ? g.bias[nh] : 0.f;
+        const float bt = g.bias ? g.bias[nh + 32] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < M) {
+                    const float hh = fmaxf(acc[tm][0][r] + bh, 0.f);
+                    const float tt = sigmoidf_(acc[tm][1][r] + bt);
+                    const float x = g.A[(size_t)m * g.lda + unit];
+                    g.C[(size_t)m * g.ldc + g.coff + unit] = hh * tt + x * (1.0f - tt);
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int n = n0 + wn * 64 + tn * 32 + li;
+        if (n >= N) continue;
+        const float bv = g.bias ? g.bias[n] : 0.f;
+        const float sc = g.scale ? g.scale[n] : 1.f;
+        const float sh = g.scale ? g.shift[n] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < M) {
+                    float v = apply_act(acc[tm][tn][r] + bv, g.act);
+                    v = v * sc + sh;
+                    if (g.R) v += g.R[(size_t)m * g.ldr + n];
+                    g.C[(size_t)m * g.ldc + g.coff + n] = v;
+                }
+            }
+    }
+}
+
+hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups) {
+    int max_n = 0;
+    for (int i = 0; i < n_groups; ++i) max_n = b.g[i].N > max_n ? b.g[i].N : max_n;
+    dim3 grid((b.g[0].M + BM - 1) / BM, (max_n + BN - 1) / BN, n_groups);
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+
+}  // namespace tts

@@ -1,0 +1,37 @@
+// Griffin-Lim / audio kernel launchers shared between griffin_lim.hip and api.hip.
+#pragma once
+#include "tts_common.h"
+
+namespace tts {
+
+#define TTS_GL_FP 1028      // padded row length of the frame-major spectra (F = 1025)
+#define TTS_GL_NFFT 2048
+
+struct GlParams {
+    const float* mag;        // [B][T][FP]
+    const float2* phase_in;  // [B][T][FP] unit phasors
+    float2* phase_out;       // [B][T][FP]       (iteration)
+    float* wav;              // [B][hop*(T-1)]   (final iSTFT)
+    float* mse_partial;      // [B][nchunks] or null
+    const float* window;     // [win] periodic hann
+    const float* wss;        // [n_fft + hop*(T-1)] window sum-square (librosa window_sumsquare)
+    const float2* tw1024;    // exp(-2 pi i k / 1024), k < 1024
+    const float2* tw2048;    // exp(-2 pi i k / 2048), k < 1024
+    int T, FP, win, hop;
+    int C;                   // frames owned per workgroup
+    int ncol;                // ceil(win / hop): overlap-add colouring rounds, halo = ncol - 1
+};
+
+size_t gl_lds_bytes(const GlParams& p);
+hipError_t gl_configure();
+hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int B, int final_istft);
+hipError_t launch_gl_mse_reduce(hipStream_t s, const float* partial, int B, int nchunks, float denom, float* mse);
+hipError_t launch_mag_ft_to_tf(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP);
+hipError_t launch_tf_to_ft(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP);
+hipError_t launch_phase_init(hipStream_t s, const float* init_ft, uint64_t seed, void* out, int B, int F, int T,
+                             int FP);
+hipError_t launch_denorm_power(hipStream_t s, const float* lin, float* mag, size_t rows, int F, int FP,
+                               float ref_db, float max_db, float power);
+hipError_t launch_peak_normalize(hipStream_t s, float* wav, int B, int n);
+
+}  // namespace tts

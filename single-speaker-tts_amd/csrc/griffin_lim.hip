@@ -1,0 +1,502 @@
+// Griffin-Lim phase reconstruction, STFT analysis and the spectrogram de-normalisation (gfx950).
+//
+// Replaces, batched and on device:
+//   griffin_lim_v2 / spectrogram_to_wav   reference audio/synthesis.py:43-125, 5-40
+//     (librosa.istft + librosa.stft per iteration, a per-frame Python loop in the reference)
+//   inv_normalize_decibel / decibel_to_magnitude / ** power
+//                                          reference audio/conversion.py:81-102, 32-53,
+//                                          tacotron/inference.py:93-101, 175
+//   librosa.output.write_wav(norm=True)    reference audio/io.py:53 (peak normalisation)
+//   linear_scale_spectrogram / mel         reference audio/features.py:5-86, 116-145
+//
+// Internal layout: frame-major.  mag [B][T][FP] float, phase [B][T][FP] float2 (unit phasors),
+// FP = 1028 (F = 1025 padded so that every row is 16-byte aligned).  One frame's spectrum is a
+// contiguous row, which is also how the network produces it (B,T,F): the reference's (F,T)
+// transpose exists only at the C ABI.
+//
+// One Griffin-Lim iteration is ONE kernel: a 512-thread workgroup owns a chunk of C frames of one
+// utterance.  Phase A inverse-FFTs the chunk plus a halo of `ncol-1` frames either side
+// (ncol = ceil(win/hop) = 5) and overlap-adds them, window-weighted, into a time-domain buffer
+// that lives only in LDS; frames are processed in `ncol` rounds so that the 8 waves of a round
+// touch disjoint samples (no atomics, fixed summation order => bit-reproducible).  After the
+// window-sum-square normalisation, phase B forward-FFTs the C owned frames straight from LDS
+// (reflect padding at the utterance edges is an index map) and stores the new unit phasors.  The
+// time-domain signal never goes to HBM; per bin and iteration the algorithmic traffic is
+// 4 B |S| + 8 B phase in + 8 B phase out.
+//
+// FFT: real 2048-point transforms as 1024-point complex FFTs with a split/merge pass.  One wave
+// per FFT, 16 points per lane: radix-16 in registers -> LDS transpose -> radix-4 -> LDS transpose
+// -> radix-16, twiddles held in registers for the whole kernel.  Index math validated against
+// numpy in tests/test_fft_emulation.py.
+#include "tts_common.h"
+#include "griffin_lim.h"
+
+namespace tts {
+
+// ------------------------------------------------------------------------------------ complex helpers
+typedef float2 cf;
+__device__ __forceinline__ cf cmk(float a, float b) { return make_float2(a, b); }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return cmk(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return cmk(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return cmk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cf cconj(cf a) { return cmk(a.x, -a.y); }
+__device__ __forceinline__ cf cmul_mi(cf a) { return cmk(a.y, -a.x); }   // a * (-i)
+__device__ __forceinline__ cf cmul_pi(cf a) { return cmk(-a.y, a.x); }   // a * (+i)
+__device__ __forceinline__ cf cscale(cf a, float s) { return cmk(a.x * s, a.y * s); }
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS hand-off between lanes of ONE wave: LDS executes a wave's DS ops in order; this only
+    // stops the compiler from moving memory operations across the hand-off point.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// forward radix-4 butterfly (W4 = -i)
+__device__ __forceinline__ void r4(cf& a, cf& b, cf& c, cf& d) {
+    const cf s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = csub(b, d);
+    a = cadd(s0, s2);
+    c = csub(s0, s2);
+    b = cadd(s1, cmul_mi(s3));   // a - i b - c + i d
+    d = cadd(s1, cmul_pi(s3));   // a + i b - c - i d
+}
+
+// forward 16-point DFT in registers, natural order in and out: out[k] = sum_j v[j] W16^{jk}
+__device__ __forceinline__ void fft16(cf (&v)[16]) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+    // step 1: for each j1, radix-4 over j2 (elements j1 + 4 j2) -> t[j1][k2] stored at v[j1 + 4 k2]
+#pragma unroll
+    for (int j1 = 0; j1 < 4; ++j1) r4(v[j1], v[j1 + 4], v[j1 + 8], v[j1 + 12]);
+    // twiddle t[j1][k2] *= W16^{j1 k2}
+    v[1 + 4] = cmul(v[1 + 4], cmk(C1, -S1));    // W^1
+    v[1 + 8] = cmul(v[1 + 8], cmk(R2, -R2));    // W^2
+    v[1 + 12] = cmul(v[1 + 12], cmk(S1, -C1));  // W^3
+    v[2 + 4] = cmul(v[2 + 4], cmk(R2, -R2));    // W^2
+    v[2 + 8] = cmul_mi(v[2 + 8]);               // W^4 = -i
+    v[2 + 12] = cmul(v[2 + 12], cmk(-R2, -R2)); // W^6
+    v[3 + 4] = cmul(v[3 + 4], cmk(S1, -C1));    // W^3
+    v[3 + 8] = cmul(v[3 + 8], cmk(-R2, -R2));   // W^6
+    v[3 + 12] = cmul(v[3 + 12], cmk(-C1, S1));  // W^9
+    // step 2: for each k2, radix-4 over j1 -> out[k2 + 4 k1] ; data for k2 sits at v[4 k2 + j1]
+    cf o[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        cf a = v[4 * k2 + 0], b = v[4 * k2 + 1], c = v[4 * k2 + 2], d = v[4 * k2 + 3];
+        r4(a, b, c, d);
+        o[k2 + 0] = a; o[k2 + 4] = b; o[k2 + 8] = c; o[k2 + 12] = d;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = o[i];
+}
+
+#define E1S 80   // row stride (complex) of the first exchange image: 2*E1S = 32 (mod 64) banks
+#define E2S 17
+#define EX_CPLX 1280
+
+struct FftTw {
+    cf a[15];   // W1024^{lane*k2}, k2 = 1..15
+    cf b[3];    // W64^{(lane&15)*d}, d = 1..3
+};
+
+// forward 1024-point complex FFT across one wave.  in: v[j] = z[lane + 64 j]; out: v[c] = Z[lane + 64 c].
+__device__ __forceinline__ void fft1024(cf (&v)[16], cf* ex, const FftTw& tw, int lane) {
+    fft16(v);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) v[k2] = cmul(v[k2], tw.a[k2 - 1]);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) ex[k2 * E1S + lane] = v[k2];
+    wave_lds_sync();
+    const int a = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v[4 * i + b] = ex[(kq + 4 * i) * E1S + a + 16 * b];
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+#pragma unroll
+        for (int d = 1; d < 4; ++d) v[4 * i + d] = cmul(v[4 * i + d], tw.b[d - 1]);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) ex[(16 * d + kq + 4 * i) * E2S + a] = v[4 * i + d];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int x = 0; x < 16; ++x) v[x] = ex[lane * E2S + x];
+    wave_lds_sync();
+    fft16(v);
+}
+
+// ------------------------------------------------------------------------------------ GL iteration
+#define GL_NW 8            // waves per workgroup
+#define GL_THREADS 512
+#define NFFT 2048
+#define MH 1024            // NFFT / 2
+
+__device__ __forceinline__ cf unit_phasor(cf z) {
+    // exp(1j * angle(z)); angle(0) = 0 -> 1+0j  (reference audio/synthesis.py:109)
+    const float m = fmaxf(fabsf(z.x), fabsf(z.y));
+    if (!(m > 0.f)) return cmk(1.f, 0.f);
+    const float xr = z.x / m, xi = z.y / m;
+    const float r = rsqrtf(xr * xr + xi * xi);
+    return cmk(xr * r, xi * r);
+}
+
+// MODE 0: iteration (phase_in -> phase_out); MODE 1: final iSTFT (phase_in -> wav)
+template <int MODE>
+__global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // carve: [exchange buffers: GL_NW * EX_CPLX cf][window: win floats (padded to 4)][signal]
+    cf* ex_all = reinterpret_cast<cf*>(smem_raw);
+    float* wtab = reinterpret_cast<float*>(ex_all + GL_NW * EX_CPLX);
+    float* sig = wtab + ((p.win + 3) & ~3);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    cf* ex = ex_all + wave * EX_CPLX;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * p.C;
+    const int halo = p.ncol - 1;
+    const int nA = p.C + 2 * halo;
+    const int span = (nA - 1) * p.hop + p.win;
+    const int wpad = (NFFT - p.win) >> 1;
+    const int L = p.hop * (p.T - 1);
+
+    for (int i = tid; i < p.win; i += GL_THREADS) wtab[i] = p.window[i];
+    for (int i = tid; i < span; i += GL_THREADS) sig[i] = 0.f;
+
+    FftTw tw;
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) tw.a[k2 - 1] = p.tw1024[lane * k2];
+#pragma unroll
+    for (int d = 1; d < 4; ++d) tw.b[d - 1] = p.tw1024[16 * (lane & 15) * d];
+    cf twr[16];   // e^{-2 pi i k / 2048}, k = lane + 64 c
+#pragma unroll
+    for (int c = 0; c < 16; ++c) twr[c] = p.tw2048[lane + 64 * c];
+    __syncthreads();
+
+    const float* magb = p.mag + (size_t)b * p.T * p.FP;
+    const cf* phb = p.phase_in + (size_t)b * p.T * p.FP;
+
+    // ---------------- phase A: inverse FFT + windowed overlap-add into LDS
+    for (int r = 0; r < p.ncol; ++r) {
+        const int fa = r + p.ncol * wave;
+        const int tf = t0 - halo + fa;
+        if (fa < nA && tf >= 0 && tf < p.T) {
+            const float* mrow = magb + (size_t)tf * p.FP;
+            const cf* prow = phb + (size_t)tf * p.FP;
+            // wide loads: lane handles k = 4*lane + 256*jj + (0..3)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int k = 4 * lane + 256 * jj;
+                const float4 m4 = *reinterpret_cast<const float4*>(mrow + k);
+                const float4 pa = *reinterpret_cast<const float4*>(prow + k);
+                const float4 pb = *reinterpret_cast<const float4*>(prow + k + 2);
+                float4 xa, xb;
+                xa.x = m4.x * pa.x; xa.y = m4.x * pa.y; xa.z = m4.y * pa.z; xa.w = m4.y * pa.w;
+                xb.x = m4.z * pb.x; xb.y = m4.z * pb.y; xb.z = m4.w * pb.z; xb.w = m4.w * pb.w;
+                *reinterpret_cast<float4*>(ex + k) = xa;
+                *reinterpret_cast<float4*>(ex + k + 2) = xb;
+            }
+            if (lane == 0) ex[MH] = cmk(mrow[MH] * prow[MH].x, 0.f);
+            wave_lds_sync();
+            cf v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int k = lane + 64 * j;
+                cf xk = ex[k];
+                cf xm = cconj(ex[MH - k]);
+                if (k == 0) { xk.y = 0.f; xm.y = 0.f; }
+                // Zin = E + i O, E = (xk + xm)/2, O = conj(twr) (xk - xm)/2 ; feed conj(Zin)
+                const cf e = cscale(cadd(xk, xm), 0.5f);
+                const cf o = cmul(cconj(twr[j]), cscale(csub(xk, xm), 0.5f));
+                const cf zin = cadd(e, cmul_pi(o));
+                v[j] = cconj(zin);
+            }
+            wave_lds_sync();
+            fft1024(v, ex, tw, lane);
+            // z[m] = conj(v)/MH, m = lane + 64 c: x[2m] = Re, x[2m+1] = Im
+            const float inv = 1.0f / (float)MH;
+            float* sf = sig + fa * p.hop;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int n = 2 * (lane + 64 * c);
+                const int nw0 = n - wpad, nw1 = n + 1 - wpad;
+                if (nw0 >= 0 && nw0 < p.win) sf[nw0] += wtab[nw0] * (v[c].x * inv);
+                if (nw1 >= 0 && nw1 < p.win) sf[nw1] += wtab[nw1] * (-v[c].y * inv);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- window-sum-square normalisation (librosa istft: divide where wss > tiny)
+    const int ybase = (t0 - halo) * p.hop + wpad - MH;   // trimmed-signal index of sig[0]
+    const int wss_len = NFFT + p.hop * (p.T - 1);
+    for (int i = tid; i < span; i += GL_THREADS) {
+        const int mfull = ybase + i + MH;
+        if (mfull >= 0 && mfull < wss_len) {
+            const float ws = p.wss[mfull];
+            if (ws > 1.17549435e-38f) sig[i] = sig[i] / ws;
+        }
+    }
+    __syncthreads();
+
+    if (MODE == 1) {
+        // owned samples: y in [t0*hop, (t0+C)*hop) intersected with [0, L)
+        float* wb = p.wav + (size_t)b * L;
+        const int y0 = t0 * p.hop;
+        const int y1 = min((t0 + p.C) * p.hop, L);
+        for (int y = y0 + tid; y < y1; y += GL_THREADS) wb[y] = sig[y - ybase];
+        return;
+    }
+
+    // ---------------- phase B: forward FFT of the owned frames, new unit phasors
+    cf* pob = p.phase_out + (size_t)b * p.T * p.FP;
+    float mse_acc = 0.f;
+    const int nB = (p.C + GL_NW - 1) / GL_NW;
+    for (int r = 0; r < nB; ++r) {
+        const int fb = wave + GL_NW * r;
+        const int t = t0 + fb;
+        if (fb >= p.C || t >= p.T) continue;   // wave-uniform
+        cf v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int n = 2 * (lane + 64 * j);
+            float x0 = 0.f, x1 = 0.f;
+            const int nw0 = n - wpad, nw1 = n + 1 - wpad;
+            if (nw0 >= 0 && nw0 < p.win) {
+                int y = t * p.hop + nw0 + wpad - MH;
+                y = y < 0 ? -y : y;
+                y = y >= L ? 2 * (L - 1) - y : y;
+                x0 = wtab[nw0] * sig[y - ybase];
+            }
+            if (nw1 >= 0 && nw1 < p.win) {
+                int y = t * p.hop + nw1 + wpad - MH;
+                y = y < 0 ? -y : y;
+                y = y >= L ? 2 * (L - 1) - y : y;
+                x1 = wtab[nw1] * sig[y - ybase];
+            }
+            v[j] = cmk(x0, x1);
+        }
+        fft1024(v, ex, tw, lane);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
+        wave_lds_sync();
+        cf* orow = pob + (size_t)t * p.FP;
+        const float* mrow = magb + (size_t)t * p.FP;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int k = lane + 64 * c;
+            const cf zk = v[c];
+            const cf zm = cconj(ex[(MH - k) & (MH - 1)]);
+            // X[k] = (zk + zm)/2 - (i/2) twr (zk - zm)
+            const cf e = cscale(cadd(zk, zm), 0.5f);
+            const cf o = cmul(twr[c], cscale(csub(zk, zm), 0.5f));
+            const cf x = cadd(e, cmul_mi(o));
+            orow[k] = unit_phasor(x);
+            if (p.mse_partial) {
+                const float d = fabsf(mrow[k]) - sqrtf(x.x * x.x + x.y * x.y);
+                mse_acc += d * d;
+            }
+        }
+        if (lane == 0) {
+            const cf z0 = v[0];
+            const float xn = z0.x - z0.y;   // Nyquist bin, real
+            orow[MH] = cmk(xn < 0.f ? -1.f : 1.f, 0.f);
+            if (p.mse_partial) {
+                const float d = fabsf(mrow[MH]) - fabsf(xn);
+                mse_acc += d * d;
+            }
+        }
+        wave_lds_sync();
+    }
+    if (p.mse_partial) {
+        __syncthreads();   // all waves done with their exchange buffers
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mse_acc += __shfl_xor(mse_acc, o);
+        float* red = reinterpret_cast<float*>(ex_all);
+        if (lane == 0) red[wave] = mse_acc;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int w = 0; w < GL_NW; ++w) s += red[w];
+            p.mse_partial[(size_t)b * gridDim.x + blockIdx.x] = s;
+        }
+    }
+}
+
+size_t gl_lds_bytes(const GlParams& p) {
+    const int halo = p.ncol - 1;
+    const int nA = p.C + 2 * halo;
+    const int span = (nA - 1) * p.hop + p.win;
+    return (size_t)GL_NW * EX_CPLX * sizeof(cf) + (size_t)((p.win + 3) & ~3) * sizeof(float) +
+           (size_t)((span + 3) & ~3) * sizeof(float);
+}
+
+hipError_t gl_configure() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_iter_kernel<0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_iter_kernel<1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int B, int final_istft) {
+    const int nchunks = (p.T + p.C - 1) / p.C;
+    dim3 grid(nchunks, B);
+    const size_t lds = gl_lds_bytes(p);
+    if (final_istft)
+        hipLaunchKernelGGL(gl_iter_kernel<1>, grid, dim3(GL_THREADS), lds, s, p);
+    else
+        hipLaunchKernelGGL(gl_iter_kernel<0>, grid, dim3(GL_THREADS), lds, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ small kernels
+// mse[b] = sum(partials[b][:]) / (F*T), fixed order.
+__global__ void gl_mse_reduce_kernel(const float* partial, int nchunks, float denom, float* mse) {
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < nchunks; ++i) s += partial[(size_t)b * nchunks + i];
+        mse[b] = s / denom;
+    }
+}
+hipError_t launch_gl_mse_reduce(hipStream_t s, const float* partial, int B, int nchunks, float denom, float* mse) {
+    hipLaunchKernelGGL(gl_mse_reduce_kernel, dim3(B), dim3(64), 0, s, partial, nchunks, denom, mse);
+    return hipGetLastError();
+}
+
+// (B,F,T) reference layout -> internal (B,T,FP) magnitude (abs taken, as griffin_lim_v2 does)
+__global__ void mag_ft_to_tf_kernel(const float* in, float* out, int F, int T, int FP) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int f = f0 + i, t = t0 + tx;
+        tile[i][tx] = (f < F && t < T) ? fabsf(in[((size_t)b * F + f) * T + t]) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, f = f0 + tx;
+        if (t < T && f < FP) out[((size_t)b * T + t) * FP + f] = tile[tx][i];
+    }
+}
+hipError_t launch_mag_ft_to_tf(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP) {
+    dim3 grid((T + 31) / 32, (FP + 31) / 32, B);
+    hipLaunchKernelGGL(mag_ft_to_tf_kernel, grid, dim3(32, 8), 0, s, in, out, F, T, FP);
+    return hipGetLastError();
+}
+
+// internal (B,T,FP) -> (B,F,T)
+__global__ void tf_to_ft_kernel(const float* in, float* out, int F, int T, int FP) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, f = f0 + tx;
+        tile[i][tx] = (t < T && f < F) ? in[((size_t)b * T + t) * FP + f] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int f = f0 + i, t = t0 + tx;
+        if (f < F && t < T) out[((size_t)b * F + f) * T + t] = tile[tx][i];
+    }
+}
+hipError_t launch_tf_to_ft(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP) {
+    dim3 grid((T + 31) / 32, (F + 31) / 32, B);
+    hipLaunchKernelGGL(tf_to_ft_kernel, grid, dim3(32, 8), 0, s, in, out, F, T, FP);
+    return hipGetLastError();
+}
+
+// counter-based uniform [0,1) generator (splitmix64 finaliser) for the initial phases
+__device__ __forceinline__ float u01(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// angles = exp(2 pi i u): u from init (B,F,T) reference layout or from the seed; out (B,T,FP)
+__global__ void phase_init_kernel(const float* init_ft, uint64_t seed, cf* out, int F, int T, int FP) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int i = ty; i < 32; i += 8) {
+        const int f = f0 + i, t = t0 + tx;
+        float u = 0.f;
+        if (f < F && t < T) {
+            const size_t idx = ((size_t)b * F + f) * T + t;
+            u = init_ft ? init_ft[idx] : u01(seed, idx);
+        }
+        tile[i][tx] = u;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, f = f0 + tx;
+        if (t < T && f < FP) {
+            float sn, cs;
+            sincospif(2.0f * tile[tx][i], &sn, &cs);
+            out[((size_t)b * T + t) * FP + f] = f < F ? cmk(cs, sn) : cmk(0.f, 0.f);
+        }
+    }
+}
+hipError_t launch_phase_init(hipStream_t s, const float* init_ft, uint64_t seed, void* out, int B, int F,
+                             int T, int FP) {
+    dim3 grid((T + 31) / 32, (FP + 31) / 32, B);
+    hipLaunchKernelGGL(phase_init_kernel, grid, dim3(32, 8), 0, s, init_ft, seed, reinterpret_cast<cf*>(out),
+                       F, T, FP);
+    return hipGetLastError();
+}
+
+// linear (B,T,F) network output -> internal magnitude (B,T,FP):
+//   db = (clip(x,0,1) - 1) * (|ref| + |max|) + ref;  mag = 10^(db/20);  mag ** power
+__global__ void denorm_power_kernel(const float* lin, float* mag, size_t rows, int F, int FP, float ref_db,
+                                    float range_db, float power) {
+    const size_t row = blockIdx.x;
+    if (row >= rows) return;
+    const float* in = lin + row * F;
+    float* out = mag + row * FP;
+    for (int f = threadIdx.x; f < FP; f += blockDim.x) {
+        float v = 0.f;
+        if (f < F) {
+            const float x = fminf(fmaxf(in[f], 0.f), 1.f);
+            const float db = (x - 1.0f) * range_db + ref_db;
+            const float m = exp2f(db * (0.05f * 3.3219280948873623f));   // 10^(db/20)
+            v = powf(m, power);
+        }
+        out[f] = v;
+    }
+}
+hipError_t launch_denorm_power(hipStream_t s, const float* lin, float* mag, size_t rows, int F, int FP,
+                               float ref_db, float max_db, float power) {
+    hipLaunchKernelGGL(denorm_power_kernel, dim3((unsigned)rows), dim3(256), 0, s, lin, mag, rows, F, FP, ref_db,
+                       fabsf(ref_db) + fabsf(max_db), power);
+    return hipGetLastError();
+}
+
+// peak normalisation: wav /= max|wav| per utterance unless the peak is below FLT_MIN
+__global__ __launch_bounds__(1024) void peak_normalize_kernel(float* wav, int n) {
+    __shared__ float red[16];
+    float* w = wav + (size_t)blockIdx.x * n;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, red[i]);
+    if (m < 1.17549435e-38f) m = 1.0f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) w[i] = w[i] / m;
+}
+hipError_t launch_peak_normalize(hipStream_t s, float* wav, int B, int n) {
+    hipLaunchKernelGGL(peak_normalize_kernel, dim3(B), dim3(1024), 0, s, wav, n);
+    return hipGetLastError();
+}
+
+}  // namespace tts

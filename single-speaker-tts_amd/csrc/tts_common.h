@@ -1,0 +1,73 @@
+// Internal declarations shared by the HIP translation units of libsstts_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sstts_hip.h"
+
+namespace tts {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3 };
+enum Epi { EPI_STD = 0, EPI_HIGHWAY = 1 };
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, abs error ~1e-7.
+    float e = __expf(2.0f * x);
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == ACT_SIGMOID) return sigmoidf_(v);
+    if (act == ACT_TANH) return tanhf_(v);
+    return v;
+}
+
+// ----------------------------------------------------------------------------- GEMM (gemm_f32.hip)
+// C[m, coff+n] = epi( sum_k A_op[m,k] * Wt[n,k] ), fp32 MFMA.  A_op is an implicit im2col of a
+// channels-last (rows = B*T) activation: element (m, k) = x[m - padl + k / Cin][k % Cin] when the
+// shifted time index stays inside the row's sequence, else 0 (TF 'SAME' conv1d, stride 1).
+// Dense layers are the Cin == K, padl == 0 case.
+struct GemmGroup {
+    const float* A;
+    const int32_t* gather;  // optional: row m reads A + gather[m] * lda (embedding lookup)
+    const float* Wt;        // packed weights [N][K], k contiguous
+    const float* bias;      // [N] or null
+    const float* scale;     // [N] folded batch-norm scale or null
+    const float* shift;     // [N] folded batch-norm shift (used with scale)
+    const float* R;         // residual [M][ldr] or null
+    float* C;
+    int M, N, K;
+    int lda, T, Cin, padl, pool;
+    int ldc, coff, ldr;
+    int act, epi;
+};
+#define TTS_GEMM_MAX_GROUPS 16
+struct GemmBatch {
+    GemmGroup g[TTS_GEMM_MAX_GROUPS];
+};
+// Launches one grouped GEMM; all groups must share M (grid.x) and have N <= max_n.
+hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups);
+
+// ----------------------------------------------------------------------------- bi-GRU (gru.hip)
+// xproj [B*T][xld]: per direction d a block of 3*H input projections (bias included) at column
+// d*3H: [r | u | c].  wpack: per direction, recurrent weights packed by pack_gru_recurrent().
+// out [B*T][2H] = [fw | bw].
+hipError_t launch_bigru(hipStream_t s, const float* xproj, int xld, const float* wrec, float* out,
+                        int B, int T, int H, int cudnn);
+size_t bigru_wrec_floats(int H, int cudnn);
+
+// ----------------------------------------------------------------------------- helpers
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace tts

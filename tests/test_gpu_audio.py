@@ -1,0 +1,106 @@
+"""GPU parity: Griffin-Lim / de-normalisation / peak-normalise kernels vs the numpy oracle.
+
+Tolerances: one iteration from identical phases: rel-L2 <= 1e-4 on the
+waveform; after n iterations the oracle's own convergence measures (mse, spectral
+convergence) within 1 %, not sample equality.
+"""
+import numpy as np
+import pytest
+
+from conftest import pkg, rel_l2
+from oracle import audio_oracle as A
+
+pytestmark = pytest.mark.gpu
+
+N_FFT, WIN, HOP = 2048, 1102, 275
+
+
+def synth_mag(rng, B, T):
+    """magnitude spectrograms of band-limited noise + tones, (B, 1025, T) float32."""
+    out = []
+    for b in range(B):
+        n = HOP * (T - 1)
+        t = np.arange(n) / 22050.0
+        y = 0.3 * np.sin(2 * np.pi * (220 + 40 * b) * t) + 0.1 * rng.standard_normal(n)
+        out.append(np.abs(A.stft(y.astype(np.float32), N_FFT, HOP, WIN)).astype(np.float32))
+    return np.stack(out)
+
+
+@pytest.mark.parametrize('B,T,n_iter', [(1, 12, 0), (2, 12, 1), (2, 40, 1), (1, 70, 3)])
+def test_griffin_lim_few_iterations(engine, B, T, n_iter):
+    rng = np.random.default_rng(10 * T + n_iter)
+    mag = synth_mag(rng, B, T)
+    assert mag.shape == (B, 1025, T)
+    init = rng.random(mag.shape).astype(np.float32)
+    wav, mse = engine.griffin_lim(mag, n_iter, WIN, HOP, N_FFT, init_phase=init)
+    wav, mse = wav.to_host(), mse.to_host()
+    for b in range(B):
+        ref_wav, ref_mse = A.griffin_lim_v2(mag[b], WIN, HOP, N_FFT, n_iter, init_phase=init[b])
+        e = rel_l2(wav[b], ref_wav)
+        print('GL B={} T={} it={} b={}: wav rel-L2 {:.3e} mse {} vs {}'.format(B, T, n_iter, b, e, mse[b], ref_mse))
+        assert wav[b].shape == ref_wav.shape
+        assert e < 1e-4 * max(1, n_iter) * 3
+        if n_iter > 0:
+            assert abs(mse[b] - ref_mse) <= 1e-3 * abs(ref_mse) + 1e-9
+
+
+def test_griffin_lim_convergence_matches_oracle(engine):
+    rng = np.random.default_rng(3)
+    B, T, n_iter = 2, 48, 30
+    mag = synth_mag(rng, B, T)
+    init = rng.random(mag.shape).astype(np.float32)
+    wav, mse = engine.griffin_lim(mag, n_iter, WIN, HOP, N_FFT, init_phase=init)
+    wav, mse = wav.to_host(), mse.to_host()
+    for b in range(B):
+        ref_wav, ref_mse = A.griffin_lim_v2(mag[b], WIN, HOP, N_FFT, n_iter, init_phase=init[b])
+        sc = lambda w: np.linalg.norm(np.abs(A.stft(w, N_FFT, HOP, WIN)) - mag[b]) / np.linalg.norm(mag[b])
+        print('GL 30 it b={}: mse {} vs {}, spectral convergence {} vs {}'.format(b, mse[b], ref_mse, sc(wav[b]),
+                                                                                    sc(ref_wav)))
+        assert abs(mse[b] - ref_mse) <= 0.01 * abs(ref_mse)
+        assert abs(sc(wav[b]) - sc(ref_wav)) <= 0.01 * sc(ref_wav)
+
+
+def test_griffin_lim_seeded_is_deterministic(engine):
+    rng = np.random.default_rng(4)
+    mag = engine.to_device(synth_mag(rng, 2, 20))
+    w0, _ = engine.griffin_lim(mag, 2, WIN, HOP, N_FFT, seed=1234)
+    w1, _ = engine.griffin_lim(mag, 2, WIN, HOP, N_FFT, seed=1234)
+    w2, _ = engine.griffin_lim(mag, 2, WIN, HOP, N_FFT, seed=99)
+    assert np.array_equal(w0.to_host(), w1.to_host())
+    assert not np.array_equal(w0.to_host(), w2.to_host())
+    assert np.isfinite(w0.to_host()).all()
+
+
+def test_griffin_lim_zero_bins(engine):
+    # zero magnitude everywhere -> zero signal; angle(0) = 0 must not produce NaNs
+    mag = np.zeros((1, 1025, 12), np.float32)
+    wav, mse = engine.griffin_lim(mag, 2, WIN, HOP, N_FFT, seed=5)
+    assert np.array_equal(wav.to_host(), np.zeros((1, HOP * 11), np.float32))
+    assert mse.to_host()[0] == 0.0
+
+
+def test_denorm_power(engine):
+    rng = np.random.default_rng(6)
+    lin = (rng.random((2, 9, 1025)) * 1.4 - 0.2).astype(np.float32)   # exercises both clip sides
+    mag = engine.denorm_power(lin, 6.02, 99.89, 1.3).to_host()
+    for b in range(2):
+        ref = A.linear_to_magnitude(lin[b], 6.02, 99.89, 1.3)
+        assert mag[b].shape == ref.shape == (1025, 9)
+        assert rel_l2(mag[b], ref) < 1e-5
+        assert np.allclose(mag[b], ref, rtol=2e-5, atol=0)
+
+
+def test_denorm_db_assertion(engine):
+    lin = np.zeros((1, 4, 1025), np.float32)
+    with pytest.raises(AssertionError):
+        engine.denorm_power(lin, -50.0, 99.89, 1.3)
+
+
+def test_peak_normalize(engine):
+    rng = np.random.default_rng(8)
+    wav = (rng.standard_normal((3, 5000)) * 0.01).astype(np.float32)
+    wav[2] = 0.0
+    d = engine.to_device(wav)
+    got = engine.peak_normalize(d).to_host()
+    for b in range(3):
+        assert np.array_equal(got[b], A.peak_normalize(wav[b]))
