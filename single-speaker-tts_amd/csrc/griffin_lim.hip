@@ -93,15 +93,15 @@ __device__ __forceinline__ void fft16(cf (&v)[16]) {
 #define EX_CPLX 1280
 
 struct FftTw {
-    cf a[15];   // W1024^{lane*k2}, k2 = 1..15
-    cf b[3];    // W64^{(lane&15)*d}, d = 1..3
+    const cf* a;   // LDS table: a[(k2-1)*64] = W1024^{lane*k2}, k2 = 1..15 (already offset by lane)
+    cf b[3];       // W64^{(lane&15)*d}, d = 1..3
 };
 
 // forward 1024-point complex FFT across one wave.  in: v[j] = z[lane + 64 j]; out: v[c] = Z[lane + 64 c].
 __device__ __forceinline__ void fft1024(cf (&v)[16], cf* ex, const FftTw& tw, int lane) {
     fft16(v);
 #pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) v[k2] = cmul(v[k2], tw.a[k2 - 1]);
+    for (int k2 = 1; k2 < 16; ++k2) v[k2] = cmul(v[k2], tw.a[(k2 - 1) * 64]);
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) ex[k2 * E1S + lane] = v[k2];
     wave_lds_sync();
@@ -134,6 +134,11 @@ __device__ __forceinline__ void fft1024(cf (&v)[16], cf* ex, const FftTw& tw, in
 
 __device__ __forceinline__ cf unit_phasor(cf z) {
     // exp(1j * angle(z)); angle(0) = 0 -> 1+0j  (reference audio/synthesis.py:109)
+    const float s = fmaf(z.x, z.x, z.y * z.y);
+    if (s > 1e-30f && s < 1e30f) {   // common case: no risk of under/overflow in s
+        const float r = rsqrtf(s);
+        return cmk(z.x * r, z.y * r);
+    }
     const float m = fmaxf(fabsf(z.x), fabsf(z.y));
     if (!(m > 0.f)) return cmk(1.f, 0.f);
     const float xr = z.x / m, xi = z.y / m;
@@ -141,14 +146,27 @@ __device__ __forceinline__ cf unit_phasor(cf z) {
     return cmk(xr * r, xi * r);
 }
 
-// MODE 0: iteration (phase_in -> phase_out); MODE 1: final iSTFT (phase_in -> wav)
-template <int MODE>
+struct GlFrameRegs {   // one frame's |S| and phase row, as loaded (k = 4*lane + 256*jj + 0..3)
+    float4 m[4];
+    float4 pa[4], pb[4];
+    float mn, pn;      // Nyquist bin (lane 0)
+};
+
+// MODE 0: iteration (phase_in -> phase_out); MODE 1: final iSTFT (phase_in -> wav).
+// WIN_CT / HOP_CT: compile-time window / hop (0 = take them from the parameters); the reference
+// configuration 1102 / 275 gets its own instantiation so that all window-support tests fold away.
+template <int MODE, int WIN_CT, int HOP_CT>
 __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    // carve: [exchange buffers: GL_NW * EX_CPLX cf][window: win floats (padded to 4)][signal]
+    const int win = WIN_CT ? WIN_CT : p.win;
+    const int hop = HOP_CT ? HOP_CT : p.hop;
+    const int ncol = (WIN_CT && HOP_CT) ? (WIN_CT + HOP_CT - 1) / (HOP_CT ? HOP_CT : 1) : p.ncol;
+    // carve: [exchange: GL_NW * EX_CPLX cf][twR: 1024 cf][twA: 15*64 cf][window][signal]
     cf* ex_all = reinterpret_cast<cf*>(smem_raw);
-    float* wtab = reinterpret_cast<float*>(ex_all + GL_NW * EX_CPLX);
-    float* sig = wtab + ((p.win + 3) & ~3);
+    cf* twR = ex_all + GL_NW * EX_CPLX;
+    cf* twA = twR + 1024;
+    float* wtab = reinterpret_cast<float*>(twA + 15 * 64);
+    float* sig = wtab + ((win + 3) & ~3);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -156,49 +174,65 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     cf* ex = ex_all + wave * EX_CPLX;
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * p.C;
-    const int halo = p.ncol - 1;
+    const int halo = ncol - 1;
     const int nA = p.C + 2 * halo;
-    const int span = (nA - 1) * p.hop + p.win;
-    const int wpad = (NFFT - p.win) >> 1;
-    const int L = p.hop * (p.T - 1);
-
-    for (int i = tid; i < p.win; i += GL_THREADS) wtab[i] = p.window[i];
-    for (int i = tid; i < span; i += GL_THREADS) sig[i] = 0.f;
-
-    FftTw tw;
-#pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) tw.a[k2 - 1] = p.tw1024[lane * k2];
-#pragma unroll
-    for (int d = 1; d < 4; ++d) tw.b[d - 1] = p.tw1024[16 * (lane & 15) * d];
-    cf twr[16];   // e^{-2 pi i k / 2048}, k = lane + 64 c
-#pragma unroll
-    for (int c = 0; c < 16; ++c) twr[c] = p.tw2048[lane + 64 * c];
-    __syncthreads();
+    const int span = (nA - 1) * hop + win;
+    const int wpad = (NFFT - win) >> 1;
+    const int L = hop * (p.T - 1);
 
     const float* magb = p.mag + (size_t)b * p.T * p.FP;
     const cf* phb = p.phase_in + (size_t)b * p.T * p.FP;
 
-    // ---------------- phase A: inverse FFT + windowed overlap-add into LDS
-    for (int r = 0; r < p.ncol; ++r) {
-        const int fa = r + p.ncol * wave;
+    auto frame_valid = [&](int fa) {
         const int tf = t0 - halo + fa;
-        if (fa < nA && tf >= 0 && tf < p.T) {
-            const float* mrow = magb + (size_t)tf * p.FP;
-            const cf* prow = phb + (size_t)tf * p.FP;
-            // wide loads: lane handles k = 4*lane + 256*jj + (0..3)
+        return fa < nA && tf >= 0 && tf < p.T;
+    };
+    auto load_frame = [&](int fa, GlFrameRegs& g) {
+        if (!frame_valid(fa)) return;
+        const int tf = t0 - halo + fa;
+        const float* mrow = magb + (size_t)tf * p.FP;
+        const cf* prow = phb + (size_t)tf * p.FP;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int k = 4 * lane + 256 * jj;
+            g.m[jj] = *reinterpret_cast<const float4*>(mrow + k);
+            g.pa[jj] = *reinterpret_cast<const float4*>(prow + k);
+            g.pb[jj] = *reinterpret_cast<const float4*>(prow + k + 2);
+        }
+        g.mn = 0.f; g.pn = 0.f;
+        if (lane == 0) { g.mn = mrow[MH]; g.pn = prow[MH].x; }
+    };
+
+    GlFrameRegs nxt;
+    load_frame(0 + ncol * wave, nxt);   // round 0's frame, in flight during the prologue
+
+    for (int i = tid; i < win; i += GL_THREADS) wtab[i] = p.window[i];
+    for (int i = tid; i < span; i += GL_THREADS) sig[i] = 0.f;
+    for (int i = tid; i < 1024; i += GL_THREADS) twR[i] = p.tw2048[i];
+    for (int i = tid; i < 15 * 64; i += GL_THREADS) twA[i] = p.tw1024[(i & 63) * ((i >> 6) + 1)];
+    FftTw tw;
+#pragma unroll
+    for (int d = 1; d < 4; ++d) tw.b[d - 1] = p.tw1024[16 * (lane & 15) * d];
+    tw.a = twA + lane;
+    __syncthreads();
+
+    // ---------------- phase A: inverse FFT + windowed overlap-add into LDS
+    for (int r = 0; r < ncol; ++r) {
+        const int fa = r + ncol * wave;
+        GlFrameRegs cur = nxt;
+        if (r + 1 < ncol) load_frame(fa + 1, nxt);
+        if (frame_valid(fa)) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int k = 4 * lane + 256 * jj;
-                const float4 m4 = *reinterpret_cast<const float4*>(mrow + k);
-                const float4 pa = *reinterpret_cast<const float4*>(prow + k);
-                const float4 pb = *reinterpret_cast<const float4*>(prow + k + 2);
+                const float4 m4 = cur.m[jj], pa = cur.pa[jj], pb = cur.pb[jj];
                 float4 xa, xb;
                 xa.x = m4.x * pa.x; xa.y = m4.x * pa.y; xa.z = m4.y * pa.z; xa.w = m4.y * pa.w;
                 xb.x = m4.z * pb.x; xb.y = m4.z * pb.y; xb.z = m4.w * pb.z; xb.w = m4.w * pb.w;
                 *reinterpret_cast<float4*>(ex + k) = xa;
                 *reinterpret_cast<float4*>(ex + k + 2) = xb;
             }
-            if (lane == 0) ex[MH] = cmk(mrow[MH] * prow[MH].x, 0.f);
+            if (lane == 0) ex[MH] = cmk(cur.mn * cur.pn, 0.f);
             wave_lds_sync();
             cf v[16];
 #pragma unroll
@@ -209,7 +243,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 if (k == 0) { xk.y = 0.f; xm.y = 0.f; }
                 // Zin = E + i O, E = (xk + xm)/2, O = conj(twr) (xk - xm)/2 ; feed conj(Zin)
                 const cf e = cscale(cadd(xk, xm), 0.5f);
-                const cf o = cmul(cconj(twr[j]), cscale(csub(xk, xm), 0.5f));
+                const cf o = cmul(cconj(twR[k]), cscale(csub(xk, xm), 0.5f));
                 const cf zin = cadd(e, cmul_pi(o));
                 v[j] = cconj(zin);
             }
@@ -217,21 +251,21 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             fft1024(v, ex, tw, lane);
             // z[m] = conj(v)/MH, m = lane + 64 c: x[2m] = Re, x[2m+1] = Im
             const float inv = 1.0f / (float)MH;
-            float* sf = sig + fa * p.hop;
+            float* sf = sig + fa * hop;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const int n = 2 * (lane + 64 * c);
                 const int nw0 = n - wpad, nw1 = n + 1 - wpad;
-                if (nw0 >= 0 && nw0 < p.win) sf[nw0] += wtab[nw0] * (v[c].x * inv);
-                if (nw1 >= 0 && nw1 < p.win) sf[nw1] += wtab[nw1] * (-v[c].y * inv);
+                if (nw0 >= 0 && nw0 < win) sf[nw0] += wtab[nw0] * (v[c].x * inv);
+                if (nw1 >= 0 && nw1 < win) sf[nw1] += wtab[nw1] * (-v[c].y * inv);
             }
         }
         __syncthreads();
     }
 
     // ---------------- window-sum-square normalisation (librosa istft: divide where wss > tiny)
-    const int ybase = (t0 - halo) * p.hop + wpad - MH;   // trimmed-signal index of sig[0]
-    const int wss_len = NFFT + p.hop * (p.T - 1);
+    const int ybase = (t0 - halo) * hop + wpad - MH;   // trimmed-signal index of sig[0]
+    const int wss_len = NFFT + hop * (p.T - 1);
     for (int i = tid; i < span; i += GL_THREADS) {
         const int mfull = ybase + i + MH;
         if (mfull >= 0 && mfull < wss_len) {
@@ -244,8 +278,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     if (MODE == 1) {
         // owned samples: y in [t0*hop, (t0+C)*hop) intersected with [0, L)
         float* wb = p.wav + (size_t)b * L;
-        const int y0 = t0 * p.hop;
-        const int y1 = min((t0 + p.C) * p.hop, L);
+        const int y0 = t0 * hop;
+        const int y1 = min((t0 + p.C) * hop, L);
         for (int y = y0 + tid; y < y1; y += GL_THREADS) wb[y] = sig[y - ybase];
         return;
     }
@@ -259,24 +293,39 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         const int t = t0 + fb;
         if (fb >= p.C || t >= p.T) continue;   // wave-uniform
         cf v[16];
+        const int ylo = t * hop + wpad - MH;          // y index of window sample 0
+        const bool edge = ylo < 0 || ylo + win > L;   // wave-uniform: reflect padding needed
+        if (!edge) {
+            const float* sf = sig + (fb + halo) * hop;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int n = 2 * (lane + 64 * j);
-            float x0 = 0.f, x1 = 0.f;
-            const int nw0 = n - wpad, nw1 = n + 1 - wpad;
-            if (nw0 >= 0 && nw0 < p.win) {
-                int y = t * p.hop + nw0 + wpad - MH;
-                y = y < 0 ? -y : y;
-                y = y >= L ? 2 * (L - 1) - y : y;
-                x0 = wtab[nw0] * sig[y - ybase];
+            for (int j = 0; j < 16; ++j) {
+                const int n = 2 * (lane + 64 * j);
+                const int nw0 = n - wpad, nw1 = n + 1 - wpad;
+                float x0 = 0.f, x1 = 0.f;
+                if (nw0 >= 0 && nw0 < win) x0 = wtab[nw0] * sf[nw0];
+                if (nw1 >= 0 && nw1 < win) x1 = wtab[nw1] * sf[nw1];
+                v[j] = cmk(x0, x1);
             }
-            if (nw1 >= 0 && nw1 < p.win) {
-                int y = t * p.hop + nw1 + wpad - MH;
-                y = y < 0 ? -y : y;
-                y = y >= L ? 2 * (L - 1) - y : y;
-                x1 = wtab[nw1] * sig[y - ybase];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int n = 2 * (lane + 64 * j);
+                float x0 = 0.f, x1 = 0.f;
+                const int nw0 = n - wpad, nw1 = n + 1 - wpad;
+                if (nw0 >= 0 && nw0 < win) {
+                    int y = ylo + nw0;
+                    y = y < 0 ? -y : y;
+                    y = y >= L ? 2 * (L - 1) - y : y;
+                    x0 = wtab[nw0] * sig[y - ybase];
+                }
+                if (nw1 >= 0 && nw1 < win) {
+                    int y = ylo + nw1;
+                    y = y < 0 ? -y : y;
+                    y = y >= L ? 2 * (L - 1) - y : y;
+                    x1 = wtab[nw1] * sig[y - ybase];
+                }
+                v[j] = cmk(x0, x1);
             }
-            v[j] = cmk(x0, x1);
         }
         fft1024(v, ex, tw, lane);
 #pragma unroll
@@ -291,7 +340,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             const cf zm = cconj(ex[(MH - k) & (MH - 1)]);
             // X[k] = (zk + zm)/2 - (i/2) twr (zk - zm)
             const cf e = cscale(cadd(zk, zm), 0.5f);
-            const cf o = cmul(twr[c], cscale(csub(zk, zm), 0.5f));
+            const cf o = cmul(twR[k], cscale(csub(zk, zm), 0.5f));
             const cf x = cadd(e, cmul_mi(o));
             orow[k] = unit_phasor(x);
             if (p.mse_partial) {
@@ -329,26 +378,36 @@ size_t gl_lds_bytes(const GlParams& p) {
     const int halo = p.ncol - 1;
     const int nA = p.C + 2 * halo;
     const int span = (nA - 1) * p.hop + p.win;
-    return (size_t)GL_NW * EX_CPLX * sizeof(cf) + (size_t)((p.win + 3) & ~3) * sizeof(float) +
+    return (size_t)(GL_NW * EX_CPLX + 1024 + 15 * 64) * sizeof(cf) + (size_t)((p.win + 3) & ~3) * sizeof(float) +
            (size_t)((span + 3) & ~3) * sizeof(float);
 }
 
-hipError_t gl_configure() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_iter_kernel<0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_iter_kernel<1>),
+template <int MODE, int W, int H>
+static hipError_t gl_set_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_iter_kernel<MODE, W, H>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t gl_configure() {
+    hipError_t e;
+    if ((e = gl_set_attr<0, 0, 0>()) != hipSuccess) return e;
+    if ((e = gl_set_attr<1, 0, 0>()) != hipSuccess) return e;
+    if ((e = gl_set_attr<0, 1102, 275>()) != hipSuccess) return e;
+    return gl_set_attr<1, 1102, 275>();
 }
 
 hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int B, int final_istft) {
     const int nchunks = (p.T + p.C - 1) / p.C;
     dim3 grid(nchunks, B);
     const size_t lds = gl_lds_bytes(p);
-    if (final_istft)
-        hipLaunchKernelGGL(gl_iter_kernel<1>, grid, dim3(GL_THREADS), lds, s, p);
-    else
-        hipLaunchKernelGGL(gl_iter_kernel<0>, grid, dim3(GL_THREADS), lds, s, p);
+    const bool ref_cfg = p.win == 1102 && p.hop == 275;   // the reference's 50 ms / 12.5 ms at 22.05 kHz
+    if (final_istft) {
+        if (ref_cfg) hipLaunchKernelGGL((gl_iter_kernel<1, 1102, 275>), grid, dim3(GL_THREADS), lds, s, p);
+        else hipLaunchKernelGGL((gl_iter_kernel<1, 0, 0>), grid, dim3(GL_THREADS), lds, s, p);
+    } else {
+        if (ref_cfg) hipLaunchKernelGGL((gl_iter_kernel<0, 1102, 275>), grid, dim3(GL_THREADS), lds, s, p);
+        else hipLaunchKernelGGL((gl_iter_kernel<0, 0, 0>), grid, dim3(GL_THREADS), lds, s, p);
+    }
     return hipGetLastError();
 }
 
