@@ -135,14 +135,24 @@ int tts_griffin_lim(tts_handle_t h, const float* mag, const float* init_phase, u
  * utterance unless the peak is below FLT_MIN.  In place, wav [B*n]. */
 int tts_peak_normalize(tts_handle_t h, float* wav, int B, int n);
 
-/* ---- analysis features (audio/features.py:5-86,116-145) ------------------------------- */
-/* |librosa.stft(wav)| ** power, centre/reflect, hann.  wav [B*n] -> lin [B*F*n_frames],
- * n_frames = 1 + n/hop. */
+/* ---- analysis features (audio/features.py:5-86,116-145) and dB helpers ---------------- */
+/* librosa.stft(wav, n_fft, hop, win) as linear_scale_spectrogram returns it (features.py:145):
+ * centre/reflect padding, periodic hann.  wav [B*n] -> out complex64 interleaved
+ * [B*F*n_frames*2], n_frames = 1 + n/hop. */
+int tts_stft(tts_handle_t h, const float* wav, int B, int n, int n_fft, int win_length,
+             int hop_length, float* out);
+/* abs(stft) ** power (features.py:62-71).  wav [B*n] -> lin [B*F*n_frames]. */
 int tts_stft_magnitude(tts_handle_t h, const float* wav, int B, int n, int n_fft, int win_length,
                        int hop_length, float power, float* lin);
-/* librosa.filters.mel(htk=True) applied: lin [B*F*n_frames] -> mel [B*n_mels*n_frames]. */
+/* np.dot(librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax, htk=True), lin) (features.py:75-84).
+ * lin [B*F*n_frames] -> mel [B*n_mels*n_frames]. */
 int tts_mel_spectrogram(tts_handle_t h, const float* lin, int B, int n_frames, int n_fft,
                         int sampling_rate, int n_mels, float fmin, float fmax, float* mel);
+/* Elementwise audio/conversion.py: mode 0 magnitude_to_decibel (:5-29), 1 decibel_to_magnitude
+ * (:32-53; TTS_ERR_DB_RANGE if any input < -100, synchronous), 2 normalize_decibel (:56-78),
+ * 3 inv_normalize_decibel (:81-102).  in/out [n] (may alias). */
+int tts_db_convert(tts_handle_t h, const float* in, size_t n, int mode, float ref_db, float max_db,
+                   float* out);
 
 /* ---- end to end -------------------------------------------------------------------------- */
 /* ids -> waveform: encoder, decoder (n_steps), post-net, de-normalise, ** power, Griffin-Lim,

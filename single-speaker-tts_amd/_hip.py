@@ -79,6 +79,8 @@ _PROTOTYPES = {
     'tts_griffin_lim': (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_void_p, c_void_p]),
     'tts_peak_normalize': (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    'tts_stft': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'tts_db_convert': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_float, c_float, c_void_p]),
     'tts_stft_magnitude': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     'tts_mel_spectrogram': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                                     c_void_p]),
@@ -328,6 +330,38 @@ class Engine(object):
                                             ali.data_ptr() if ali is not None else None,
                                             lin.data_ptr() if lin is not None else None))
         return dict(wav=wav, mel=mel, alignments=ali, linear=lin)
+
+    def stft(self, wav, n_fft, win_length, hop_length):
+        """complex64 (B, F, n_frames) = librosa.stft per utterance."""
+        B, n = wav.shape
+        p_wav, _k = self._in(wav, np.float32)
+        Tf = 1 + n // hop_length
+        out = self.empty((B, 1 + n_fft // 2, Tf), np.complex64)
+        self._check(self.lib.tts_stft(self.handle, p_wav, B, n, n_fft, win_length, hop_length, out.data_ptr()))
+        return out
+
+    def stft_magnitude(self, wav, n_fft, win_length, hop_length, power=1.0):
+        B, n = wav.shape
+        p_wav, _k = self._in(wav, np.float32)
+        Tf = 1 + n // hop_length
+        out = self.empty((B, 1 + n_fft // 2, Tf))
+        self._check(self.lib.tts_stft_magnitude(self.handle, p_wav, B, n, n_fft, win_length, hop_length, power,
+                                                out.data_ptr()))
+        return out
+
+    def mel_spectrogram(self, lin, n_fft, sampling_rate, n_mels, fmin, fmax):
+        B, F, Tf = lin.shape
+        p_lin, _k = self._in(lin, np.float32)
+        out = self.empty((B, n_mels, Tf))
+        self._check(self.lib.tts_mel_spectrogram(self.handle, p_lin, B, Tf, n_fft, sampling_rate, n_mels, fmin,
+                                                 fmax if fmax is not None else 0.0, out.data_ptr()))
+        return out
+
+    def db_convert(self, x, mode, ref_db=0.0, max_db=0.0):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        d = self.to_device(x)
+        self._check(self.lib.tts_db_convert(self.handle, d.ptr, x.size, mode, ref_db, max_db, d.ptr))
+        return d.to_host()
 
     # ------------------------------------------------------------------ profiling / debug
     def profile_reset(self):

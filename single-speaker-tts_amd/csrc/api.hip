@@ -103,6 +103,16 @@ struct tts_handle_s {
         bool configured = false;
     } gl;
 
+    // analysis-side tables (STFT window, mel basis)
+    struct {
+        int win = 0;
+        float* window = nullptr;
+        int sr = 0, n_fft = 0, n_mels = 0;
+        float fmin = 0, fmax = 0;
+        float* mel_wt = nullptr;   // [n_mels][FP]
+        int* flag = nullptr;
+    } an;
+
     // profiling
     std::vector<ProfSpan> spans;
     double prof_ms[ST_COUNT] = {0};
@@ -614,6 +624,55 @@ int check_ready(tts_handle_t h) {
 }
 
 // ------------------------------------------------------------------------------------ Griffin-Lim
+int gl_tables(tts_handle_t h) {
+    auto& g = h->gl;
+    if (g.configured) return TTS_OK;
+    HIPCHK(h, gl_configure());
+    std::vector<float2> t1(1024), t2(1024);
+    for (int k = 0; k < 1024; ++k) {
+        const double a1 = -2.0 * M_PI * k / 1024.0, a2 = -2.0 * M_PI * k / 2048.0;
+        t1[k] = make_float2((float)std::cos(a1), (float)std::sin(a1));
+        t2[k] = make_float2((float)std::cos(a2), (float)std::sin(a2));
+    }
+    HIPCHK(h, hipMalloc(&g.tw1024, 1024 * sizeof(float2)));
+    HIPCHK(h, hipMalloc(&g.tw2048, 1024 * sizeof(float2)));
+    HIPCHK(h, hipMemcpy(g.tw1024, t1.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(g.tw2048, t2.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
+    g.configured = true;
+    return TTS_OK;
+}
+
+int stft_prepare(tts_handle_t h, int n, int win, int hop, int n_fft) {
+    if (n_fft != TTS_GL_NFFT) return fail(h, TTS_ERR_UNSUPPORTED, "stft: only n_fft == 2048 is implemented");
+    if (win < 2 || win > n_fft || hop < 1) return fail(h, TTS_ERR_INVALID, "stft: need 2 <= win_length <= n_fft, hop >= 1");
+    if (n <= n_fft / 2) return fail(h, TTS_ERR_INVALID, "stft: signal shorter than n_fft/2 (reflect padding undefined)");
+    int rc = gl_tables(h);
+    if (rc) return rc;
+    auto& a = h->an;
+    if (a.win != win) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (a.window) hipFree(a.window);
+        a.window = nullptr;
+        std::vector<float> wf(win);
+        for (int i = 0; i < win; ++i) wf[i] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * i / win));
+        HIPCHK(h, hipMalloc(&a.window, win * sizeof(float)));
+        HIPCHK(h, hipMemcpy(a.window, wf.data(), win * sizeof(float), hipMemcpyHostToDevice));
+        a.win = win;
+    }
+    return TTS_OK;
+}
+
+int stft_run(tts_handle_t h, const float* wav, int B, int n, int n_fft, int win, int hop, float2** out, int* Tf_out) {
+    int rc = stft_prepare(h, n, win, hop, n_fft);
+    if (rc) return rc;
+    const int Tf = 1 + n / hop;
+    WS(h, "an.stft", float2, (size_t)B * Tf * TTS_GL_FP, buf);
+    HIPCHK(h, launch_stft(h->stream, wav, B, n, Tf, h->an.window, win, hop, h->gl.tw1024, h->gl.tw2048, buf, TTS_GL_FP));
+    *out = buf;
+    *Tf_out = Tf;
+    return TTS_OK;
+}
+
 int gl_prepare(tts_handle_t h, int T, int win, int hop, int n_fft) {
     if (n_fft != TTS_GL_NFFT) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: only n_fft == 2048 is implemented");
     if (win < 2 || win > n_fft || hop < 1 || T < 1)
@@ -623,19 +682,9 @@ int gl_prepare(tts_handle_t h, int T, int win, int hop, int n_fft) {
     if ((long long)hop * (T - 1) <= n_fft / 2)
         return fail(h, TTS_ERR_INVALID, "griffin_lim: signal shorter than n_fft/2 (reflect padding undefined)");
     auto& g = h->gl;
-    if (!g.configured) {
-        HIPCHK(h, gl_configure());
-        std::vector<float2> t1(1024), t2(1024);
-        for (int k = 0; k < 1024; ++k) {
-            const double a1 = -2.0 * M_PI * k / 1024.0, a2 = -2.0 * M_PI * k / 2048.0;
-            t1[k] = make_float2((float)std::cos(a1), (float)std::sin(a1));
-            t2[k] = make_float2((float)std::cos(a2), (float)std::sin(a2));
-        }
-        HIPCHK(h, hipMalloc(&g.tw1024, 1024 * sizeof(float2)));
-        HIPCHK(h, hipMalloc(&g.tw2048, 1024 * sizeof(float2)));
-        HIPCHK(h, hipMemcpy(g.tw1024, t1.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(g.tw2048, t2.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
-        g.configured = true;
+    {
+        int rc = gl_tables(h);
+        if (rc) return rc;
     }
     if (g.win == win && g.hop == hop && g.T == T) return TTS_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -797,6 +846,9 @@ int tts_destroy(tts_handle_t h) {
     if (h->gl.wss) hipFree(h->gl.wss);
     if (h->gl.tw1024) hipFree(h->gl.tw1024);
     if (h->gl.tw2048) hipFree(h->gl.tw2048);
+    if (h->an.window) hipFree(h->an.window);
+    if (h->an.mel_wt) hipFree(h->an.mel_wt);
+    if (h->an.flag) hipFree(h->an.flag);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return TTS_OK;
@@ -1140,11 +1192,86 @@ int tts_peak_normalize(tts_handle_t h, float* wav, int B, int n) {
     return TTS_OK;
 }
 
-int tts_stft_magnitude(tts_handle_t h, const float*, int, int, int, int, int, float, float*) {
-    return fail(h, TTS_ERR_UNSUPPORTED, "stft_magnitude: not implemented yet");
+int tts_stft(tts_handle_t h, const float* wav, int B, int n, int n_fft, int win_length, int hop_length, float* out) {
+    if (!h || !wav || !out || B < 1) return fail(h, TTS_ERR_INVALID, "stft: bad arguments");
+    float2* buf;
+    int Tf;
+    int rc = stft_run(h, wav, B, n, n_fft, win_length, hop_length, &buf, &Tf);
+    if (rc) return rc;
+    HIPCHK(h, launch_cplx_tf_to_ft(h->stream, buf, out, B, 1 + n_fft / 2, Tf, TTS_GL_FP, 0, 1.0f));
+    return TTS_OK;
 }
-int tts_mel_spectrogram(tts_handle_t h, const float*, int, int, int, int, int, float, float, float*) {
-    return fail(h, TTS_ERR_UNSUPPORTED, "mel_spectrogram: not implemented yet");
+
+int tts_stft_magnitude(tts_handle_t h, const float* wav, int B, int n, int n_fft, int win_length, int hop_length,
+                       float power, float* lin) {
+    if (!h || !wav || !lin || B < 1) return fail(h, TTS_ERR_INVALID, "stft_magnitude: bad arguments");
+    float2* buf;
+    int Tf;
+    int rc = stft_run(h, wav, B, n, n_fft, win_length, hop_length, &buf, &Tf);
+    if (rc) return rc;
+    HIPCHK(h, launch_cplx_tf_to_ft(h->stream, buf, lin, B, 1 + n_fft / 2, Tf, TTS_GL_FP, 1, power));
+    return TTS_OK;
+}
+
+int tts_mel_spectrogram(tts_handle_t h, const float* lin, int B, int n_frames, int n_fft, int sr, int n_mels, float fmin,
+                        float fmax, float* mel) {
+    if (!h || !lin || !mel || B < 1 || n_frames < 1 || n_mels < 1 || sr < 1)
+        return fail(h, TTS_ERR_INVALID, "mel_spectrogram: bad arguments");
+    if (n_fft != TTS_GL_NFFT) return fail(h, TTS_ERR_UNSUPPORTED, "mel_spectrogram: only n_fft == 2048 is implemented");
+    const int F = 1 + n_fft / 2, FP = TTS_GL_FP;
+    auto& a = h->an;
+    if (!a.mel_wt || a.sr != sr || a.n_fft != n_fft || a.n_mels != n_mels || a.fmin != fmin || a.fmax != fmax) {
+        // librosa.filters.mel(htk=True, norm=1) [librosa-0.6]; reference audio/features.py:75-80
+        auto hz2mel = [](double f) { return 2595.0 * std::log10(1.0 + f / 700.0); };
+        auto mel2hz = [](double m) { return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0); };
+        const double fmx = fmax > 0 ? fmax : sr / 2.0;
+        std::vector<double> mel_f(n_mels + 2);
+        const double m0 = hz2mel(fmin), m1 = hz2mel(fmx);
+        for (int i = 0; i < n_mels + 2; ++i) mel_f[i] = mel2hz(m0 + (m1 - m0) * i / (n_mels + 1));
+        std::vector<float> wt((size_t)n_mels * FP, 0.f);
+        for (int i = 0; i < n_mels; ++i) {
+            const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+            for (int f = 0; f < F; ++f) {
+                const double freq = (sr / 2.0) * f / (F - 1);
+                const double lower = (freq - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
+                const double upper = (mel_f[i + 2] - freq) / (mel_f[i + 2] - mel_f[i + 1]);
+                const double v = std::max(0.0, std::min(lower, upper));
+                wt[(size_t)i * FP + f] = (float)(v * enorm);
+            }
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (a.mel_wt) hipFree(a.mel_wt);
+        a.mel_wt = nullptr;
+        HIPCHK(h, hipMalloc(&a.mel_wt, wt.size() * sizeof(float)));
+        HIPCHK(h, hipMemcpy(a.mel_wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+        a.sr = sr; a.n_fft = n_fft; a.n_mels = n_mels; a.fmin = fmin; a.fmax = fmax;
+    }
+    WS(h, "an.lin_tf", float, (size_t)B * n_frames * FP, lin_tf);
+    WS(h, "an.mel_tf", float, (size_t)B * n_frames * n_mels, mel_tf);
+    HIPCHK(h, launch_mag_ft_to_tf(h->stream, lin, lin_tf, B, F, n_frames, FP));
+    int rc = run_single(h, dense_group(lin_tf, FP, a.mel_wt, nullptr, mel_tf, n_mels, B * n_frames, n_mels, FP, ACT_NONE));
+    if (rc) return rc;
+    HIPCHK(h, launch_tf_to_ft(h->stream, mel_tf, mel, B, n_mels, n_frames, n_mels));
+    return TTS_OK;
+}
+
+int tts_db_convert(tts_handle_t h, const float* in, size_t n, int mode, float ref_db, float max_db, float* out) {
+    if (!h || !in || !out || mode < 0 || mode > 3) return fail(h, TTS_ERR_INVALID, "db_convert: bad arguments");
+    if (n == 0) return TTS_OK;
+    if (mode == 1) {
+        // reference audio/conversion.py:47-49: AssertionError if any dB value < -100
+        if (!h->an.flag) HIPCHK(h, hipMalloc(&h->an.flag, sizeof(int)));
+        HIPCHK(h, hipMemsetAsync(h->an.flag, 0, sizeof(int), h->stream));
+        HIPCHK(h, launch_any_below(h->stream, in, n, -100.0f, h->an.flag));
+        int flag = 0;
+        HIPCHK(h, hipMemcpyAsync(&flag, h->an.flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (flag)
+            return fail(h, TTS_ERR_DB_RANGE,
+                        "\"conversion.decibel_to_magnitude\" was asked to convert a dB value smaller -100 dB.");
+    }
+    HIPCHK(h, launch_db_convert(h->stream, in, out, n, mode, ref_db, max_db));
+    return TTS_OK;
 }
 
 int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_synth_params_t* sp,

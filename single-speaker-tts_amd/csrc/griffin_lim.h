@@ -33,5 +33,11 @@ hipError_t launch_phase_init(hipStream_t s, const float* init_ft, uint64_t seed,
 hipError_t launch_denorm_power(hipStream_t s, const float* lin, float* mag, size_t rows, int F, int FP,
                                float ref_db, float max_db, float power);
 hipError_t launch_peak_normalize(hipStream_t s, float* wav, int B, int n);
+hipError_t launch_stft(hipStream_t s, const float* wav, int B, int n, int Tf, const float* window, int win, int hop,
+                       const float2* tw1024, const float2* tw2048, float2* out, int FP);
+hipError_t launch_cplx_tf_to_ft(hipStream_t s, const float2* in, float* out, int B, int F, int T, int FP, int mode,
+                                float power);
+hipError_t launch_db_convert(hipStream_t s, const float* in, float* out, size_t n, int mode, float ref_db, float max_db);
+hipError_t launch_any_below(hipStream_t s, const float* in, size_t n, float lim, int* flag);
 
 }  // namespace tts

@@ -411,6 +411,150 @@ hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int B, int final_ist
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------ analysis STFT
+// librosa.stft(center=True, reflect, hann) of real signals: one wave per frame, signal read straight
+// from global memory (this is the feature-extraction side, reference audio/features.py:62,145 --
+// not part of the synthesis loop).  out [B][Tf][FP] complex.
+__global__ __launch_bounds__(GL_THREADS) void stft_kernel(const float* __restrict__ wav, int n, int Tf,
+                                                          const float* __restrict__ window, int win, int hop,
+                                                          const cf* __restrict__ tw1024, const cf* __restrict__ tw2048,
+                                                          cf* __restrict__ out, int FP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf* ex_all = reinterpret_cast<cf*>(smem_raw);
+    cf* twR = ex_all + GL_NW * EX_CPLX;
+    cf* twA = twR + 1024;
+    float* wtab = reinterpret_cast<float*>(twA + 15 * 64);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cf* ex = ex_all + wave * EX_CPLX;
+    for (int i = tid; i < win; i += GL_THREADS) wtab[i] = window[i];
+    for (int i = tid; i < 1024; i += GL_THREADS) twR[i] = tw2048[i];
+    for (int i = tid; i < 15 * 64; i += GL_THREADS) twA[i] = tw1024[(i & 63) * ((i >> 6) + 1)];
+    FftTw tw;
+#pragma unroll
+    for (int d = 1; d < 4; ++d) tw.b[d - 1] = tw1024[16 * (lane & 15) * d];
+    tw.a = twA + lane;
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * GL_NW + wave;
+    if (t >= Tf) return;
+    const float* y = wav + (size_t)b * n;
+    const int wpad = (NFFT - win) >> 1;
+    const int ylo = t * hop + wpad - MH;
+    cf v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int nn = 2 * (lane + 64 * j);
+        float x[2] = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int nw = nn + e - wpad;
+            if (nw >= 0 && nw < win) {
+                int yi = ylo + nw;
+                yi = yi < 0 ? -yi : yi;
+                yi = yi >= n ? 2 * (n - 1) - yi : yi;
+                x[e] = wtab[nw] * y[yi];
+            }
+        }
+        v[j] = cmk(x[0], x[1]);
+    }
+    fft1024(v, ex, tw, lane);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
+    wave_lds_sync();
+    cf* orow = out + ((size_t)b * Tf + t) * FP;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int k = lane + 64 * c;
+        const cf zk = v[c];
+        const cf zm = cconj(ex[(MH - k) & (MH - 1)]);
+        const cf e = cscale(cadd(zk, zm), 0.5f);
+        const cf o = cmul(twR[k], cscale(csub(zk, zm), 0.5f));
+        orow[k] = cadd(e, cmul_mi(o));
+    }
+    if (lane == 0) orow[MH] = cmk(v[0].x - v[0].y, 0.f);
+    if (lane < FP - MH - 1) orow[MH + 1 + lane] = cmk(0.f, 0.f);
+}
+
+hipError_t launch_stft(hipStream_t s, const float* wav, int B, int n, int Tf, const float* window, int win, int hop,
+                       const float2* tw1024, const float2* tw2048, float2* out, int FP) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const size_t lds = (size_t)(GL_NW * EX_CPLX + 1024 + 15 * 64) * sizeof(cf) + (size_t)((win + 3) & ~3) * sizeof(float);
+    dim3 grid((Tf + GL_NW - 1) / GL_NW, B);
+    hipLaunchKernelGGL(stft_kernel, grid, dim3(GL_THREADS), lds, s, wav, n, Tf, window, win, hop, tw1024, tw2048, out, FP);
+    return hipGetLastError();
+}
+
+// complex (B,T,FP) -> (B,F,T): mode 0 interleaved complex64, mode 1 |z| ** power
+__global__ void cplx_tf_to_ft_kernel(const cf* in, float* out, int F, int T, int FP, int mode, float power) {
+    __shared__ cf tile[32][33];
+    const int b = blockIdx.z;
+    const int f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, f = f0 + tx;
+        tile[i][tx] = (t < T && f < F) ? in[((size_t)b * T + t) * FP + f] : cmk(0.f, 0.f);
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int f = f0 + i, t = t0 + tx;
+        if (f < F && t < T) {
+            const cf z = tile[tx][i];
+            const size_t o = ((size_t)b * F + f) * T + t;
+            if (mode == 0) {
+                reinterpret_cast<cf*>(out)[o] = z;
+            } else {
+                const float m = sqrtf(z.x * z.x + z.y * z.y);
+                out[o] = power == 1.0f ? m : (power == 2.0f ? m * m : powf(m, power));
+            }
+        }
+    }
+}
+hipError_t launch_cplx_tf_to_ft(hipStream_t s, const float2* in, float* out, int B, int F, int T, int FP, int mode,
+                                float power) {
+    dim3 grid((T + 31) / 32, (F + 31) / 32, B);
+    hipLaunchKernelGGL(cplx_tf_to_ft_kernel, grid, dim3(32, 8), 0, s, in, out, F, T, FP, mode, power);
+    return hipGetLastError();
+}
+
+// elementwise dB conversions of reference audio/conversion.py: mode 0 magnitude_to_decibel (:5-29),
+// 1 decibel_to_magnitude (:32-53), 2 normalize_decibel (:56-78), 3 inv_normalize_decibel (:81-102)
+__global__ void db_convert_kernel(const float* in, float* out, size_t n, int mode, float ref_db, float max_db) {
+    const float range = fabsf(ref_db) + fabsf(max_db);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = in[i];
+        float y;
+        if (mode == 0) y = 20.0f * log10f(fmaxf(1e-5f, x));
+        else if (mode == 1) y = exp2f(x * (0.05f * 3.3219280948873623f));
+        else if (mode == 2) y = fminf(fmaxf(1.0f + (x - ref_db) / range, 0.f), 1.f);
+        else y = (fminf(fmaxf(x, 0.f), 1.f) - 1.0f) * range + ref_db;
+        out[i] = y;
+    }
+}
+hipError_t launch_db_convert(hipStream_t s, const float* in, float* out, size_t n, int mode, float ref_db, float max_db) {
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(db_convert_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, in, out, n, mode, ref_db, max_db);
+    return hipGetLastError();
+}
+
+// any value below lim?  (decibel_to_magnitude's assertion, reference audio/conversion.py:47-49)
+__global__ void any_below_kernel(const float* in, size_t n, float lim, int* flag) {
+    bool hit = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        hit |= in[i] < lim;
+    if (hit) *flag = 1;
+}
+hipError_t launch_any_below(hipStream_t s, const float* in, size_t n, float lim, int* flag) {
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(any_below_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, in, n, lim, flag);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------ small kernels
 // mse[b] = sum(partials[b][:]) / (F*T), fixed order.
 __global__ void gl_mse_reduce_kernel(const float* partial, int nchunks, float denom, float* mse) {

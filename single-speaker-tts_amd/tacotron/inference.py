@@ -1,0 +1,87 @@
+"""Drop-in mirror of the reference's ``tacotron.inference`` (tacotron/inference.py).
+
+``pad_sentence`` (:22-27), ``inference(model, sentences)`` (:30-105) and the body of
+``__main__`` (:130-200) as :func:`synthesize_sentences`: ids -> padded batch -> network ->
+de-normalise -> ``** magnitude_power`` -> Griffin-Lim -> ``{i+1}.wav``.
+
+Where the reference fans Griffin-Lim out to 6 worker processes, one utterance each
+(:185-188), the whole batch is reconstructed by one batched kernel sequence on the GPU.
+"""
+import os
+
+import numpy as np
+
+from ..audio.conversion import ms_to_samples
+from ..audio.io import save_wav
+from .model import Mode, Tacotron
+from .params import dataset_params, inference_params, model_params
+
+
+def pad_sentence(_sentence, _max_len):
+    """reference tacotron/inference.py:22-27."""
+    pad_len = _max_len - len(_sentence)
+    pad_token = dataset_params.vocabulary_dict['pad']
+    return np.append(_sentence, [pad_token] * pad_len)
+
+
+def inference(model, sentences, n_steps=None):
+    """reference tacotron/inference.py:30-105.
+
+    Arguments:
+        model (Tacotron): model with restored weights.
+        sentences: list/array of padded id sequences (B, T_sent).
+
+    Returns:
+        list of np.ndarray: per utterance the linear-scale magnitude spectrogram, shape
+        (1025, T) float32 = decibel_to_magnitude(inv_normalize_decibel(spec.T, mel_ref_db,
+        mel_max_db)) exactly as the reference (it uses the *mel* dB constants, :96-98).
+    """
+    sentences = np.asarray(sentences, dtype=np.int32)
+    if inference_params.dump_alignments or inference_params.dump_linear_spectrogram:
+        fetches = [model.summary(), model.output_linear_spec] \
+            if os.path.isdir(inference_params.synthesis_dir) else [model.output_linear_spec]
+    else:
+        fetches = [model.output_linear_spec]
+    out = model.predict_device(sentences, n_steps)
+    if len(fetches) == 2:
+        model._dump(out)
+    loader = dataset_params.dataset_loader
+    mag = model.engine.denorm_power(out['linear'], loader.mel_mag_ref_db, loader.mel_mag_max_db, 1.0).to_host()
+    return [mag[b] for b in range(mag.shape[0])]
+
+
+def synthesize_batch(model, sentences, n_steps=None, n_iter=None, init_phase=None, seed=0, peak_normalize=False):
+    """ids (B, T_sent) -> waveforms (B, hop*(T-1)) float32: inference() + the synthesize() closure
+    of the reference (tacotron/inference.py:170-188) fused into one device call."""
+    hp = model.hparams
+    loader = dataset_params.dataset_loader
+    win_len = ms_to_samples(hp.win_len, hp.sampling_rate)
+    win_hop = ms_to_samples(hp.win_hop, hp.sampling_rate)
+    S = n_steps or model.n_steps()
+    out = model.engine.synthesize(np.ascontiguousarray(sentences, dtype=np.int32), S, loader.mel_mag_ref_db,
+                                  loader.mel_mag_max_db, hp.magnitude_power,
+                                  hp.reconstruction_iterations if n_iter is None else n_iter, win_len, win_hop,
+                                  init_phase=init_phase, seed=seed, peak_normalize=peak_normalize)
+    return out['wav'].to_host()
+
+
+def synthesize_sentences(raw_sentences, weights, dataset=None, out_dir=None, device_id=0, seed=0):
+    """The reference's ``__main__`` (tacotron/inference.py:130-200) as a function.
+
+    raw text lines -> process_sentences -> pad -> model -> wavs -> ``{i+1}.wav`` (peak-normalised
+    float32 WAV, save_wav(norm=True)).  Returns the list of waveforms."""
+    from ..datasets.lj_speech import LJSpeechDatasetHelper
+    out_dir = out_dir or inference_params.synthesis_dir
+    if not os.path.isdir(out_dir):
+        raise NotADirectoryError('The specified synthesis target folder does not exist.')
+    dataset = dataset or LJSpeechDatasetHelper(dataset_folder=dataset_params.dataset_folder,
+                                                char_dict=dataset_params.vocabulary_dict, fill_dict=False)
+    id_sequences, sequence_lengths = dataset.process_sentences(raw_sentences)
+    sentences = [np.frombuffer(s, dtype=np.int32) for s in id_sequences]
+    max_length = max(sequence_lengths)
+    sentences = np.array([pad_sentence(s, max_length) for s in sentences], dtype=np.int32)
+    model = Tacotron(inputs=Tacotron.model_placeholders(), mode=Mode.PREDICT, weights=weights, device_id=device_id)
+    wavs = synthesize_batch(model, sentences, seed=seed, peak_normalize=False)
+    for i, wav in enumerate(wavs):
+        save_wav(os.path.join(out_dir, '{}.wav'.format(i + 1)), wav, model_params.sampling_rate, True)
+    return list(wavs)

@@ -107,7 +107,7 @@ _VOCAB = {
 @dataclass
 class DatasetParams:
     dataset_folder: str = '/thesis/datasets/ljspeech'
-    dataset_loader: type = LJSpeechConstants
+    dataset_loader: type = LJSpeechConstants  # the text helper lives in datasets.lj_speech
     vocabulary_dict: dict = field(default_factory=lambda: dict(_VOCAB))
     vocabulary_size: int = 39
 

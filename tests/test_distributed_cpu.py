@@ -1,0 +1,57 @@
+"""CPU: the N > 1 path (weight broadcast + utterance shards) with world_size 2 over gloo."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+from conftest import ROOT, PKG
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp):
+    import importlib
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    S = importlib.import_module(PKG + '.sharding')
+    W = importlib.import_module(PKG + '.tacotron.weights')
+    n = W.n_parameters()
+    if rank == 0:
+        blob = W.pack_blob(W.synthetic_weights(0))
+    else:
+        blob = np.zeros(n, np.float32)
+    got = S.broadcast_blob(blob, src=0, device='cpu')
+    # every rank ends up with the same named tensors
+    w = W.unpack_blob(got)
+    digest = float(sum(float(np.abs(v).sum()) for v in w.values()))
+    # utterance shards of a 9-utterance batch padded to the GLOBAL length
+    seqs = [list(range(2, 2 + L)) + [1] for L in (3, 9, 5, 4, 8, 2, 7, 6, 1)]
+    batch = S.pad_batch(seqs)
+    lo, hi = S.shard_range(len(seqs), world, rank)
+    mine = batch[lo:hi]
+    assert mine.shape[1] == batch.shape[1] == 10
+    back = S.gather_host(mine, dst=0)
+    np.save(os.path.join(tmp, 'digest{}.npy'.format(rank)), np.array([digest]))
+    if rank == 0:
+        assert np.array_equal(back, batch)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_shards_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    d0 = np.load(tmp_path / 'digest0.npy')[0]
+    d1 = np.load(tmp_path / 'digest1.npy')[0]
+    assert d0 == d1 and d0 > 0

@@ -1,0 +1,177 @@
+"""GPU: the reference-shaped Python surface (tacotron.model / tacotron.inference / audio.*), the
+analysis features, golden fixtures and C-ABI behaviour, all through libsstts_hip.so."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import pkg, rel_l2
+from oracle import audio_oracle as A
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+N_FFT, WIN, HOP = 2048, 1102, 275
+
+
+def test_manifest_matches_python(engine, hparams):
+    W = pkg('tacotron.weights')
+    m = W.manifest(hparams)
+    assert engine.manifest() == [(k, tuple(v)) for k, v in m.items()]
+
+
+def test_golden_network_fixture(engine):
+    g = np.load(os.path.join(GOLD, 'network_small.npz'))
+    S = int(g['n_steps'])
+    mem = engine.encoder_forward(g['ids'])
+    assert rel_l2(mem.to_host(), g['memory']) < 1e-3
+    mel, al = engine.decoder_forward(mem, S)
+    assert rel_l2(mel.to_host(), g['reduced_mel']) < 1e-3
+    assert np.abs(al.to_host() - g['alignments']).max() < 1e-4
+    lin = engine.postnet_forward(mel.to_host().reshape(2, -1, 80))
+    assert rel_l2(lin.to_host(), g['linear']) < 1e-3
+
+
+def test_golden_griffin_lim_fixture(engine):
+    g = np.load(os.path.join(GOLD, 'griffin_lim_small.npz'))
+    wav, mse = engine.griffin_lim(g['mag'][None], int(g['n_iter']), WIN, HOP, N_FFT, init_phase=g['init_phase'][None])
+    assert rel_l2(wav.to_host()[0], g['wav']) < 1e-4
+    assert abs(mse.to_host()[0] - g['mse']) < 1e-3 * g['mse']
+    w1, _ = engine.griffin_lim(g['mag'][None], 1, WIN, HOP, N_FFT, init_phase=g['init_phase'][None])
+    assert rel_l2(w1.to_host()[0], g['wav_after_1']) < 1e-4
+    mag = engine.denorm_power(g['linear'][None], 6.02, 99.89, 1.3).to_host()[0]
+    assert rel_l2(mag, g['linear_mag']) < 1e-5
+
+
+def test_weights_required(hparams):
+    sstts = pkg()
+    eng = sstts.Engine(hparams)
+    with pytest.raises(sstts.TtsError) as e:
+        eng.encoder_forward(np.zeros((1, 4), np.int32))
+    assert e.value.code == -2
+    with pytest.raises(sstts.TtsError):
+        eng.load_weights({})
+    eng.close()
+
+
+def test_unsupported_configs_are_rejected(hparams):
+    import copy
+    sstts = pkg()
+    hp = copy.deepcopy(hparams)
+    hp.encoder.n_gru_units = 64
+    with pytest.raises(sstts.TtsError) as e:
+        sstts.Engine(hp)
+    assert e.value.code == -5
+    eng = sstts.Engine(hparams)
+    with pytest.raises(sstts.TtsError) as e:
+        eng.griffin_lim(np.ones((1, 513, 8), np.float32), 1, 400, 100, 1024)
+    assert e.value.code == -5
+    eng.close()
+
+
+def test_stft_and_mel_features(engine):
+    rng = np.random.default_rng(0)
+    F = pkg('audio.features')
+    y = (0.3 * np.sin(2 * np.pi * 440 * np.arange(HOP * 30) / 22050) + 0.05 * rng.standard_normal(HOP * 30)).astype(np.float32)
+    S = F.linear_scale_spectrogram(y, N_FFT, HOP, WIN, engine=engine)
+    ref = A.stft(y, N_FFT, HOP, WIN)
+    assert S.dtype == np.complex64 and S.shape == ref.shape == (1025, 31)
+    assert np.linalg.norm(S - ref) / np.linalg.norm(ref) < 1e-5
+    mel = F.mel_scale_spectrogram(y, N_FFT, 22050, 80, 0, 8000, HOP, WIN, 1.0, engine=engine)
+    rmel, rlin = A.mel_scale_spectrogram(y, N_FFT, 22050, 80, 0, 8000, HOP, WIN, 1.0)
+    assert mel.shape == rmel.shape == (80, 31)
+    assert rel_l2(mel, rmel) < 1e-5
+    lin2 = engine.stft_magnitude(y[None], N_FFT, WIN, HOP, 2.0).to_host()[0]
+    assert rel_l2(lin2, np.abs(ref) ** 2) < 1e-5
+    # default hop = win // 4, default win = n_fft (librosa defaults kept by the reference wrapper)
+    S2 = F.linear_scale_spectrogram(y, N_FFT, engine=engine)
+    assert S2.shape == (1025, 1 + len(y) // 512)
+    assert np.linalg.norm(S2 - A.stft(y, N_FFT, 512, N_FFT)) / np.linalg.norm(S2) < 1e-5
+
+
+def test_conversion_module(engine):
+    C = pkg('audio.conversion')
+    rng = np.random.default_rng(1)
+    x = rng.random((7, 5)).astype(np.float32) * 3
+    assert np.allclose(C.magnitude_to_decibel(x, engine=engine), A.magnitude_to_decibel(x), rtol=1e-5, atol=1e-4)
+    assert C.magnitude_to_decibel(np.zeros(3, np.float32), engine=engine).tolist() == [-100.0] * 3
+    db = (rng.random((4, 6)).astype(np.float32) - 0.7) * 100
+    assert np.allclose(C.decibel_to_magnitude(db, engine=engine), A.decibel_to_magnitude(db), rtol=2e-5)
+    with pytest.raises(AssertionError):
+        C.decibel_to_magnitude(np.array([0.0, -100.5], np.float32), engine=engine)
+    n = rng.random(11).astype(np.float32) * 1.4 - 0.2
+    assert np.allclose(C.inv_normalize_decibel(n, 6.02, 99.89, engine=engine), A.inv_normalize_decibel(n, 6.02, 99.89), atol=1e-4)
+    assert np.allclose(C.normalize_decibel(db, 6.02, 99.89, engine=engine), A.normalize_decibel(db, 6.02, 99.89), atol=1e-6)
+    assert C.ms_to_samples(50.0, 22050) == 1102 and C.ms_to_samples(12.5, 22050) == 275
+    assert C.samples_to_ms(22050, 22050) == 1000
+
+
+def test_synthesis_module_single_and_batched(engine):
+    S = pkg('audio.synthesis')
+    g = np.load(os.path.join(GOLD, 'griffin_lim_small.npz'))
+    wav = S.spectrogram_to_wav(g['mag'], WIN, HOP, N_FFT, 2, init_phase=g['init_phase'], engine=engine)
+    assert wav.dtype == np.float32 and wav.shape == g['wav'].shape
+    assert rel_l2(wav, g['wav']) < 1e-4
+    sig, mse = S.griffin_lim_v2(np.stack([g['mag'], g['mag']]), WIN, HOP, N_FFT, 2,
+                                init_phase=np.stack([g['init_phase']] * 2), engine=engine)
+    assert sig.shape == (2,) + g['wav'].shape and np.array_equal(sig[0], sig[1])
+    unseeded = S.spectrogram_to_wav(g['mag'], WIN, HOP, N_FFT, 1, engine=engine)
+    assert np.isfinite(unseeded).all()
+
+
+def test_save_wav_float32_peak_normalised(engine, tmp_path):
+    io = pkg('audio.io')
+    wav = (np.random.default_rng(2).standard_normal(3000) * 0.1).astype(np.float32)
+    p = str(tmp_path / '1.wav')
+    io.save_wav(p, wav, 22050, True, engine=engine)
+    from scipy.io import wavfile
+    sr, data = wavfile.read(p)
+    assert sr == 22050 and data.dtype == np.float32
+    assert np.array_equal(data, A.peak_normalize(wav))
+
+
+def test_tacotron_facade_and_inference(weights, hparams, tmp_path):
+    M = pkg('tacotron.model')
+    I = pkg('tacotron.inference')
+    P = pkg('tacotron.params')
+    with pytest.raises(NotImplementedError):
+        M.Tacotron(M.Tacotron.model_placeholders(), M.Mode.TRAIN)
+    ph = M.Tacotron.model_placeholders()
+    assert set(ph) == {'ph_sentences', 'ph_sentence_length', 'ph_mel_specs', 'ph_lin_specs', 'ph_time_frames'}
+    model = M.Tacotron(inputs=ph, mode=M.Mode.PREDICT, weights=weights)
+    ids = np.array([I.pad_sentence(np.array([5, 9, 1]), 6), [4, 5, 6, 7, 8, 1]], dtype=np.int32)
+    assert ids[0].tolist() == [5, 9, 1, 0, 0, 0]
+    lin, mel, red, al = model.run([model.output_linear_spec, model.output_mel_spec, model.reduced_output_mel_spec,
+                                   model.alignment_history], {model.inp_sentences: ids}, n_steps=3)
+    assert lin.shape == (2, 15, 1025) and mel.shape == (2, 15, 80) and red.shape == (2, 3, 400) and al.shape == (3, 2, 6)
+    assert np.array_equal(red.reshape(2, 15, 80), mel)
+    P.inference_params.synthesis_dir = str(tmp_path)
+    specs = I.inference(model, ids, n_steps=3)
+    assert len(specs) == 2 and specs[0].shape == (1025, 15) and specs[0].dtype == np.float32
+    ref = A.decibel_to_magnitude(A.inv_normalize_decibel(lin[0].T, 6.02, 99.89))
+    assert rel_l2(specs[0], ref) < 1e-5
+    a = np.load(tmp_path / 'alignments.npz')['alignments']
+    s = np.load(tmp_path / 'linear-spectrogram.npz')['linear_spec']
+    assert a.shape == (2, 6, 3) and s.shape == (1, 1025, 15, 1)           # reference model.py:552-598 layouts
+    assert np.array_equal(a, np.transpose(al, (1, 2, 0))) and np.array_equal(s[0, :, :, 0], lin[0].T)
+    wavs = I.synthesize_batch(model, ids, n_steps=3, n_iter=2, seed=3)
+    assert wavs.shape == (2, 275 * 14) and np.isfinite(wavs).all()
+    model.engine.close()
+
+
+def test_synthesize_sentences_writes_numbered_wavs(weights, tmp_path):
+    I = pkg('tacotron.inference')
+    P = pkg('tacotron.params')
+    P.model_params.decoder.maximum_iterations = 20       # 4 decoder steps keep the test small
+    P.model_params.reconstruction_iterations = 2
+    try:
+        with pytest.raises(NotADirectoryError):
+            I.synthesize_sentences(['hello'], weights, out_dir=str(tmp_path / 'missing'))
+        wavs = I.synthesize_sentences(['Hello world.', 'Mr. Smith said hi!'], weights, out_dir=str(tmp_path))
+    finally:
+        P.model_params.decoder.maximum_iterations = 1000
+        P.model_params.reconstruction_iterations = 50
+    assert sorted(os.listdir(tmp_path)) == ['1.wav', '2.wav']
+    from scipy.io import wavfile
+    sr, d = wavfile.read(tmp_path / '2.wav')
+    assert sr == 22050 and d.dtype == np.float32 and d.shape == wavs[1].shape == (275 * 19,)
+    assert np.isclose(np.abs(d).max(), 1.0)

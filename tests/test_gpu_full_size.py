@@ -1,0 +1,118 @@
+"""GPU: BASELINE.json's full-size configurations -- direct oracle comparison where the oracle
+finishes in seconds, size-independent properties (shard invariance, softmax normalisation,
+determinism, round trips) at the sizes where it does not."""
+import numpy as np
+import pytest
+
+from conftest import pkg, rel_l2
+from oracle import audio_oracle as A
+from oracle import tacotron_oracle as O
+
+pytestmark = pytest.mark.gpu
+N_FFT, WIN, HOP = 2048, 1102, 275
+
+
+def bench_ids(B, Ts, seed):
+    rng = np.random.default_rng(seed)
+    ids = np.zeros((B, Ts), np.int32)
+    for b in range(B):
+        L = int(np.clip(round(rng.normal(100, 30)), 20, Ts - 1))
+        ids[b, :L] = rng.integers(2, 39, L)
+        ids[b, L] = 1
+    return ids
+
+
+def test_config2_encoder_32x150(engine, hparams, weights64):
+    ids = bench_ids(32, 150, 1234)
+    ref = O.encoder(ids, weights64, hparams)
+    got = engine.encoder_forward(ids).to_host()
+    e = rel_l2(got, ref)
+    print('config 2 encoder 32x150 rel-L2', e)
+    assert e < 1e-3
+
+
+def test_config3_decoder_200_steps_b64(engine, hparams, weights64):
+    """200 autoregressive steps: the fp32 error must not grow past the 1e-3 parity bar."""
+    rng = np.random.default_rng(7)
+    memory = (rng.standard_normal((64, 150, 256)) * 0.5).astype(np.float32)
+    ref_mel, ref_al = O.decoder(memory.astype(np.float64), weights64, hparams)
+    mel, al = engine.decoder_forward(memory, 200)
+    mel, al = mel.to_host(), al.to_host()
+    assert mel.shape == (64, 200, 400) and al.shape == (200, 64, 150)
+    e = rel_l2(mel, ref_mel)
+    e_last = rel_l2(mel[:, -1], ref_mel[:, -1])
+    print('config 3 decoder B=64 S=200: mel rel-L2 {:.3e} (last step {:.3e}), align max-abs {:.3e}'.format(
+        e, e_last, float(np.abs(al - ref_al).max())))
+    assert e < 1e-3 and e_last < 1e-3
+    assert np.abs(al - ref_al).max() < 1e-4
+    assert np.allclose(al.sum(-1), 1.0, atol=1e-5)
+
+
+def test_shard_invariance(engine):
+    """Utterance i gives bit-identical results alone, in a shard of 8 and in the batch of 64:
+    the property that makes the multi-GPU utterance sharding exact."""
+    ids = bench_ids(64, 150, 99)
+    mem = engine.encoder_forward(ids).to_host()
+    mem8 = engine.encoder_forward(ids[16:24]).to_host()
+    assert np.array_equal(mem[16:24], mem8)
+    mel, _ = engine.decoder_forward(mem, 12, want_alignments=False)
+    mel8, _ = engine.decoder_forward(mem[16:24], 12, want_alignments=False)
+    assert np.array_equal(mel.to_host()[16:24], mel8.to_host())
+    m = mel.to_host().reshape(64, -1, 80)
+    lin = engine.postnet_forward(m).to_host()
+    lin1 = engine.postnet_forward(m[17:18]).to_host()
+    assert np.array_equal(lin[17:18], lin1)
+
+
+def test_config4_postnet_full_length(engine, hparams, weights64):
+    rng = np.random.default_rng(11)
+    mel = rng.random((4, 1000, 80)).astype(np.float32)
+    ref = O.post_process(mel.astype(np.float64), weights64, hparams)
+    got = engine.postnet_forward(mel).to_host()
+    e = rel_l2(got, ref)
+    print('config 4 post-net T=1000 rel-L2', e)
+    assert got.shape == (4, 1000, 1025) and e < 1e-3
+
+
+def test_config4_griffin_lim_full_length(engine):
+    rng = np.random.default_rng(42)
+    T = 1000
+    n = HOP * (T - 1)
+    t = np.arange(n) / 22050.0
+    y = (0.3 * np.sin(2 * np.pi * 200 * t * (1 + 0.2 * np.sin(2 * np.pi * 0.7 * t))) + 0.02 * rng.standard_normal(n)).astype(np.float32)
+    mag1 = np.abs(A.stft(y, N_FFT, HOP, WIN)).astype(np.float32)
+    assert mag1.shape == (1025, 1000)
+    init = rng.random((1, 1025, T)).astype(np.float32)
+    ref_wav, ref_mse = A.griffin_lim_v2(mag1, WIN, HOP, N_FFT, 3, init_phase=init[0])
+    wav, mse = engine.griffin_lim(mag1[None], 3, WIN, HOP, N_FFT, init_phase=init)
+    assert wav.shape == (1, 274725)
+    e = rel_l2(wav.to_host()[0], ref_wav)
+    print('config 4 GL T=1000, 3 iterations: wav rel-L2 {:.3e}, mse {} vs {}'.format(e, mse.to_host()[0], ref_mse))
+    assert e < 1e-3 and abs(mse.to_host()[0] - ref_mse) < 1e-3 * ref_mse
+    # batch of 64 copies: every row identical to the single run (no cross-utterance coupling)
+    big = engine.to_device(np.broadcast_to(mag1, (64,) + mag1.shape).copy())
+    init64 = engine.to_device(np.broadcast_to(init[0], (64,) + init[0].shape).copy())
+    w64, m64 = engine.griffin_lim(big, 3, WIN, HOP, N_FFT, init_phase=init64)
+    w64 = w64.to_host()
+    assert np.array_equal(w64[0], wav.to_host()[0]) and np.array_equal(w64[63], w64[0])
+    # mse decreases with iterations; round trip: |STFT(iSTFT(S))| of a consistent S returns S
+    _, m10 = engine.griffin_lim(mag1[None], 10, WIN, HOP, N_FFT, init_phase=init)
+    assert m10.to_host()[0] < mse.to_host()[0]
+
+
+def test_end_to_end_synthesize_matches_staged(engine, hparams):
+    ids = bench_ids(3, 40, 5)
+    init = np.random.default_rng(1).random((3, 1025, 50)).astype(np.float32)
+    out = engine.synthesize(ids, 10, 6.02, 99.89, 1.3, 4, WIN, HOP, init_phase=init, peak_normalize=True,
+                            want_mel=True, want_alignments=True, want_linear=True)
+    mem = engine.encoder_forward(ids)
+    mel, al = engine.decoder_forward(mem, 10)
+    lin = engine.postnet_forward(mel.to_host().reshape(3, 50, 80))
+    mag = engine.denorm_power(lin, 6.02, 99.89, 1.3)
+    wav, _ = engine.griffin_lim(mag, 4, WIN, HOP, N_FFT, init_phase=init)
+    wav = engine.peak_normalize(wav)
+    assert np.array_equal(out['mel'].to_host().reshape(3, 10, 400), mel.to_host())
+    assert np.array_equal(out['linear'].to_host(), lin.to_host())
+    assert np.array_equal(out['alignments'].to_host(), al.to_host())
+    assert np.array_equal(out['wav'].to_host(), wav.to_host())
+    assert np.abs(out['wav'].to_host()).max(axis=1).tolist() == [1.0, 1.0, 1.0]
