@@ -529,7 +529,7 @@ __global__ void db_convert_kernel(const float* in, float* out, size_t n, int mod
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float x = in[i];
         float y;
-        if (mode == 0) y = 20.0f * log10f(fmaxf(1e-5f, x));
+        if (mode == 0) y = (float)(20.0 * log10((double)fmaxf(1e-5f, x)));   // analysis side: exact rounding
         else if (mode == 1) y = exp2f(x * (0.05f * 3.3219280948873623f));
         else if (mode == 2) y = fminf(fmaxf(1.0f + (x - ref_db) / range, 0.f), 1.f);
         else y = (fminf(fmaxf(x, 0.f), 1.f) - 1.0f) * range + ref_db;

@@ -50,7 +50,8 @@ def main():
     lin = (rng.random((T, 1025)) * 1.2 - 0.1).astype(np.float32)
     np.savez_compressed(os.path.join(HERE, 'griffin_lim_small.npz'), mag=mag, init_phase=init, n_iter=2,
                         wav=wav.astype(np.float32), mse=np.float32(mse),
-                        wav_after_1=hist[0]['signal'].astype(np.float32),
+                        wav_n0=A.griffin_lim_v2(mag, 1102, 275, 2048, 0, init_phase=init)[0].astype(np.float32),
+                        wav_n1=A.griffin_lim_v2(mag, 1102, 275, 2048, 1, init_phase=init)[0].astype(np.float32),
                         linear=lin, linear_mag=A.linear_to_magnitude(lin, 6.02, 99.89, 1.3).astype(np.float32),
                         peak_norm=A.peak_normalize(wav))
     print('weights sha256', digest)
