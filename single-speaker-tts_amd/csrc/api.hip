@@ -62,6 +62,13 @@ struct tts_handle_s {
     std::string err;
     int use_graph = 1;
     int profile = 0;
+    // tts_synthesize pipelining: encoder + decoder (latency bound, few CUs) of call k+1 run on
+    // `front` while post-net + Griffin-Lim (throughput bound) of call k run on `stream`.
+    int pipeline = 0;      // opt-in: measured gain on MI355X is ~2 % (GL workgroups fill every CU)
+    int reserve_cus = 0;   // opt-in CU-mask reservation for the front stream
+    hipStream_t front = nullptr;
+    hipEvent_t ev_front_done = nullptr, ev_post_done = nullptr;
+    bool post_pending = false;
 
     std::vector<ManifestEntry> manifest;
     std::map<std::string, std::vector<float>> host_w;
@@ -448,11 +455,20 @@ GruOffsets pack_dec_gru(tts_handle_t h, Packer& p, const std::string& scope, int
 }
 
 // ------------------------------------------------------------------------------------ workspace
+int sync_all(tts_handle_t h) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->front && h->front != h->stream) HIPCHK(h, hipStreamSynchronize(h->front));
+    return TTS_OK;
+}
+
 int ws_get(tts_handle_t h, const char* name, size_t bytes, void** out) {
     DevBuf& b = h->ws[name];
     if (b.bytes < bytes) {
         if (b.p) {
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+            {
+                int rc = sync_all(h);
+                if (rc) return rc;
+            }
             HIPCHK(h, hipFree(b.p));
             b.p = nullptr;
             b.bytes = 0;
@@ -497,7 +513,7 @@ struct ProfScope {
 };
 
 void prof_collect(tts_handle_t h) {
-    hipStreamSynchronize(h->stream);
+    sync_all(h);
     for (auto& s : h->spans) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
@@ -849,6 +865,12 @@ int tts_destroy(tts_handle_t h) {
     if (h->an.window) hipFree(h->an.window);
     if (h->an.mel_wt) hipFree(h->an.mel_wt);
     if (h->an.flag) hipFree(h->an.flag);
+    if (h->front) {
+        hipStreamSynchronize(h->front);
+        hipStreamDestroy(h->front);
+    }
+    if (h->ev_front_done) hipEventDestroy(h->ev_front_done);
+    if (h->ev_post_done) hipEventDestroy(h->ev_post_done);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return TTS_OK;
@@ -858,7 +880,11 @@ const char* tts_last_error(tts_handle_t h) { return h ? h->err.c_str() : g_creat
 
 int tts_set_stream(tts_handle_t h, void* s) {
     if (!h) return TTS_ERR_INVALID;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    {
+        int rc = sync_all(h);
+        if (rc) return rc;
+    }
+    h->post_pending = false;
     if (h->dec_graph) {
         hipGraphExecDestroy(h->dec_graph);
         h->dec_graph = nullptr;
@@ -878,14 +904,22 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     if (!h || !key) return TTS_ERR_INVALID;
     if (!std::strcmp(key, "use_graph")) h->use_graph = value;
     else if (!std::strcmp(key, "profile")) h->profile = value;
+    else if (!std::strcmp(key, "reserve_cus")) {
+        if (h->front) return fail(h, TTS_ERR_INVALID, "reserve_cus must be set before the first tts_synthesize");
+        h->reserve_cus = value;
+    } else if (!std::strcmp(key, "pipeline")) {
+        int rc = sync_all(h);
+        if (rc) return rc;
+        h->post_pending = false;
+        h->pipeline = value;
+    }
     else return fail(h, TTS_ERR_INVALID, std::string("unknown option ") + key);
     return TTS_OK;
 }
 
 int tts_synchronize(tts_handle_t h) {
     if (!h) return TTS_ERR_INVALID;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return TTS_OK;
+    return sync_all(h);
 }
 
 int tts_manifest_size(tts_handle_t h) { return h ? (int)h->manifest.size() : TTS_ERR_INVALID; }
@@ -960,6 +994,32 @@ int tts_finalize_weights(tts_handle_t h) {
         o_dpb[i] = pack_copy(p, W(h, s + "/bias").data(), c.dec_prenet_units[i]);
         n_in = c.dec_prenet_units[i];
     }
+    // pre-net layer 1 with the output projection folded in (steps >= 1):
+    //   x_t W1x = (y W_o + b_o)[-n_mels:] W1x = y (W_o[:, -n_mels:] W1x) + b_o[-n_mels:] W1x
+    size_t o_dpfw, o_dpfb;
+    {
+        const int NM = c.n_mels, OUTW = c.n_mels * c.reduction, P1 = c.dec_prenet_units[0];
+        const std::string s1 = std::string(kAtt) + "/pre_net/1-FC-" + std::to_string(P1);
+        const auto& w1 = W(h, s1 + "/kernel");   // [NM + att][P1]
+        const auto& b1 = W(h, s1 + "/bias");
+        const auto& wo = W(h, "decoder2/decoder/output_projection_wrapper/kernel");   // [U][OUTW]
+        const auto& bo = W(h, "decoder2/decoder/output_projection_wrapper/bias");
+        const int K = U + att;
+        o_dpfw = p.alloc((size_t)P1 * K);
+        o_dpfb = p.alloc((size_t)P1);
+        for (int n = 0; n < P1; ++n) {
+            for (int k = 0; k < U; ++k) {
+                double acc = 0.0;
+                for (int j = 0; j < NM; ++j)
+                    acc += (double)wo[(size_t)k * OUTW + (OUTW - NM) + j] * (double)w1[(size_t)j * P1 + n];
+                p.host[o_dpfw + (size_t)n * K + k] = (float)acc;
+            }
+            for (int k = 0; k < att; ++k) p.host[o_dpfw + (size_t)n * K + U + k] = w1[(size_t)(NM + k) * P1 + n];
+            double bacc = (double)b1[n];
+            for (int j = 0; j < NM; ++j) bacc += (double)bo[(OUTW - NM) + j] * (double)w1[(size_t)j * P1 + n];
+            p.host[o_dpfb + n] = (float)bacc;
+        }
+    }
     const GruOffsets o_ag = pack_dec_gru(h, p, std::string(kAtt) + "/gru_cell", n_in, att, cudnn);
     const size_t o_al = pack_transposed(p, W(h, std::string(kAtt) + "/attention_layer/kernel").data(), att + mem, att);
     GruOffsets o_dg[4];
@@ -976,7 +1036,10 @@ int tts_finalize_weights(tts_handle_t h) {
     const size_t o_db = pack_copy(p, W(h, "dense/bias").data(), F);
     const size_t o_zero = p.alloc(1024);
 
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    {
+        int rc = sync_all(h);
+        if (rc) return rc;
+    }
     if (h->dec_graph) {
         hipGraphExecDestroy(h->dec_graph);
         h->dec_graph = nullptr;
@@ -1000,6 +1063,7 @@ int tts_finalize_weights(tts_handle_t h) {
     DecoderWeights& d = h->dec;
     std::memset(&d, 0, sizeof(d));
     d.prenet1_wt = base + o_dpw[0]; d.prenet1_b = base + o_dpb[0];
+    d.prenet1f_wt = base + o_dpfw; d.prenet1f_b = base + o_dpfb;
     d.prenet2_wt = base + o_dpw[1]; d.prenet2_b = base + o_dpb[1];
     d.att_gru = {base + o_ag.gates_wt, base + o_ag.gates_b, base + o_ag.cand_wt, base + o_ag.cand_b};
     d.attn_layer_wt = base + o_al;
@@ -1031,6 +1095,7 @@ int tts_memcpy_h2d(tts_handle_t h, void* dst, const void* src, size_t bytes) {
 }
 int tts_memcpy_d2h(tts_handle_t h, void* dst, const void* src, size_t bytes) {
     if (!h) return TTS_ERR_INVALID;
+    if (h->front) HIPCHK(h, hipStreamSynchronize(h->front));   // optional outputs of a pipelined synthesize
     HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return TTS_OK;
@@ -1079,7 +1144,11 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
     WS(h, "dec.keys", float, (size_t)B * Ts * A, keys);
     const size_t state_floats = (size_t)B * (A + A + (size_t)NL * U);
     WS(h, "dec.state", float, state_floats, state);
-    WS(h, "dec.tmp", float, (size_t)B * (c.dec_prenet_units[0] + c.dec_prenet_units[1] + 8 * (size_t)U), tmp);
+    WS(h, "dec.tmp", float, (size_t)B * (c.dec_prenet_units[0] + c.dec_prenet_units[1] + 6 * (size_t)U), tmp);
+    WS(h, "dec.ctx_parts", float, (size_t)TTS_ATT_PARTS * B * mem, ctx_parts);
+    WS(h, "dec.att_stats", float, (size_t)n_steps * B * TTS_ATT_PARTS * 2, att_stats);
+    WS(h, "dec.yhist", float, (size_t)B * n_steps * U, yhist);
+    WS(h, "dec.align_raw", float, (size_t)n_steps * B * Ts, align_raw);
     DecoderScratch sc;
     std::memset(&sc, 0, sizeof(sc));
     sc.state = state;
@@ -1094,47 +1163,52 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
     sc.u = t; t += (size_t)B * U;
     sc.hh = t; t += (size_t)B * U;
     sc.xi = t; t += (size_t)B * U;
-    sc.ctx = t; t += (size_t)B * U;
     sc.y0 = t; t += (size_t)B * U;
     sc.y1 = t; t += (size_t)B * U;
+    sc.ctx_parts = ctx_parts;
+    sc.att_stats = att_stats;
+    sc.yhist = yhist;
+    sc.align_raw = align_raw;
     sc.zeros = h->zeros;
 
-    const int64_t per_step = 2 + 2 + 1 + 1 + 2 * NL + 1;
-    ProfScope ps(h, ST_DECODER, 1 + per_step * n_steps);
+    const int OUT = c.n_mels * c.reduction;
+    const int64_t per_step = 2 + 2 + 1 + 1 + 2 * NL;
+    ProfScope ps(h, ST_DECODER, 3 + per_step * n_steps);
     // keys = memory_layer(memory), no bias (LuongAttention; values stay the raw memory)
     if ((rc = run_single(h, dense_group(memory, mem, h->mem_wt, nullptr, keys, A, B * Ts, A, mem, ACT_NONE)))) return rc;
 
     if (!h->use_graph) {
-        HIPCHK(h, decoder_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, mel, alignments, c.force_cudnn));
-        return TTS_OK;
+        HIPCHK(h, decoder_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, alignments, c.force_cudnn));
+    } else {
+        auto& k = h->dec_key;
+        if (!h->dec_graph || k.memory != memory || k.align != alignments || k.B != B || k.Ts != Ts ||
+            k.n_steps != n_steps) {
+            if (h->dec_graph) {
+                hipGraphExecDestroy(h->dec_graph);
+                h->dec_graph = nullptr;
+            }
+            hipGraph_t graph = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            hipError_t e = decoder_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, alignments, c.force_cudnn);
+            hipError_t e2 = hipStreamEndCapture(h->stream, &graph);
+            if (e != hipSuccess || e2 != hipSuccess) {
+                if (graph) hipGraphDestroy(graph);
+                h->err = std::string("decoder graph capture failed: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+                return TTS_ERR_HIP;
+            }
+            e = hipGraphInstantiate(&h->dec_graph, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (e != hipSuccess) {
+                h->dec_graph = nullptr;
+                h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
+                return TTS_ERR_HIP;
+            }
+            k.memory = memory; k.mel = nullptr; k.align = alignments; k.B = B; k.Ts = Ts; k.n_steps = n_steps;
+        }
+        HIPCHK(h, hipGraphLaunch(h->dec_graph, h->stream));
     }
-    auto& k = h->dec_key;
-    if (!h->dec_graph || k.memory != memory || k.mel != mel || k.align != alignments || k.B != B || k.Ts != Ts ||
-        k.n_steps != n_steps) {
-        if (h->dec_graph) {
-            hipGraphExecDestroy(h->dec_graph);
-            h->dec_graph = nullptr;
-        }
-        hipGraph_t graph = nullptr;
-        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        hipError_t e = decoder_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, mel, alignments, c.force_cudnn);
-        hipError_t e2 = hipStreamEndCapture(h->stream, &graph);
-        if (e != hipSuccess || e2 != hipSuccess) {
-            if (graph) hipGraphDestroy(graph);
-            h->err = std::string("decoder graph capture failed: ") + hipGetErrorString(e != hipSuccess ? e : e2);
-            return TTS_ERR_HIP;
-        }
-        e = hipGraphInstantiate(&h->dec_graph, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
-        if (e != hipSuccess) {
-            h->dec_graph = nullptr;
-            h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
-            return TTS_ERR_HIP;
-        }
-        k.memory = memory; k.mel = mel; k.align = alignments; k.B = B; k.Ts = Ts; k.n_steps = n_steps;
-    }
-    HIPCHK(h, hipGraphLaunch(h->dec_graph, h->stream));
-    return TTS_OK;
+    // OutputProjectionWrapper for all steps at once: mel[b][t][:] = y[b][t] W_o + b_o
+    return run_single(h, dense_group(yhist, U, h->dec.out_wt, h->dec.out_b, mel, OUT, B * n_steps, OUT, U, ACT_NONE));
 }
 
 int tts_postnet_forward(tts_handle_t h, const float* mel, int B, int T, float* linear) {
@@ -1296,9 +1370,67 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         linear = linb;
     }
     WS(h, "gl.mag", float, (size_t)B * T * FP, magi);
-    if ((rc = tts_encoder_forward(h, ids, B, Ts, memory))) return rc;
-    if ((rc = tts_decoder_forward(h, memory, B, Ts, sp->n_steps, mel, align_out))) return rc;
+    if (h->pipeline) {
+        if (!h->front) {
+            // The decoder's ~2200 small dependent launches must not queue behind the long, CU-filling
+            // Griffin-Lim workgroups of the previous call: reserve `reserve_cus` CUs for the front
+            // stream with CU masks (front = those CUs only, main = all the others).  Falls back to
+            // a plain high-priority stream when masking is unavailable or the main stream is borrowed.
+            bool masked = false;
+            if (h->reserve_cus > 0 && h->own_stream) {
+                hipDeviceProp_t prop;
+                HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+                const int ncu = prop.multiProcessorCount;
+                const int words = (ncu + 31) / 32;
+                if (h->reserve_cus < ncu / 2) {
+                    std::vector<uint32_t> mf(words, 0u), mm(words, 0u);
+                    for (int i = 0; i < ncu; ++i) {
+                        if (i < h->reserve_cus) mf[i / 32] |= 1u << (i % 32);
+                        else mm[i / 32] |= 1u << (i % 32);
+                    }
+                    hipStream_t sf = nullptr, sm = nullptr;
+                    if (hipExtStreamCreateWithCUMask(&sf, words, mf.data()) == hipSuccess &&
+                        hipExtStreamCreateWithCUMask(&sm, words, mm.data()) == hipSuccess) {
+                        HIPCHK(h, hipStreamSynchronize(h->stream));
+                        hipStreamDestroy(h->stream);
+                        h->stream = sm;
+                        h->front = sf;
+                        masked = true;
+                    } else {
+                        if (sf) hipStreamDestroy(sf);
+                        if (sm) hipStreamDestroy(sm);
+                        (void)hipGetLastError();
+                    }
+                }
+            }
+            if (!masked) {
+                int prio_least = 0, prio_greatest = 0;
+                HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+                HIPCHK(h, hipStreamCreateWithPriority(&h->front, hipStreamNonBlocking, prio_greatest));
+            }
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_front_done, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_post_done, hipEventDisableTiming));
+        }
+    }
+    hipStream_t main_stream = h->stream;
+    if (h->pipeline) {
+        // the previous call's post-net still reads the shared mel / scratch the decoder writes
+        if (h->post_pending) HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_post_done, 0));
+        h->stream = h->front;
+    }
+    rc = tts_encoder_forward(h, ids, B, Ts, memory);
+    if (!rc) rc = tts_decoder_forward(h, memory, B, Ts, sp->n_steps, mel, align_out);
+    h->stream = main_stream;
+    if (rc) return rc;
+    if (h->pipeline) {
+        HIPCHK(h, hipEventRecord(h->ev_front_done, h->front));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_front_done, 0));
+    }
     if ((rc = tts_postnet_forward(h, mel, B, T, linear))) return rc;
+    if (h->pipeline) {
+        HIPCHK(h, hipEventRecord(h->ev_post_done, h->stream));
+        h->post_pending = true;
+    }
     {
         ProfScope ps(h, ST_DENORM, 1);
         HIPCHK(h, launch_denorm_power(h->stream, linear, magi, (size_t)B * T, F, FP, sp->ref_db, sp->max_db, sp->power));

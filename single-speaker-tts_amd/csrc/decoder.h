@@ -6,8 +6,12 @@ namespace tts {
 
 enum DecEpi { DEC_EPI_ACT = 0, DEC_EPI_GRU_GATES = 1, DEC_EPI_GRU_CAND = 2, DEC_EPI_GRU_CUDNN_PRE = 3 };
 
+#define TTS_ATT_PARTS 4   // attention positions are split over this many workgroups per utterance
+
 // out[B][N] = epi( [a0 | a1][B][K] . Wt[N][K]^T + bias ); the A operand is the concatenation of
 // two row-major segments: columns [0,k0) from a0 (row stride lda0), [k0,K) from a1 (lda1).
+// With `parts` set, segment 1 is the attention context assembled on the fly from the
+// TTS_ATT_PARTS partial contexts and their softmax statistics (see dec_attention_kernel).
 struct DecGemm {
     const float* a0;
     const float* a1;
@@ -20,9 +24,11 @@ struct DecGemm {
     float* hh;
     float* xi;
     const float* resid;
+    const float* parts;  // [TTS_ATT_PARTS][B][lda1] partial (unnormalised) contexts or null
+    const float* stats;  // [B][TTS_ATT_PARTS][2] = (max, sum) per part
     int lda0, lda1, k0;
     int B, N, K;
-    int ldo, U, act, epi;
+    int ldo, ldr, U, act, epi;
 };
 
 struct DecoderWeights {
@@ -32,12 +38,13 @@ struct DecoderWeights {
         const float* cand_wt;   // [U][in+U]   (GRUCell only)
         const float* cand_b;
     };
-    const float* prenet1_wt; const float* prenet1_b;   // [P1][n_mels + A]
-    const float* prenet2_wt; const float* prenet2_b;   // [P2][P1]
+    const float* prenet1_wt; const float* prenet1_b;     // [P1][n_mels + A]   (step 0: GO frame)
+    const float* prenet1f_wt; const float* prenet1f_b;   // [P1][U + A] with the output projection folded in
+    const float* prenet2_wt; const float* prenet2_b;     // [P2][P1]
     Gru att_gru;
-    const float* attn_layer_wt;                        // [A][A + mem]
+    const float* attn_layer_wt;                          // [A][A + mem]
     Gru gru[4];
-    const float* out_wt; const float* out_b;           // [r*n_mels][U]
+    const float* out_wt; const float* out_b;             // [r*n_mels][U]
     int n_layers, att_units, dec_units, mem_units, n_mels, reduction, prenet1_units, prenet2_units;
 };
 
@@ -45,13 +52,19 @@ struct DecoderScratch {
     float* state;        // att | h_att | h_dec[0..n_layers) contiguous, zeroed per call
     size_t state_bytes;
     float* att; float* h_att; float* h_dec[4];
-    float* p1; float* p2; float* rh; float* u; float* hh; float* xi; float* ctx; float* y0; float* y1;
+    float* p1; float* p2; float* rh; float* u; float* hh; float* xi; float* y0; float* y1;
+    float* ctx_parts;    // [TTS_ATT_PARTS][B][mem]
+    float* att_stats;    // [n_steps][B][TTS_ATT_PARTS][2]
+    float* yhist;        // [B][n_steps][U]: top-layer outputs of every step (feeds the deferred output projection)
+    float* align_raw;    // [n_steps][B][Ts] unnormalised exp(score - part max), used when the caller wants no alignments
     const float* zeros;  // >= n_mels zero floats
 };
 
-// Enqueues the whole n_steps loop on stream s (capturable: no syncs, no allocations).
+// Enqueues the whole n_steps loop on stream s (capturable: no syncs, no allocations), including
+// the deferred alignment normalisation.  The output projection of all steps (yhist -> mel) is
+// one large GEMM issued by the caller.
 hipError_t decoder_enqueue(hipStream_t s, const DecoderWeights& w, const DecoderScratch& sc,
                            const float* memory, const float* keys, int B, int Ts, int n_steps,
-                           float* mel, float* align, int cudnn);
+                           float* align, int cudnn);
 
 }  // namespace tts

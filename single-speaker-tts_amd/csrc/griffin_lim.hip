@@ -133,17 +133,15 @@ __device__ __forceinline__ void fft1024(cf (&v)[16], cf* ex, const FftTw& tw, in
 #define MH 1024            // NFFT / 2
 
 __device__ __forceinline__ cf unit_phasor(cf z) {
-    // exp(1j * angle(z)); angle(0) = 0 -> 1+0j  (reference audio/synthesis.py:109)
-    const float s = fmaf(z.x, z.x, z.y * z.y);
-    if (s > 1e-30f && s < 1e30f) {   // common case: no risk of under/overflow in s
-        const float r = rsqrtf(s);
-        return cmk(z.x * r, z.y * r);
-    }
-    const float m = fmaxf(fabsf(z.x), fabsf(z.y));
-    if (!(m > 0.f)) return cmk(1.f, 0.f);
-    const float xr = z.x / m, xi = z.y / m;
-    const float r = rsqrtf(xr * xr + xi * xi);
-    return cmk(xr * r, xi * r);
+    // exp(1j * angle(z)); angle(0) = 0 -> 1+0j  (reference audio/synthesis.py:109).  Branch-free:
+    // exact power-of-two pre-scaling keeps x^2 + y^2 inside the normal range.
+    const float ax = fmaxf(fabsf(z.x), fabsf(z.y));
+    const float sc = ax < 1e-18f ? 1.8446744e19f : (ax > 1e18f ? 5.4210109e-20f : 1.0f);   // 2^64, 2^-64
+    const float x = z.x * sc, y = z.y * sc;
+    const float s = fmaf(x, x, y * y);
+    const float r = rsqrtf(s);
+    const bool ok = s > 0.f && r < 3.0e38f;
+    return cmk(ok ? x * r : 1.f, ok ? y * r : 0.f);
 }
 
 struct GlFrameRegs {   // one frame's |S| and phase row, as loaded (k = 4*lane + 256*jj + 0..3)
@@ -155,7 +153,7 @@ struct GlFrameRegs {   // one frame's |S| and phase row, as loaded (k = 4*lane +
 // MODE 0: iteration (phase_in -> phase_out); MODE 1: final iSTFT (phase_in -> wav).
 // WIN_CT / HOP_CT: compile-time window / hop (0 = take them from the parameters); the reference
 // configuration 1102 / 275 gets its own instantiation so that all window-support tests fold away.
-template <int MODE, int WIN_CT, int HOP_CT>
+template <int MODE, int WIN_CT, int HOP_CT, bool MSE>
 __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int win = WIN_CT ? WIN_CT : p.win;
@@ -203,8 +201,21 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         if (lane == 0) { g.mn = mrow[MH]; g.pn = prow[MH].x; }
     };
 
+#ifndef GL_PREFETCH_REGS
+#define GL_PREFETCH_REGS 1
+#endif
+    // L2-warming touch of a frame's rows: one dword per 128-byte line (used instead of the register
+    // prefetch when GL_PREFETCH_REGS == 0)
+    auto touch_frame = [&](int fa, float& ta, float& tb) {
+        ta = 0.f; tb = 0.f;
+        if (!frame_valid(fa)) return;
+        const int tf = t0 - halo + fa;
+        ta = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(magb + (size_t)tf * p.FP) + lane * 64);
+        tb = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(phb + (size_t)tf * p.FP) + lane * 128);
+    };
     GlFrameRegs nxt;
-    load_frame(0 + ncol * wave, nxt);   // round 0's frame, in flight during the prologue
+    float ta = 0.f, tb = 0.f;
+    if (GL_PREFETCH_REGS) load_frame(0 + ncol * wave, nxt);   // round 0's frame, in flight during the prologue
 
     for (int i = tid; i < win; i += GL_THREADS) wtab[i] = p.window[i];
     for (int i = tid; i < span; i += GL_THREADS) sig[i] = 0.f;
@@ -219,8 +230,14 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     // ---------------- phase A: inverse FFT + windowed overlap-add into LDS
     for (int r = 0; r < ncol; ++r) {
         const int fa = r + ncol * wave;
-        GlFrameRegs cur = nxt;
-        if (r + 1 < ncol) load_frame(fa + 1, nxt);
+        GlFrameRegs cur;
+        if (GL_PREFETCH_REGS) {
+            cur = nxt;
+            if (r + 1 < ncol) load_frame(fa + 1, nxt);
+        } else {
+            load_frame(fa, cur);
+            if (r + 1 < ncol) touch_frame(fa + 1, ta, tb);
+        }
         if (frame_valid(fa)) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -260,6 +277,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 if (nw1 >= 0 && nw1 < win) sf[nw1] += wtab[nw1] * (-v[c].y * inv);
             }
         }
+        if (!GL_PREFETCH_REGS) asm volatile("" ::"v"(ta), "v"(tb));
         __syncthreads();
     }
 
@@ -343,7 +361,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             const cf o = cmul(twR[k], cscale(csub(zk, zm), 0.5f));
             const cf x = cadd(e, cmul_mi(o));
             orow[k] = unit_phasor(x);
-            if (p.mse_partial) {
+            if (MSE) {
                 const float d = fabsf(mrow[k]) - sqrtf(x.x * x.x + x.y * x.y);
                 mse_acc += d * d;
             }
@@ -352,14 +370,14 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             const cf z0 = v[0];
             const float xn = z0.x - z0.y;   // Nyquist bin, real
             orow[MH] = cmk(xn < 0.f ? -1.f : 1.f, 0.f);
-            if (p.mse_partial) {
+            if (MSE) {
                 const float d = fabsf(mrow[MH]) - fabsf(xn);
                 mse_acc += d * d;
             }
         }
         wave_lds_sync();
     }
-    if (p.mse_partial) {
+    if (MSE) {
         __syncthreads();   // all waves done with their exchange buffers
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mse_acc += __shfl_xor(mse_acc, o);
@@ -382,18 +400,20 @@ size_t gl_lds_bytes(const GlParams& p) {
            (size_t)((span + 3) & ~3) * sizeof(float);
 }
 
-template <int MODE, int W, int H>
+template <int MODE, int W, int H, bool MSE>
 static hipError_t gl_set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_iter_kernel<MODE, W, H>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_iter_kernel<MODE, W, H, MSE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 hipError_t gl_configure() {
     hipError_t e;
-    if ((e = gl_set_attr<0, 0, 0>()) != hipSuccess) return e;
-    if ((e = gl_set_attr<1, 0, 0>()) != hipSuccess) return e;
-    if ((e = gl_set_attr<0, 1102, 275>()) != hipSuccess) return e;
-    return gl_set_attr<1, 1102, 275>();
+    if ((e = gl_set_attr<0, 0, 0, false>()) != hipSuccess) return e;
+    if ((e = gl_set_attr<0, 0, 0, true>()) != hipSuccess) return e;
+    if ((e = gl_set_attr<1, 0, 0, false>()) != hipSuccess) return e;
+    if ((e = gl_set_attr<0, 1102, 275, false>()) != hipSuccess) return e;
+    if ((e = gl_set_attr<0, 1102, 275, true>()) != hipSuccess) return e;
+    return gl_set_attr<1, 1102, 275, false>();
 }
 
 hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int B, int final_istft) {
@@ -401,13 +421,19 @@ hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int B, int final_ist
     dim3 grid(nchunks, B);
     const size_t lds = gl_lds_bytes(p);
     const bool ref_cfg = p.win == 1102 && p.hop == 275;   // the reference's 50 ms / 12.5 ms at 22.05 kHz
+    const bool mse = p.mse_partial != nullptr;
+#define GL_LAUNCH(MODE, W, H, M) hipLaunchKernelGGL((gl_iter_kernel<MODE, W, H, M>), grid, dim3(GL_THREADS), lds, s, p)
     if (final_istft) {
-        if (ref_cfg) hipLaunchKernelGGL((gl_iter_kernel<1, 1102, 275>), grid, dim3(GL_THREADS), lds, s, p);
-        else hipLaunchKernelGGL((gl_iter_kernel<1, 0, 0>), grid, dim3(GL_THREADS), lds, s, p);
+        if (ref_cfg) GL_LAUNCH(1, 1102, 275, false);
+        else GL_LAUNCH(1, 0, 0, false);
+    } else if (mse) {
+        if (ref_cfg) GL_LAUNCH(0, 1102, 275, true);
+        else GL_LAUNCH(0, 0, 0, true);
     } else {
-        if (ref_cfg) hipLaunchKernelGGL((gl_iter_kernel<0, 1102, 275>), grid, dim3(GL_THREADS), lds, s, p);
-        else hipLaunchKernelGGL((gl_iter_kernel<0, 0, 0>), grid, dim3(GL_THREADS), lds, s, p);
+        if (ref_cfg) GL_LAUNCH(0, 1102, 275, false);
+        else GL_LAUNCH(0, 0, 0, false);
     }
+#undef GL_LAUNCH
     return hipGetLastError();
 }
 

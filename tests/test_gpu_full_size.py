@@ -109,7 +109,7 @@ def test_end_to_end_synthesize_matches_staged(engine, hparams):
     mel, al = engine.decoder_forward(mem, 10)
     lin = engine.postnet_forward(mel.to_host().reshape(3, 50, 80))
     mag = engine.denorm_power(lin, 6.02, 99.89, 1.3)
-    wav, _ = engine.griffin_lim(mag, 4, WIN, HOP, N_FFT, init_phase=init)
+    wav, _ = engine.griffin_lim(mag, 4, WIN, HOP, N_FFT, init_phase=init, want_mse=False)   # same kernel variant
     wav = engine.peak_normalize(wav)
     assert np.array_equal(out['mel'].to_host().reshape(3, 10, 400), mel.to_host())
     assert np.array_equal(out['linear'].to_host(), lin.to_host())
