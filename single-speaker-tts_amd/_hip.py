@@ -15,7 +15,7 @@ from ctypes import (POINTER, byref, c_char_p, c_float, c_int, c_int32, c_int64, 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsstts_hip.so')
+LIB_PATH = os.environ.get('SSTTS_HIP_LIB') or os.path.join(_HERE, 'libsstts_hip.so')
 
 TTS_OK = 0
 TTS_ERR_INVALID = -1

@@ -45,9 +45,15 @@ __device__ __forceinline__ cf cmul_pi(cf a) { return cmk(-a.y, a.x); }   // a * 
 __device__ __forceinline__ cf cscale(cf a, float s) { return cmk(a.x * s, a.y * s); }
 
 __device__ __forceinline__ void wave_lds_sync() {
-    // LDS hand-off between lanes of ONE wave: LDS executes a wave's DS ops in order; this only
-    // stops the compiler from moving memory operations across the hand-off point.
+    // LDS hand-off between lanes of ONE wave.  The LDS unit executes one wave's DS operations in
+    // issue order, so a ds_read issued after a ds_write of the same wave observes it for every
+    // lane: no s_waitcnt is needed, only a compiler-level ordering point (the compiler still waits
+    // on lgkmcnt before it USES a loaded register).
+#ifdef GL_DRAIN_LDS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -164,16 +170,19 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     cf* twR = ex_all + GL_NW * EX_CPLX;
     cf* twA = twR + 1024;
     float* wtab = reinterpret_cast<float*>(twA + 15 * 64);
-    float* sig = wtab + ((win + 3) & ~3);
+    int* ola_done = reinterpret_cast<int*>(wtab + ((win + 3) & ~3));   // overlap-add progress per wave (16 ints)
+    float* sig = reinterpret_cast<float*>(ola_done + 16);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     cf* ex = ex_all + wave * EX_CPLX;
     const int b = blockIdx.y;
-    const int t0 = blockIdx.x * p.C;
+    // frames owned per workgroup: 8*ncol - 2*halo (= 32 for the reference configuration)
+    const int C = (WIN_CT && HOP_CT) ? (GL_NW * ncol - 2 * (ncol - 1) > 32 ? 32 : GL_NW * ncol - 2 * (ncol - 1)) : p.C;
+    const int t0 = blockIdx.x * C;
     const int halo = ncol - 1;
-    const int nA = p.C + 2 * halo;
+    const int nA = C + 2 * halo;
     const int span = (nA - 1) * hop + win;
     const int wpad = (NFFT - win) >> 1;
     const int L = hop * (p.T - 1);
@@ -215,8 +224,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     };
     GlFrameRegs nxt;
     float ta = 0.f, tb = 0.f;
-    if (GL_PREFETCH_REGS) load_frame(0 + ncol * wave, nxt);   // round 0's frame, in flight during the prologue
+    load_frame(0 + ncol * wave, nxt);   // round 0's frame, in flight during the prologue
 
+    if (tid < GL_NW) ola_done[tid] = 0;
     for (int i = tid; i < win; i += GL_THREADS) wtab[i] = p.window[i];
     for (int i = tid; i < span; i += GL_THREADS) sig[i] = 0.f;
     for (int i = tid; i < 1024; i += GL_THREADS) twR[i] = p.tw2048[i];
@@ -226,60 +236,85 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     for (int d = 1; d < 4; ++d) tw.b[d - 1] = p.tw1024[16 * (lane & 15) * d];
     tw.a = twA + lane;
     __syncthreads();
+    // this lane's window samples (n = 2*(lane + 64 c) + {0,1}); wreg carries the iFFT scale 1/(2*MH)
+    // (the forward FFT of phase B uses the same scaled window: unit phasors do not depend on scale)
+    float wreg[16][2];
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int nw = 2 * (lane + 64 * c) + e - wpad;
+            wreg[c][e] = (nw >= 0 && nw < win) ? wtab[nw] * (0.5f / (float)MH) : 0.f;
+        }
 
     // ---------------- phase A: inverse FFT + windowed overlap-add into LDS
+#ifndef GL_NO_UNROLL_A
+#pragma unroll
+#endif
     for (int r = 0; r < ncol; ++r) {
         const int fa = r + ncol * wave;
-        GlFrameRegs cur;
-        if (GL_PREFETCH_REGS) {
-            cur = nxt;
-            if (r + 1 < ncol) load_frame(fa + 1, nxt);
-        } else {
-            load_frame(fa, cur);
-            if (r + 1 < ncol) touch_frame(fa + 1, ta, tb);
-        }
-        if (frame_valid(fa)) {
+        const bool ok = frame_valid(fa);
+        cf v[16];
+        if (ok) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int k = 4 * lane + 256 * jj;
-                const float4 m4 = cur.m[jj], pa = cur.pa[jj], pb = cur.pb[jj];
+                const float4 m4 = nxt.m[jj], pa = nxt.pa[jj], pb = nxt.pb[jj];
                 float4 xa, xb;
                 xa.x = m4.x * pa.x; xa.y = m4.x * pa.y; xa.z = m4.y * pa.z; xa.w = m4.y * pa.w;
                 xb.x = m4.z * pb.x; xb.y = m4.z * pb.y; xb.z = m4.w * pb.z; xb.w = m4.w * pb.w;
                 *reinterpret_cast<float4*>(ex + k) = xa;
                 *reinterpret_cast<float4*>(ex + k + 2) = xb;
             }
-            if (lane == 0) ex[MH] = cmk(cur.mn * cur.pn, 0.f);
+            if (lane == 0) ex[MH] = cmk(nxt.mn * nxt.pn, 0.f);
+        }
+        // the raw rows are consumed: fetch the next round's frame into the same registers now, it
+        // lands while this frame's FFT runs
+        if (r + 1 < ncol) load_frame(fa + 1, nxt);
+        if (ok) {
             wave_lds_sync();
-            cf v[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int k = lane + 64 * j;
                 cf xk = ex[k];
                 cf xm = cconj(ex[MH - k]);
                 if (k == 0) { xk.y = 0.f; xm.y = 0.f; }
-                // Zin = E + i O, E = (xk + xm)/2, O = conj(twr) (xk - xm)/2 ; feed conj(Zin)
-                const cf e = cscale(cadd(xk, xm), 0.5f);
-                const cf o = cmul(cconj(twR[k]), cscale(csub(xk, xm), 0.5f));
+                // Zin = E + i O, E = (xk + xm)/2, O = conj(twr) (xk - xm)/2 ; feed conj(Zin).
+                // The two 1/2 factors are folded into the output scale (the FFT is linear).
+                const cf e = cadd(xk, xm);
+                const cf o = cmul(cconj(twR[k]), csub(xk, xm));
                 const cf zin = cadd(e, cmul_pi(o));
                 v[j] = cconj(zin);
             }
             wave_lds_sync();
             fft1024(v, ex, tw, lane);
             // z[m] = conj(v)/MH, m = lane + 64 c: x[2m] = Re, x[2m+1] = Im
-            const float inv = 1.0f / (float)MH;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] = cmk(v[c].x * wreg[c][0], -v[c].y * wreg[c][1]);
+        }
+        // Overlap-add ordering without a workgroup barrier: frame fa = r + ncol*wave overlaps, among
+        // the frames of OTHER waves, only frames of wave+1 from EARLIER rounds (distance
+        // ncol + r' - r < ncol iff r' < r).  So wave w may accumulate round r once wave w+1 has
+        // finished rounds < r; every overlapping pair is ordered => fixed summation order.
+        if (r > 0 && wave + 1 < GL_NW) {
+            volatile int* flag = ola_done + wave + 1;
+            while (*flag < r) __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        if (ok) {
             float* sf = sig + fa * hop;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const int n = 2 * (lane + 64 * c);
                 const int nw0 = n - wpad, nw1 = n + 1 - wpad;
-                if (nw0 >= 0 && nw0 < win) sf[nw0] += wtab[nw0] * (v[c].x * inv);
-                if (nw1 >= 0 && nw1 < win) sf[nw1] += wtab[nw1] * (-v[c].y * inv);
+                if (nw0 >= 0 && nw0 < win) sf[nw0] += v[c].x;
+                if (nw1 >= 0 && nw1 < win) sf[nw1] += v[c].y;
             }
         }
-        if (!GL_PREFETCH_REGS) asm volatile("" ::"v"(ta), "v"(tb));
-        __syncthreads();
+        asm volatile("" ::: "memory");
+        if (lane == 0) *reinterpret_cast<volatile int*>(ola_done + wave) = r + 1;
     }
+    __syncthreads();
 
     // ---------------- window-sum-square normalisation (librosa istft: divide where wss > tiny)
     const int ybase = (t0 - halo) * hop + wpad - MH;   // trimmed-signal index of sig[0]
@@ -297,7 +332,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         // owned samples: y in [t0*hop, (t0+C)*hop) intersected with [0, L)
         float* wb = p.wav + (size_t)b * L;
         const int y0 = t0 * hop;
-        const int y1 = min((t0 + p.C) * hop, L);
+        const int y1 = min((t0 + C) * hop, L);
         for (int y = y0 + tid; y < y1; y += GL_THREADS) wb[y] = sig[y - ybase];
         return;
     }
@@ -305,11 +340,14 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     // ---------------- phase B: forward FFT of the owned frames, new unit phasors
     cf* pob = p.phase_out + (size_t)b * p.T * p.FP;
     float mse_acc = 0.f;
-    const int nB = (p.C + GL_NW - 1) / GL_NW;
+    const int nB = (C + GL_NW - 1) / GL_NW;
+#ifdef GL_UNROLL_B
+#pragma unroll
+#endif
     for (int r = 0; r < nB; ++r) {
         const int fb = wave + GL_NW * r;
         const int t = t0 + fb;
-        if (fb >= p.C || t >= p.T) continue;   // wave-uniform
+        if (fb >= C || t >= p.T) continue;   // wave-uniform
         cf v[16];
         const int ylo = t * hop + wpad - MH;          // y index of window sample 0
         const bool edge = ylo < 0 || ylo + win > L;   // wave-uniform: reflect padding needed
@@ -320,8 +358,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 const int n = 2 * (lane + 64 * j);
                 const int nw0 = n - wpad, nw1 = n + 1 - wpad;
                 float x0 = 0.f, x1 = 0.f;
-                if (nw0 >= 0 && nw0 < win) x0 = wtab[nw0] * sf[nw0];
-                if (nw1 >= 0 && nw1 < win) x1 = wtab[nw1] * sf[nw1];
+                if (nw0 >= 0 && nw0 < win) x0 = wreg[j][0] * sf[nw0];
+                if (nw1 >= 0 && nw1 < win) x1 = wreg[j][1] * sf[nw1];
                 v[j] = cmk(x0, x1);
             }
         } else {
@@ -334,13 +372,13 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                     int y = ylo + nw0;
                     y = y < 0 ? -y : y;
                     y = y >= L ? 2 * (L - 1) - y : y;
-                    x0 = wtab[nw0] * sig[y - ybase];
+                    x0 = wreg[j][0] * sig[y - ybase];
                 }
                 if (nw1 >= 0 && nw1 < win) {
                     int y = ylo + nw1;
                     y = y < 0 ? -y : y;
                     y = y >= L ? 2 * (L - 1) - y : y;
-                    x1 = wtab[nw1] * sig[y - ybase];
+                    x1 = wreg[j][1] * sig[y - ybase];
                 }
                 v[j] = cmk(x0, x1);
             }
@@ -356,13 +394,13 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             const int k = lane + 64 * c;
             const cf zk = v[c];
             const cf zm = cconj(ex[(MH - k) & (MH - 1)]);
-            // X[k] = (zk + zm)/2 - (i/2) twr (zk - zm)
-            const cf e = cscale(cadd(zk, zm), 0.5f);
-            const cf o = cmul(twR[k], cscale(csub(zk, zm), 0.5f));
+            // 2 X[k] = (zk + zm) - i twr (zk - zm); the phase does not care about the factor 2
+            const cf e = cadd(zk, zm);
+            const cf o = cmul(twR[k], csub(zk, zm));
             const cf x = cadd(e, cmul_mi(o));
             orow[k] = unit_phasor(x);
             if (MSE) {
-                const float d = fabsf(mrow[k]) - sqrtf(x.x * x.x + x.y * x.y);
+                const float d = fabsf(mrow[k]) - (float)MH * sqrtf(x.x * x.x + x.y * x.y);   // x = X / MH
                 mse_acc += d * d;
             }
         }
@@ -371,7 +409,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             const float xn = z0.x - z0.y;   // Nyquist bin, real
             orow[MH] = cmk(xn < 0.f ? -1.f : 1.f, 0.f);
             if (MSE) {
-                const float d = fabsf(mrow[MH]) - fabsf(xn);
+                const float d = fabsf(mrow[MH]) - (2.0f * MH) * fabsf(xn);   // xn = X[MH] / (2 MH)
                 mse_acc += d * d;
             }
         }
@@ -397,7 +435,7 @@ size_t gl_lds_bytes(const GlParams& p) {
     const int nA = p.C + 2 * halo;
     const int span = (nA - 1) * p.hop + p.win;
     return (size_t)(GL_NW * EX_CPLX + 1024 + 15 * 64) * sizeof(cf) + (size_t)((p.win + 3) & ~3) * sizeof(float) +
-           (size_t)((span + 3) & ~3) * sizeof(float);
+           16 * sizeof(int) + (size_t)((span + 3) & ~3) * sizeof(float);
 }
 
 template <int MODE, int W, int H, bool MSE>
