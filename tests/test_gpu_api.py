@@ -176,3 +176,22 @@ def test_synthesize_sentences_writes_numbered_wavs(weights, tmp_path):
     sr, d = wavfile.read(tmp_path / '2.wav')
     assert sr == 22050 and d.dtype == np.float32 and d.shape == wavs[1].shape == (275 * 19,)
     assert np.isclose(np.abs(d).max(), 1.0)
+
+
+def test_serve_helpers(weights, tmp_path):
+    S = pkg('tacotron.serve')
+    P = pkg('tacotron.params')
+    LJ = pkg('datasets.lj_speech').LJSpeechDatasetHelper
+    ds = LJ('/nonexistent', dict(P.dataset_params.vocabulary_dict), False)
+    ids = S.pre_process_sentences(['Hello there.', 'Hi'], ds)
+    assert ids.dtype == np.int32 and ids.shape == (2, 12) and ids[1].tolist()[:3] == [9, 4, 1] and ids[1, 3:].sum() == 0
+    P.model_params.decoder.maximum_iterations = 20
+    P.model_params.reconstruction_iterations = 2
+    try:
+        gen = S.serve(iter([['Hello there.', 'Hi'], ['One more.']]), weights)
+        first = next(gen)
+        second = next(gen)
+    finally:
+        P.model_params.decoder.maximum_iterations = 1000
+        P.model_params.reconstruction_iterations = 50
+    assert len(first) == 2 and len(second) == 1 and first[0].shape == (275 * 19,) and np.isfinite(first[1]).all()
