@@ -183,7 +183,7 @@ def main():
                 traffic = json.load(f).get('hbm_bytes_per_launch')
         out = {
             'metric': 'mel-frames/sec (end-to-end text->waveform incl. 60-iter Griffin-Lim, 64-utt LJ-Speech-shaped batch per GPU)',
-            'value': frames_total / elapsed,
+            'value': frames_total * args.steps / elapsed,
             'unit': 'mel-frames/s',
             'n_gpus': world,
             'steps': args.steps,
