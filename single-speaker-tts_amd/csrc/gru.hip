@@ -5,11 +5,15 @@
 // state (no sequence_length), outputs concatenated [fw | bw].
 //
 // The input halves (x W_x + b for r, u, c and both directions) are one big MFMA GEMM done
-// beforehand; this kernel is the strictly sequential part.  It is latency bound, so the
-// design keeps everything on chip: one 256-thread workgroup per (utterance, direction), the
-// recurrent weights live in VGPRs for the whole sequence (128 + 64 floats per thread), the
-// state lives in LDS and is broadcast-read as float4, and the next step's input projections
-// are prefetched while the current step computes.
+// beforehand; this kernel is the strictly sequential part.  It is latency bound (T dependent
+// steps of a 128 -> 384 mat-vec), so the design minimises the dependent chain of one step:
+//   * one 1024-thread workgroup per (utterance, direction): 16 waves = 4 per SIMD hide the LDS and
+//     transcendental latencies of each other;
+//   * the recurrent weights live in VGPRs for the whole sequence; every gate column is split
+//     over 4 lanes (K/4 = 32 FMAs each), every candidate column over 8 lanes (16 FMAs each), and
+//     the partial sums are combined with DPP shuffles inside the wave (no LDS round trip);
+//   * the state lives in LDS in a padded layout whose four K-quarters fall into different banks;
+//   * the next step's input projections are prefetched while the current step computes.
 //
 //   GRUCell [TF-1.8]       : [r|u] = sig(xg + h Wgh);  c = tanh(xc + (r*h) Wch);  h' = u h + (1-u) c
 //   CudnnCompatibleGRUCell : c = tanh(xc + r * (h Wch + bch))
@@ -17,39 +21,42 @@
 
 namespace tts {
 
+#define GRU_THREADS 1024
+#define GRU_QPAD 36   // floats per K-quarter of the state in LDS (32 + 4: quarters hit different banks)
+
 template <int H, bool CUDNN>
-__global__ __launch_bounds__(2 * H) void bigru_kernel(const float* __restrict__ xproj, int xld,
-                                                      const float* __restrict__ wrec,
-                                                      float* __restrict__ out, int B, int T) {
-    constexpr int NT = 2 * H;        // threads
-    constexpr int HALF = H / 2;      // k-range of one candidate partial sum
+__global__ __launch_bounds__(GRU_THREADS) void bigru_kernel(const float* __restrict__ xproj, int xld,
+                                                            const float* __restrict__ wrec,
+                                                            float* __restrict__ out, int B, int T) {
+    static_assert(H == 128, "thread mapping assumes 128 units");
     const int b = blockIdx.x;
     const int d = blockIdx.y;        // 0 = forward, 1 = backward
-    const int n = threadIdx.x;
-    const int half = n / H;
-    const int col = n % H;
+    const int tid = threadIdx.x;
+    // phase 1 mapping: gate column gc (0..2H-1), K quarter kq
+    const int gc = tid >> 2, kq = tid & 3;
+    // phase 2 mapping: candidate column cc (0..H-1), K eighth ke
+    const int cc = tid >> 3, ke = tid & 7;
 
-    __shared__ __attribute__((aligned(16))) float hs[H];
-    __shared__ __attribute__((aligned(16))) float rhs[H];
-    __shared__ __attribute__((aligned(16))) float us[H];
-    __shared__ __attribute__((aligned(16))) float part[2][H];
+    __shared__ __attribute__((aligned(16))) float hs[4 * GRU_QPAD];    // state, quarter-padded
+    __shared__ __attribute__((aligned(16))) float rhs[4 * GRU_QPAD];   // r*h (GRUCell) for phase 2
+    __shared__ float us[H];
+    __shared__ float rs[H];
 
     const size_t wstride = (size_t)H * 2 * H + (size_t)H * H + (CUDNN ? H : 0);
     const float* wg_g = wrec + d * wstride;          // [H][2H]
     const float* wc_g = wg_g + (size_t)H * 2 * H;    // [H][H]
     const float* bch_g = wc_g + (size_t)H * H;       // [H] (cudnn)
 
-    float wg[H];
-    float wc[HALF];
+    float wg[32];   // Wgh[32 kq + i][gc]
+    float wc[16];   // Wch[16 ke + i][cc]
 #pragma unroll
-    for (int k = 0; k < H; ++k) wg[k] = wg_g[(size_t)k * NT + n];
+    for (int i = 0; i < 32; ++i) wg[i] = wg_g[(size_t)(32 * kq + i) * (2 * H) + gc];
 #pragma unroll
-    for (int k = 0; k < HALF; ++k) wc[k] = wc_g[(size_t)(half * HALF + k) * H + col];
+    for (int i = 0; i < 16; ++i) wc[i] = wc_g[(size_t)(16 * ke + i) * H + cc];
     float bch = 0.f;
-    if (CUDNN && n < H) bch = bch_g[n];
+    if (CUDNN) bch = bch_g[cc];
 
-    if (n < H) hs[n] = 0.f;
-    float hreg = 0.f;
+    if (tid < 4 * GRU_QPAD) { hs[tid] = 0.f; rhs[tid] = 0.f; }
     __syncthreads();
 
     const float* xb = xproj + (size_t)b * T * xld + (size_t)d * 3 * H;
@@ -57,76 +64,91 @@ __global__ __launch_bounds__(2 * H) void bigru_kernel(const float* __restrict__ 
 
     int t = d ? T - 1 : 0;
     const int dt = d ? -1 : 1;
-    float xg = xb[(size_t)t * xld + n];
-    float xc = (n < H) ? xb[(size_t)t * xld + 2 * H + n] : 0.f;
+    // lane kq == 0 of every gate column / lane ke == 0 of every candidate column owns the input term
+    float xg = (kq == 0) ? xb[(size_t)t * xld + gc] : 0.f;
+    float xc = (ke == 0) ? xb[(size_t)t * xld + 2 * H + cc] : 0.f;
+    float hreg = 0.f;   // h[cc] (valid in the ke == 0 lanes)
 
     for (int s = 0; s < T; ++s, t += dt) {
-        // prefetch the next step's input projections
         float xg_n = 0.f, xc_n = 0.f;
         if (s + 1 < T) {
             const size_t o = (size_t)(t + dt) * xld;
-            xg_n = xb[o + n];
-            if (n < H) xc_n = xb[o + 2 * H + n];
+            if (kq == 0) xg_n = xb[o + gc];
+            if (ke == 0) xc_n = xb[o + 2 * H + cc];
         }
 
-        // phase 1: gates
+        // ---- phase 1: gates.  4 lanes per column, 32 FMAs each, DPP-reduced.
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const float* hq = hs + kq * GRU_QPAD;
 #pragma unroll
-        for (int k = 0; k < H; k += 4) {
-            const float4 hv = *reinterpret_cast<const float4*>(&hs[k]);
-            a0 = fmaf(hv.x, wg[k + 0], a0);
-            a1 = fmaf(hv.y, wg[k + 1], a1);
-            a2 = fmaf(hv.z, wg[k + 2], a2);
-            a3 = fmaf(hv.w, wg[k + 3], a3);
+        for (int i = 0; i < 32; i += 4) {
+            const float4 hv = *reinterpret_cast<const float4*>(hq + i);
+            a0 = fmaf(hv.x, wg[i + 0], a0);
+            a1 = fmaf(hv.y, wg[i + 1], a1);
+            a2 = fmaf(hv.z, wg[i + 2], a2);
+            a3 = fmaf(hv.w, wg[i + 3], a3);
         }
-        const float gate = sigmoidf_(xg + ((a0 + a1) + (a2 + a3)));
-        float r = 0.f;
-        if (n < H) {
-            r = gate;
-            if (!CUDNN) rhs[n] = gate * hreg;
-        } else {
-            us[n - H] = gate;
-        }
+        float g = (a0 + a1) + (a2 + a3);
+        g += __shfl_xor(g, 1);
+        g += __shfl_xor(g, 2);
+        float pc = 0.f;
         if (CUDNN) {
+            // candidate's recurrent part does not depend on r here: compute it in the same phase
+            const float* he = hs + (ke >> 1) * GRU_QPAD + (ke & 1) * 16;
             float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
 #pragma unroll
-            for (int k = 0; k < HALF; k += 4) {
-                const float4 hv = *reinterpret_cast<const float4*>(&hs[half * HALF + k]);
-                p0 = fmaf(hv.x, wc[k + 0], p0);
-                p1 = fmaf(hv.y, wc[k + 1], p1);
-                p2 = fmaf(hv.z, wc[k + 2], p2);
-                p3 = fmaf(hv.w, wc[k + 3], p3);
+            for (int i = 0; i < 16; i += 4) {
+                const float4 hv = *reinterpret_cast<const float4*>(he + i);
+                p0 = fmaf(hv.x, wc[i + 0], p0);
+                p1 = fmaf(hv.y, wc[i + 1], p1);
+                p2 = fmaf(hv.z, wc[i + 2], p2);
+                p3 = fmaf(hv.w, wc[i + 3], p3);
             }
-            part[half][col] = (p0 + p1) + (p2 + p3);
+            pc = (p0 + p1) + (p2 + p3);
+            pc += __shfl_xor(pc, 1);
+            pc += __shfl_xor(pc, 2);
+            pc += __shfl_xor(pc, 4);
+        }
+        if (kq == 0) {
+            const float gate = sigmoidf_(xg + g);
+            if (gc < H) {
+                rs[gc] = gate;
+            } else {
+                us[gc - H] = gate;
+            }
         }
         __syncthreads();
 
         if (!CUDNN) {
-            // phase 2: candidate on r*h, K split in two halves across the 2H threads
+            // r*h in the quarter-padded layout (one thread per unit), then phase 2 on it
+            if (tid < H) rhs[(tid >> 5) * GRU_QPAD + (tid & 31)] = rs[tid] * hs[(tid >> 5) * GRU_QPAD + (tid & 31)];
+            __syncthreads();
+            const float* he = rhs + (ke >> 1) * GRU_QPAD + (ke & 1) * 16;
             float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
 #pragma unroll
-            for (int k = 0; k < HALF; k += 4) {
-                const float4 hv = *reinterpret_cast<const float4*>(&rhs[half * HALF + k]);
-                p0 = fmaf(hv.x, wc[k + 0], p0);
-                p1 = fmaf(hv.y, wc[k + 1], p1);
-                p2 = fmaf(hv.z, wc[k + 2], p2);
-                p3 = fmaf(hv.w, wc[k + 3], p3);
+            for (int i = 0; i < 16; i += 4) {
+                const float4 hv = *reinterpret_cast<const float4*>(he + i);
+                p0 = fmaf(hv.x, wc[i + 0], p0);
+                p1 = fmaf(hv.y, wc[i + 1], p1);
+                p2 = fmaf(hv.z, wc[i + 2], p2);
+                p3 = fmaf(hv.w, wc[i + 3], p3);
             }
-            part[half][col] = (p0 + p1) + (p2 + p3);
-            __syncthreads();
+            pc = (p0 + p1) + (p2 + p3);
+            pc += __shfl_xor(pc, 1);
+            pc += __shfl_xor(pc, 2);
+            pc += __shfl_xor(pc, 4);
         }
-
-        if (n < H) {
-            const float hc = part[0][n] + part[1][n];
-            const float c = CUDNN ? tanhf_(xc + r * (hc + bch)) : tanhf_(xc + hc);
-            const float u = us[n];
+        if (ke == 0) {
+            const float c = CUDNN ? tanhf_(xc + rs[cc] * (pc + bch)) : tanhf_(xc + pc);
+            const float u = us[cc];
             const float hn = u * hreg + (1.0f - u) * c;
             hreg = hn;
-            hs[n] = hn;
-            ob[(size_t)t * 2 * H + n] = hn;
+            ob[(size_t)t * 2 * H + cc] = hn;
         }
         xg = xg_n;
         xc = xc_n;
+        // every read of hs of this step happened before the barrier(s) above: publish the new state
+        if (ke == 0) hs[(cc >> 5) * GRU_QPAD + (cc & 31)] = hreg;
         __syncthreads();
     }
 }
@@ -140,9 +162,9 @@ hipError_t launch_bigru(hipStream_t s, const float* xproj, int xld, const float*
     if (H != 128) return hipErrorInvalidValue;
     dim3 grid(B, 2);
     if (cudnn)
-        hipLaunchKernelGGL((bigru_kernel<128, true>), grid, dim3(256), 0, s, xproj, xld, wrec, out, B, T);
+        hipLaunchKernelGGL((bigru_kernel<128, true>), grid, dim3(GRU_THREADS), 0, s, xproj, xld, wrec, out, B, T);
     else
-        hipLaunchKernelGGL((bigru_kernel<128, false>), grid, dim3(256), 0, s, xproj, xld, wrec, out, B, T);
+        hipLaunchKernelGGL((bigru_kernel<128, false>), grid, dim3(GRU_THREADS), 0, s, xproj, xld, wrec, out, B, T);
     return hipGetLastError();
 }
 
