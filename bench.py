@@ -160,7 +160,7 @@ def main():
 
     stage_ms = {}
     launches = {}
-    for st in ('encoder', 'decoder', 'postnet', 'denorm', 'gl_iter', 'gl_final'):
+    for st in ('encoder', 'decoder', 'postnet', 'gl_iter', 'gl_final'):
         ms, n = eng.profile_get(st)
         stage_ms[st] = ms / args.steps
         launches[st] = n // max(1, args.steps)

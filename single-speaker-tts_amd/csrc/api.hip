@@ -737,7 +737,7 @@ int gl_prepare(tts_handle_t h, int T, int win, int hop, int n_fft) {
 
 // mag_int: internal [B][T][FP]; init_ft: reference-layout U[0,1) numbers or null.
 int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t seed, int B, int T, int n_iter,
-           int win, int hop, int n_fft, float* wav, float* mse) {
+           int win, int hop, int n_fft, float* wav, float* mse, bool peak_normalize = false) {
     int rc = gl_prepare(h, T, win, hop, n_fft);
     if (rc) return rc;
     const int F = 1 + n_fft / 2, FP = TTS_GL_FP;
@@ -783,8 +783,10 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
         p.phase_out = nullptr;
         p.mse_partial = nullptr;
         p.wav = wav;
+        p.peak_partial = peak_normalize ? msep : nullptr;   // the mse partials are consumed by now
         HIPCHK(h, launch_gl_iter(h->stream, p, B, 1));
     }
+    if (peak_normalize) HIPCHK(h, launch_peak_scale(h->stream, wav, B, hop * (T - 1), msep, nchunks));
     return TTS_OK;
 }
 
@@ -1211,7 +1213,10 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
     return run_single(h, dense_group(yhist, U, h->dec.out_wt, h->dec.out_b, mel, OUT, B * n_steps, OUT, U, ACT_NONE));
 }
 
-int tts_postnet_forward(tts_handle_t h, const float* mel, int B, int T, float* linear) {
+// post-net CBHG + final Dense; with mag != null the Dense epilogue also emits the de-normalised,
+// power-raised magnitude in the internal frame-major layout [B*T][FP] (fused tts_denorm_power).
+static int postnet_impl(tts_handle_t h, const float* mel, int B, int T, float* linear, float* mag, float ref_db,
+                        float max_db, float power) {
     int rc = check_ready(h);
     if (rc) return rc;
     if (!mel || !linear || B < 1 || T < 1) return fail(h, TTS_ERR_INVALID, "postnet_forward: bad arguments");
@@ -1221,10 +1226,23 @@ int tts_postnet_forward(tts_handle_t h, const float* mel, int B, int T, float* l
     int64_t launches = 0;
     ProfScope ps(h, ST_POSTNET, 0);
     if ((rc = run_cbhg(h, h->post, "post", mel, B, T, gru, &launches))) return rc;
-    if ((rc = run_single(h, dense_group(gru, H2, h->dense_wt, h->dense_b, linear, F, M, F, H2, ACT_NONE)))) return rc;
+    GemmGroup g = dense_group(gru, H2, h->dense_wt, h->dense_b, linear, F, M, F, H2, ACT_NONE);
+    if (mag) {
+        g.C2 = mag;
+        g.ldc2 = TTS_GL_FP;
+        g.N2 = TTS_GL_FP;
+        g.d_ref = ref_db;
+        g.d_range = std::fabs(ref_db) + std::fabs(max_db);
+        g.d_pow = power;
+    }
+    if ((rc = run_single(h, g))) return rc;
     ++launches;
     if (ps.idx >= 0) h->spans[ps.idx].launches = launches;
     return TTS_OK;
+}
+
+int tts_postnet_forward(tts_handle_t h, const float* mel, int B, int T, float* linear) {
+    return postnet_impl(h, mel, B, T, linear, nullptr, 0.f, 0.f, 1.f);
 }
 
 static int denorm_check(tts_handle_t h, float ref_db, float max_db) {
@@ -1426,20 +1444,13 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         HIPCHK(h, hipEventRecord(h->ev_front_done, h->front));
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_front_done, 0));
     }
-    if ((rc = tts_postnet_forward(h, mel, B, T, linear))) return rc;
+    if ((rc = postnet_impl(h, mel, B, T, linear, magi, sp->ref_db, sp->max_db, sp->power))) return rc;
     if (h->pipeline) {
         HIPCHK(h, hipEventRecord(h->ev_post_done, h->stream));
         h->post_pending = true;
     }
-    {
-        ProfScope ps(h, ST_DENORM, 1);
-        HIPCHK(h, launch_denorm_power(h->stream, linear, magi, (size_t)B * T, F, FP, sp->ref_db, sp->max_db, sp->power));
-    }
-    if ((rc = gl_run(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav,
-                     nullptr)))
-        return rc;
-    if (sp->peak_normalize) HIPCHK(h, launch_peak_normalize(h->stream, wav, B, sp->hop_length * (T - 1)));
-    return TTS_OK;
+    return gl_run(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav, nullptr,
+                  sp->peak_normalize != 0);
 }
 
 int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* bytes) {

@@ -26,6 +26,9 @@ __device__ __forceinline__ float4 max4(float4 a, float4 b) {
     return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
 
+// DENORM: instantiation with the de-normalising second output (final Dense layer only; keeps the
+// powf out of the register allocation of every other GEMM)
+template <bool DENORM>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
     const GemmGroup& g = batch.g[blockIdx.z];
     const int M = g.M, N = g.N, K = g.K;
@@ -156,7 +159,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         const int n = n0 + wn * 64 + tn * 32 + li;
-        if (n >= N) continue;
+        if (n >= N) {
+            if (DENORM && g.C2 && n < g.N2) {   // zero the row padding of the second output
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (m < M) g.C2[(size_t)m * g.ldc2 + n] = 0.f;
+                    }
+            }
+            continue;
+        }
         const float bv = g.bias ? g.bias[n] : 0.f;
         const float sc = g.scale ? g.scale[n] : 1.f;
         const float sh = g.scale ? g.shift[n] : 0.f;
@@ -170,6 +184,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
                     v = v * sc + sh;
                     if (g.R) v += g.R[(size_t)m * g.ldr + n];
                     g.C[(size_t)m * g.ldc + g.coff + n] = v;
+                    if (DENORM && g.C2) g.C2[(size_t)m * g.ldc2 + n] = denorm_pow(v, g.d_ref, g.d_range, g.d_pow);
                 }
             }
     }
@@ -179,7 +194,10 @@ hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups) {
     int max_n = 0;
     for (int i = 0; i < n_groups; ++i) max_n = b.g[i].N > max_n ? b.g[i].N : max_n;
     dim3 grid((b.g[0].M + BM - 1) / BM, (max_n + BN - 1) / BN, n_groups);
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, s, b);
+    bool denorm = false;
+    for (int i = 0; i < n_groups; ++i) denorm = denorm || b.g[i].C2 != nullptr;
+    if (denorm) hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, s, b);
     return hipGetLastError();
 }
 

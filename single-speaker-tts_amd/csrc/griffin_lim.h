@@ -13,6 +13,7 @@ struct GlParams {
     float2* phase_out;       // [B][T][FP]       (iteration)
     float* wav;              // [B][hop*(T-1)]   (final iSTFT)
     float* mse_partial;      // [B][nchunks] or null
+    float* peak_partial;     // [B][nchunks] or null (final iSTFT: per-chunk max |wav|)
     const float* window;     // [win] periodic hann
     const float* wss;        // [n_fft + hop*(T-1)] window sum-square (librosa window_sumsquare)
     const float2* tw1024;    // exp(-2 pi i k / 1024), k < 1024
@@ -33,6 +34,7 @@ hipError_t launch_phase_init(hipStream_t s, const float* init_ft, uint64_t seed,
 hipError_t launch_denorm_power(hipStream_t s, const float* lin, float* mag, size_t rows, int F, int FP,
                                float ref_db, float max_db, float power);
 hipError_t launch_peak_normalize(hipStream_t s, float* wav, int B, int n);
+hipError_t launch_peak_scale(hipStream_t s, float* wav, int B, int n, const float* partial, int nparts);
 hipError_t launch_stft(hipStream_t s, const float* wav, int B, int n, int Tf, const float* window, int win, int hop,
                        const float2* tw1024, const float2* tw2048, float2* out, int FP);
 hipError_t launch_cplx_tf_to_ft(hipStream_t s, const float2* in, float* out, int B, int F, int T, int FP, int mode,

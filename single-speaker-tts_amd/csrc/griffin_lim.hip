@@ -333,7 +333,25 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         float* wb = p.wav + (size_t)b * L;
         const int y0 = t0 * hop;
         const int y1 = min((t0 + C) * hop, L);
-        for (int y = y0 + tid; y < y1; y += GL_THREADS) wb[y] = sig[y - ybase];
+        float pk = 0.f;
+        for (int y = y0 + tid; y < y1; y += GL_THREADS) {
+            const float v = sig[y - ybase];
+            wb[y] = v;
+            pk = fmaxf(pk, fabsf(v));
+        }
+        if (p.peak_partial) {   // per-chunk max |wav| for the fused peak normalisation
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) pk = fmaxf(pk, __shfl_xor(pk, o));
+            float* red = reinterpret_cast<float*>(ex_all);   // exchange buffers are idle now
+            __syncthreads();
+            if (lane == 0) red[wave] = pk;
+            __syncthreads();
+            if (tid == 0) {
+                float m = 0.f;
+                for (int w = 0; w < GL_NW; ++w) m = fmaxf(m, red[w]);
+                p.peak_partial[(size_t)b * gridDim.x + blockIdx.x] = m;
+            }
+        }
         return;
     }
 
@@ -730,12 +748,7 @@ __global__ void denorm_power_kernel(const float* lin, float* mag, size_t rows, i
     float* out = mag + row * FP;
     for (int f = threadIdx.x; f < FP; f += blockDim.x) {
         float v = 0.f;
-        if (f < F) {
-            const float x = fminf(fmaxf(in[f], 0.f), 1.f);
-            const float db = (x - 1.0f) * range_db + ref_db;
-            const float m = exp2f(db * (0.05f * 3.3219280948873623f));   // 10^(db/20)
-            v = powf(m, power);
-        }
+        if (f < F) v = denorm_pow(in[f], ref_db, range_db, power);
         out[f] = v;
     }
 }
@@ -761,6 +774,20 @@ __global__ __launch_bounds__(1024) void peak_normalize_kernel(float* wav, int n)
     if (m < 1.17549435e-38f) m = 1.0f;
     for (int i = threadIdx.x; i < n; i += blockDim.x) w[i] = w[i] / m;
 }
+// wav /= max(partials[b][:]) (unless below FLT_MIN): second half of the fused peak normalisation
+__global__ void peak_scale_kernel(float* wav, int n, const float* partial, int nparts) {
+    const int b = blockIdx.y;
+    float m = 0.f;
+    for (int i = 0; i < nparts; ++i) m = fmaxf(m, partial[(size_t)b * nparts + i]);
+    if (m < 1.17549435e-38f) m = 1.0f;
+    float* w = wav + (size_t)b * n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) w[i] = w[i] / m;
+}
+hipError_t launch_peak_scale(hipStream_t s, float* wav, int B, int n, const float* partial, int nparts) {
+    hipLaunchKernelGGL(peak_scale_kernel, dim3(64, B), dim3(256), 0, s, wav, n, partial, nparts);
+    return hipGetLastError();
+}
+
 hipError_t launch_peak_normalize(hipStream_t s, float* wav, int B, int n) {
     hipLaunchKernelGGL(peak_normalize_kernel, dim3(B), dim3(1024), 0, s, wav, n);
     return hipGetLastError();

@@ -23,6 +23,13 @@ __device__ __forceinline__ float tanhf_(float x) {
     float e = __expf(2.0f * x);
     return 1.0f - 2.0f / (e + 1.0f);
 }
+// reference tacotron/inference.py:96-101,175 + audio/conversion.py:102,51: clip -> dB -> magnitude -> ** power
+__device__ __forceinline__ float denorm_pow(float x, float ref_db, float range_db, float power) {
+    const float c = fminf(fmaxf(x, 0.f), 1.f);
+    const float db = (c - 1.0f) * range_db + ref_db;
+    // (10^(db/20)) ** power == 2^(db * power * log2(10) / 20): one exp2 instead of exp2 + powf
+    return exp2f(db * (power * (0.05f * 3.3219280948873623f)));
+}
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.0f);
     if (act == ACT_SIGMOID) return sigmoidf_(v);
@@ -48,6 +55,11 @@ struct GemmGroup {
     int lda, T, Cin, padl, pool;
     int ldc, coff, ldr;
     int act, epi;
+    // optional second output: C2[m][n] = (10^(((clip(v,0,1)-1)*d_range + d_ref)/20)) ** d_pow for n < N,
+    // 0 for N <= n < N2 (the de-normalised, power-raised magnitude of the final Dense layer)
+    float* C2;
+    int ldc2, N2;
+    float d_ref, d_range, d_pow;
 };
 #define TTS_GEMM_MAX_GROUPS 16
 struct GemmBatch {

@@ -114,5 +114,7 @@ def test_end_to_end_synthesize_matches_staged(engine, hparams):
     assert np.array_equal(out['mel'].to_host().reshape(3, 10, 400), mel.to_host())
     assert np.array_equal(out['linear'].to_host(), lin.to_host())
     assert np.array_equal(out['alignments'].to_host(), al.to_host())
-    assert np.array_equal(out['wav'].to_host(), wav.to_host())
+    # the fused path de-normalises in the Dense epilogue and peak-normalises in the last iSTFT: same
+    # arithmetic, different instruction selection -> equal to rounding, not bitwise
+    assert rel_l2(out['wav'].to_host(), wav.to_host()) < 1e-4
     assert np.abs(out['wav'].to_host()).max(axis=1).tolist() == [1.0, 1.0, 1.0]
