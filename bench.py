@@ -89,6 +89,8 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pipeline', type=int, default=None, help='override the library default (stream pipelining)')
+    ap.add_argument('--reserve-cus', type=int, default=None)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -121,6 +123,10 @@ def main():
         blob = shard.broadcast_blob(blob, src=0, device='cuda:{}'.format(local_rank))
     eng = sstts.Engine(hp, device_id=local_rank)
     eng.load_weights_blob(blob)
+    if args.pipeline is not None:
+        eng.set_option('pipeline', args.pipeline)
+    if args.reserve_cus is not None:
+        eng.set_option('reserve_cus', args.reserve_cus)
 
     # ---- this rank's shard of the synthetic batch, resident in HBM
     lo, hi = shard.shard_range(world * B_PER_GPU, world, rank)

@@ -64,8 +64,12 @@ struct tts_handle_s {
     int profile = 0;
     // tts_synthesize pipelining: encoder + decoder (latency bound, few CUs) of call k+1 run on
     // `front` while post-net + Griffin-Lim (throughput bound) of call k run on `stream`.
-    int pipeline = 0;      // opt-in: measured gain on MI355X is ~2 % (GL workgroups fill every CU)
-    int reserve_cus = 0;   // opt-in CU-mask reservation for the front stream
+    int pipeline = 1;      // on while the library owns its stream (see tts_synthesize); ~9 % on MI355X
+    int reserve_cus = 8;   // CUs held for the front stream by LDS-hogging sleeper workgroups (reserve.hip)
+    hipStream_t aux = nullptr;      // stream the sleepers run on
+    int* hold_flags = nullptr;      // two flag words, alternating per call
+    hipEvent_t ev_aux = nullptr;
+    unsigned call_count = 0;
     hipStream_t front = nullptr;
     hipEvent_t ev_front_done = nullptr, ev_post_done = nullptr;
     bool post_pending = false;
@@ -458,6 +462,7 @@ GruOffsets pack_dec_gru(tts_handle_t h, Packer& p, const std::string& scope, int
 int sync_all(tts_handle_t h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->front && h->front != h->stream) HIPCHK(h, hipStreamSynchronize(h->front));
+    if (h->aux) HIPCHK(h, hipStreamSynchronize(h->aux));
     return TTS_OK;
 }
 
@@ -754,6 +759,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     p.ncol = (win + hop - 1) / hop;
     p.C = 8 * p.ncol - 2 * (p.ncol - 1);
     if (p.C > 32) p.C = 32;
+    p.B = B;
     if (gl_lds_bytes(p) > 160 * 1024) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: chunk does not fit in LDS");
     const int nchunks = (T + p.C - 1) / p.C;
     WS(h, "gl.mse_partial", float, (size_t)B * nchunks, msep);
@@ -871,6 +877,12 @@ int tts_destroy(tts_handle_t h) {
         hipStreamSynchronize(h->front);
         hipStreamDestroy(h->front);
     }
+    if (h->aux) {
+        hipStreamSynchronize(h->aux);
+        hipStreamDestroy(h->aux);
+    }
+    if (h->hold_flags) hipFree(h->hold_flags);
+    if (h->ev_aux) hipEventDestroy(h->ev_aux);
     if (h->ev_front_done) hipEventDestroy(h->ev_front_done);
     if (h->ev_post_done) hipEventDestroy(h->ev_post_done);
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -907,7 +919,6 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     if (!std::strcmp(key, "use_graph")) h->use_graph = value;
     else if (!std::strcmp(key, "profile")) h->profile = value;
     else if (!std::strcmp(key, "reserve_cus")) {
-        if (h->front) return fail(h, TTS_ERR_INVALID, "reserve_cus must be set before the first tts_synthesize");
         h->reserve_cus = value;
     } else if (!std::strcmp(key, "pipeline")) {
         int rc = sync_all(h);
@@ -1388,64 +1399,48 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         linear = linb;
     }
     WS(h, "gl.mag", float, (size_t)B * T * FP, magi);
-    if (h->pipeline) {
+    const bool pipelined = h->pipeline && h->own_stream;   // inputs on a borrowed stream may still be in flight
+    if (pipelined) {
         if (!h->front) {
-            // The decoder's ~2200 small dependent launches must not queue behind the long, CU-filling
-            // Griffin-Lim workgroups of the previous call: reserve `reserve_cus` CUs for the front
-            // stream with CU masks (front = those CUs only, main = all the others).  Falls back to
-            // a plain high-priority stream when masking is unavailable or the main stream is borrowed.
-            bool masked = false;
-            if (h->reserve_cus > 0 && h->own_stream) {
-                hipDeviceProp_t prop;
-                HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
-                const int ncu = prop.multiProcessorCount;
-                const int words = (ncu + 31) / 32;
-                if (h->reserve_cus < ncu / 2) {
-                    std::vector<uint32_t> mf(words, 0u), mm(words, 0u);
-                    for (int i = 0; i < ncu; ++i) {
-                        if (i < h->reserve_cus) mf[i / 32] |= 1u << (i % 32);
-                        else mm[i / 32] |= 1u << (i % 32);
-                    }
-                    hipStream_t sf = nullptr, sm = nullptr;
-                    if (hipExtStreamCreateWithCUMask(&sf, words, mf.data()) == hipSuccess &&
-                        hipExtStreamCreateWithCUMask(&sm, words, mm.data()) == hipSuccess) {
-                        HIPCHK(h, hipStreamSynchronize(h->stream));
-                        hipStreamDestroy(h->stream);
-                        h->stream = sm;
-                        h->front = sf;
-                        masked = true;
-                    } else {
-                        if (sf) hipStreamDestroy(sf);
-                        if (sm) hipStreamDestroy(sm);
-                        (void)hipGetLastError();
-                    }
-                }
-            }
-            if (!masked) {
-                int prio_least = 0, prio_greatest = 0;
-                HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-                HIPCHK(h, hipStreamCreateWithPriority(&h->front, hipStreamNonBlocking, prio_greatest));
-            }
+            int prio_least = 0, prio_greatest = 0;
+            HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+            HIPCHK(h, hipStreamCreateWithPriority(&h->front, hipStreamNonBlocking, prio_greatest));
+            HIPCHK(h, hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, prio_greatest));
+            HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->hold_flags), 2 * sizeof(int)));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_front_done, hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_post_done, hipEventDisableTiming));
         }
     }
     hipStream_t main_stream = h->stream;
-    if (h->pipeline) {
+    int* hold_flag = nullptr;
+    if (pipelined) {
         // the previous call's post-net still reads the shared mel / scratch the decoder writes
         if (h->post_pending) HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_post_done, 0));
+        if (h->reserve_cus > 0) {
+            // reserve CUs for the front stream while the previous call's Griffin-Lim fills the rest
+            hold_flag = h->hold_flags + (h->call_count++ & 1);
+            HIPCHK(h, hipMemsetAsync(hold_flag, 0, sizeof(int), h->aux));
+            HIPCHK(h, hipEventRecord(h->ev_aux, h->aux));
+            HIPCHK(h, launch_cu_hold(h->aux, h->reserve_cus, hold_flag, 100.0));
+            HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_aux, 0));
+        }
         h->stream = h->front;
     }
     rc = tts_encoder_forward(h, ids, B, Ts, memory);
     if (!rc) rc = tts_decoder_forward(h, memory, B, Ts, sp->n_steps, mel, align_out);
     h->stream = main_stream;
-    if (rc) return rc;
-    if (h->pipeline) {
+    if (rc) {
+        if (hold_flag) hipMemsetAsync(hold_flag, 1, sizeof(int), h->front);
+        return rc;
+    }
+    if (pipelined) {
+        if (hold_flag) HIPCHK(h, hipMemsetAsync(hold_flag, 1, sizeof(int), h->front));   // release the held CUs
         HIPCHK(h, hipEventRecord(h->ev_front_done, h->front));
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_front_done, 0));
     }
     if ((rc = postnet_impl(h, mel, B, T, linear, magi, sp->ref_db, sp->max_db, sp->power))) return rc;
-    if (h->pipeline) {
+    if (pipelined) {
         HIPCHK(h, hipEventRecord(h->ev_post_done, h->stream));
         h->post_pending = true;
     }

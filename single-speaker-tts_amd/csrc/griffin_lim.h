@@ -19,6 +19,7 @@ struct GlParams {
     const float2* tw1024;    // exp(-2 pi i k / 1024), k < 1024
     const float2* tw2048;    // exp(-2 pi i k / 2048), k < 1024
     int T, FP, win, hop;
+    int B;                   // utterances
     int C;                   // frames owned per workgroup
     int ncol;                // ceil(win / hop): overlap-add colouring rounds, halo = ncol - 1
 };

@@ -177,10 +177,14 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     cf* ex = ex_all + wave * EX_CPLX;
-    const int b = blockIdx.y;
     // frames owned per workgroup: 8*ncol - 2*halo (= 32 for the reference configuration)
     const int C = (WIN_CT && HOP_CT) ? (GL_NW * ncol - 2 * (ncol - 1) > 32 ? 32 : GL_NW * ncol - 2 * (ncol - 1)) : p.C;
-    const int t0 = blockIdx.x * C;
+    // 1-D grid, utterance index fastest; the (short) partial last chunks of all utterances get the
+    // highest block ids, so they are dispatched last and fill the tail of the launch
+    const int nchunks = (p.T + C - 1) / C;
+    const int b = blockIdx.x % p.B;
+    const int chunk = blockIdx.x / p.B;
+    const int t0 = chunk * C;
     const int halo = ncol - 1;
     const int nA = C + 2 * halo;
     const int span = (nA - 1) * hop + win;
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             if (tid == 0) {
                 float m = 0.f;
                 for (int w = 0; w < GL_NW; ++w) m = fmaxf(m, red[w]);
-                p.peak_partial[(size_t)b * gridDim.x + blockIdx.x] = m;
+                p.peak_partial[(size_t)b * nchunks + chunk] = m;
             }
         }
         return;
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         if (tid == 0) {
             float s = 0.f;
             for (int w = 0; w < GL_NW; ++w) s += red[w];
-            p.mse_partial[(size_t)b * gridDim.x + blockIdx.x] = s;
+            p.mse_partial[(size_t)b * nchunks + chunk] = s;
         }
     }
 }
@@ -474,7 +478,7 @@ hipError_t gl_configure() {
 
 hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int B, int final_istft) {
     const int nchunks = (p.T + p.C - 1) / p.C;
-    dim3 grid(nchunks, B);
+    dim3 grid(nchunks * B);
     const size_t lds = gl_lds_bytes(p);
     const bool ref_cfg = p.win == 1102 && p.hop == 275;   // the reference's 50 ms / 12.5 ms at 22.05 kHz
     const bool mse = p.mse_partial != nullptr;

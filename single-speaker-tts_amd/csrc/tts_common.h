@@ -76,6 +76,9 @@ hipError_t launch_bigru(hipStream_t s, const float* xproj, int xld, const float*
                         int B, int T, int H, int cudnn);
 size_t bigru_wrec_floats(int H, int cudnn);
 
+// ----------------------------------------------------------------------------- CU reservation (reserve.hip)
+hipError_t launch_cu_hold(hipStream_t s, int n_cus, const int* flag, double timeout_ms);
+
 // ----------------------------------------------------------------------------- helpers
 struct DevBuf {
     void* p = nullptr;

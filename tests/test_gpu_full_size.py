@@ -118,3 +118,28 @@ def test_end_to_end_synthesize_matches_staged(engine, hparams):
     # arithmetic, different instruction selection -> equal to rounding, not bitwise
     assert rel_l2(out['wav'].to_host(), wav.to_host()) < 1e-4
     assert np.abs(out['wav'].to_host()).max(axis=1).tolist() == [1.0, 1.0, 1.0]
+
+
+def test_pipelined_calls_equal_sequential(engine):
+    """Back-to-back tts_synthesize calls overlap (decoder of call k+1 under Griffin-Lim of call k,
+    shared scratch, CU reservation): results must be bit-identical to fully serialised calls."""
+    batches = [bench_ids(4, 30 + 5 * i, 40 + i) for i in range(3)]
+    inits = [np.random.default_rng(i).random((4, 1025, 40)).astype(np.float32) for i in range(3)]
+
+    def run(pipeline):
+        engine.set_option('pipeline', pipeline)
+        dev_ids = [engine.to_device(b) for b in batches]
+        dev_init = [engine.to_device(x) for x in inits]
+        outs = [engine.synthesize(dev_ids[i], 8, 6.02, 99.89, 1.3, 6, WIN, HOP, init_phase=dev_init[i],
+                                  want_mel=True, want_alignments=True, want_linear=True) for i in range(3)]
+        engine.synchronize()
+        return [{k: v.to_host() for k, v in o.items()} for o in outs]
+
+    try:
+        seq = run(0)
+        pip = run(1)
+    finally:
+        engine.set_option('pipeline', 1)
+    for a, b in zip(seq, pip):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
