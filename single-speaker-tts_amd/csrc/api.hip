@@ -763,7 +763,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     if (gl_lds_bytes(p) > 160 * 1024) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: chunk does not fit in LDS");
     const int nchunks = (T + p.C - 1) / p.C;
     WS(h, "gl.mse_partial", float, (size_t)B * nchunks, msep);
-    HIPCHK(h, launch_phase_init(h->stream, init_ft, seed, ph0, B, F, T, FP));
+    HIPCHK(h, launch_phase_init(h->stream, init_ft, seed, mag_int, ph0, B, F, T, FP));
     float2* cur = ph0;
     float2* nxt = ph1;
     {

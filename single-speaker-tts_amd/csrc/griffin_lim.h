@@ -9,7 +9,7 @@ namespace tts {
 
 struct GlParams {
     const float* mag;        // [B][T][FP]
-    const float2* phase_in;  // [B][T][FP] unit phasors
+    const float2* phase_in;  // [B][T][FP] current spectrum estimate X = |S| * unit phasor
     float2* phase_out;       // [B][T][FP]       (iteration)
     float* wav;              // [B][hop*(T-1)]   (final iSTFT)
     float* mse_partial;      // [B][nchunks] or null
@@ -30,8 +30,8 @@ hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int B, int final_ist
 hipError_t launch_gl_mse_reduce(hipStream_t s, const float* partial, int B, int nchunks, float denom, float* mse);
 hipError_t launch_mag_ft_to_tf(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP);
 hipError_t launch_tf_to_ft(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP);
-hipError_t launch_phase_init(hipStream_t s, const float* init_ft, uint64_t seed, void* out, int B, int F, int T,
-                             int FP);
+hipError_t launch_phase_init(hipStream_t s, const float* init_ft, uint64_t seed, const float* mag_tf, void* out, int B,
+                             int F, int T, int FP);
 hipError_t launch_denorm_power(hipStream_t s, const float* lin, float* mag, size_t rows, int F, int FP,
                                float ref_db, float max_db, float power);
 hipError_t launch_peak_normalize(hipStream_t s, float* wav, int B, int n);

@@ -150,10 +150,9 @@ __device__ __forceinline__ cf unit_phasor(cf z) {
     return cmk(ok ? x * r : 1.f, ok ? y * r : 0.f);
 }
 
-struct GlFrameRegs {   // one frame's |S| and phase row, as loaded (k = 4*lane + 256*jj + 0..3)
-    float4 m[4];
+struct GlFrameRegs {   // one frame's spectrum estimate X = |S| * unit phasor, as loaded (k = 4*lane + 256*jj + 0..3)
     float4 pa[4], pb[4];
-    float mn, pn;      // Nyquist bin (lane 0)
+    float xn;          // Re X[Nyquist]
 };
 
 // MODE 0: iteration (phase_in -> phase_out); MODE 1: final iSTFT (phase_in -> wav).
@@ -198,37 +197,27 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         const int tf = t0 - halo + fa;
         return fa < nA && tf >= 0 && tf < p.T;
     };
-    auto load_frame = [&](int fa, GlFrameRegs& g) {
-        if (!frame_valid(fa)) return;
-        const int tf = t0 - halo + fa;
-        const float* mrow = magb + (size_t)tf * p.FP;
-        const cf* prow = phb + (size_t)tf * p.FP;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int k = 4 * lane + 256 * jj;
-            g.m[jj] = *reinterpret_cast<const float4*>(mrow + k);
-            g.pa[jj] = *reinterpret_cast<const float4*>(prow + k);
-            g.pb[jj] = *reinterpret_cast<const float4*>(prow + k + 2);
-        }
-        g.mn = 0.f; g.pn = 0.f;
-        if (lane == 0) { g.mn = mrow[MH]; g.pn = prow[MH].x; }
-    };
-
-#ifndef GL_PREFETCH_REGS
-#define GL_PREFETCH_REGS 1
-#endif
-    // L2-warming touch of a frame's rows: one dword per 128-byte line (used instead of the register
-    // prefetch when GL_PREFETCH_REGS == 0)
-    auto touch_frame = [&](int fa, float& ta, float& tb) {
-        ta = 0.f; tb = 0.f;
-        if (!frame_valid(fa)) return;
-        const int tf = t0 - halo + fa;
-        ta = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(magb + (size_t)tf * p.FP) + lane * 64);
-        tb = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(phb + (size_t)tf * p.FP) + lane * 128);
-    };
-    GlFrameRegs nxt;
-    float ta = 0.f, tb = 0.f;
-    load_frame(0 + ncol * wave, nxt);   // round 0's frame, in flight during the prologue
+    // Prefetch registers for one frame's spectrum row (k = 4*lane + 256*jj + 0..3).  Plain locals and
+    // UNCONDITIONAL loads (the frame index is clamped instead of branching): a struct filled under a
+    // branch stays in scratch memory, and hipcc then waits for the loads right after issuing them.
+    float4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
+    float xn;
+#define GL_LOAD_FRAME(FA)                                                                  \
+    {                                                                                      \
+        int tf_ = t0 - halo + (FA);                                                        \
+        tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                  \
+        const cf* prow_ = phb + (size_t)tf_ * p.FP + 4 * lane;                             \
+        pa0 = *reinterpret_cast<const float4*>(prow_);                                     \
+        pb0 = *reinterpret_cast<const float4*>(prow_ + 2);                                 \
+        pa1 = *reinterpret_cast<const float4*>(prow_ + 256);                               \
+        pb1 = *reinterpret_cast<const float4*>(prow_ + 258);                               \
+        pa2 = *reinterpret_cast<const float4*>(prow_ + 512);                               \
+        pb2 = *reinterpret_cast<const float4*>(prow_ + 514);                               \
+        pa3 = *reinterpret_cast<const float4*>(prow_ + 768);                               \
+        pb3 = *reinterpret_cast<const float4*>(prow_ + 770);                               \
+        xn = phb[(size_t)tf_ * p.FP + MH].x; /* Nyquist bin: same address in every lane */ \
+    }
+    GL_LOAD_FRAME(0 + ncol * wave)   // round 0's frame, in flight during the prologue
 
     if (tid < GL_NW) ola_done[tid] = 0;
     for (int i = tid; i < win; i += GL_THREADS) wtab[i] = p.window[i];
@@ -260,21 +249,18 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         const bool ok = frame_valid(fa);
         cf v[16];
         if (ok) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int k = 4 * lane + 256 * jj;
-                const float4 m4 = nxt.m[jj], pa = nxt.pa[jj], pb = nxt.pb[jj];
-                float4 xa, xb;
-                xa.x = m4.x * pa.x; xa.y = m4.x * pa.y; xa.z = m4.y * pa.z; xa.w = m4.y * pa.w;
-                xb.x = m4.z * pb.x; xb.y = m4.z * pb.y; xb.z = m4.w * pb.z; xb.w = m4.w * pb.w;
-                *reinterpret_cast<float4*>(ex + k) = xa;
-                *reinterpret_cast<float4*>(ex + k + 2) = xb;
+            {
+                float4* exq = reinterpret_cast<float4*>(ex + 4 * lane);
+                exq[0] = pa0; exq[1] = pb0;
+                exq[128] = pa1; exq[129] = pb1;
+                exq[256] = pa2; exq[257] = pb2;
+                exq[384] = pa3; exq[385] = pb3;
             }
-            if (lane == 0) ex[MH] = cmk(nxt.mn * nxt.pn, 0.f);
+            if (lane == 0) ex[MH] = cmk(xn, 0.f);
         }
         // the raw rows are consumed: fetch the next round's frame into the same registers now, it
         // lands while this frame's FFT runs
-        if (r + 1 < ncol) load_frame(fa + 1, nxt);
+        if (r + 1 < ncol) GL_LOAD_FRAME(fa + 1)
         if (ok) {
             wave_lds_sync();
 #pragma unroll
@@ -371,6 +357,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         const int t = t0 + fb;
         if (fb >= C || t >= p.T) continue;   // wave-uniform
         cf v[16];
+        // target magnitudes of this frame (needed only after the FFT: the loads fly meanwhile)
+        const float* mrow = magb + (size_t)t * p.FP;
+        float mg[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) mg[c] = fabsf(mrow[lane + 64 * c]);
         const int ylo = t * hop + wpad - MH;          // y index of window sample 0
         const bool edge = ylo < 0 || ylo + win > L;   // wave-uniform: reflect padding needed
         if (!edge) {
@@ -410,7 +401,6 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
         wave_lds_sync();
         cf* orow = pob + (size_t)t * p.FP;
-        const float* mrow = magb + (size_t)t * p.FP;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int k = lane + 64 * c;
@@ -420,18 +410,19 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             const cf e = cadd(zk, zm);
             const cf o = cmul(twR[k], csub(zk, zm));
             const cf x = cadd(e, cmul_mi(o));
-            orow[k] = unit_phasor(x);
+            orow[k] = cscale(unit_phasor(x), mg[c]);   // next estimate: target magnitude, new phase
             if (MSE) {
-                const float d = fabsf(mrow[k]) - (float)MH * sqrtf(x.x * x.x + x.y * x.y);   // x = X / MH
+                const float d = mg[c] - (float)MH * sqrtf(x.x * x.x + x.y * x.y);   // x = X / MH
                 mse_acc += d * d;
             }
         }
         if (lane == 0) {
             const cf z0 = v[0];
             const float xn = z0.x - z0.y;   // Nyquist bin, real
-            orow[MH] = cmk(xn < 0.f ? -1.f : 1.f, 0.f);
+            const float mn = fabsf(mrow[MH]);
+            orow[MH] = cmk(xn < 0.f ? -mn : mn, 0.f);
             if (MSE) {
-                const float d = fabsf(mrow[MH]) - (2.0f * MH) * fabsf(xn);   // xn = X[MH] / (2 MH)
+                const float d = mn - (2.0f * MH) * fabsf(xn);   // xn = X[MH] / (2 MH)
                 mse_acc += d * d;
             }
         }
@@ -710,7 +701,7 @@ __device__ __forceinline__ float u01(uint64_t seed, uint64_t idx) {
 }
 
 // angles = exp(2 pi i u): u from init (B,F,T) reference layout or from the seed; out (B,T,FP)
-__global__ void phase_init_kernel(const float* init_ft, uint64_t seed, cf* out, int F, int T, int FP) {
+__global__ void phase_init_kernel(const float* init_ft, uint64_t seed, const float* mag_tf, cf* out, int F, int T, int FP) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const int f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
@@ -730,14 +721,16 @@ __global__ void phase_init_kernel(const float* init_ft, uint64_t seed, cf* out, 
         if (t < T && f < FP) {
             float sn, cs;
             sincospif(2.0f * tile[tx][i], &sn, &cs);
-            out[((size_t)b * T + t) * FP + f] = f < F ? cmk(cs, sn) : cmk(0.f, 0.f);
+            const size_t o = ((size_t)b * T + t) * FP + f;
+            const float m = f < F ? fabsf(mag_tf[o]) : 0.f;
+            out[o] = cmk(m * cs, m * sn);   // X0 = |S| exp(2 pi i u)
         }
     }
 }
-hipError_t launch_phase_init(hipStream_t s, const float* init_ft, uint64_t seed, void* out, int B, int F,
-                             int T, int FP) {
+hipError_t launch_phase_init(hipStream_t s, const float* init_ft, uint64_t seed, const float* mag_tf, void* out, int B,
+                             int F, int T, int FP) {
     dim3 grid((T + 31) / 32, (FP + 31) / 32, B);
-    hipLaunchKernelGGL(phase_init_kernel, grid, dim3(32, 8), 0, s, init_ft, seed, reinterpret_cast<cf*>(out),
+    hipLaunchKernelGGL(phase_init_kernel, grid, dim3(32, 8), 0, s, init_ft, seed, mag_tf, reinterpret_cast<cf*>(out),
                        F, T, FP);
     return hipGetLastError();
 }
