@@ -102,8 +102,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        # one process per GPU over RCCL ("nccl" IS RCCL on ROCm).  SSTTS_DIST_BACKEND=gloo lets the
+        # N > 1 path be rehearsed on a box with fewer GPUs than ranks (ranks then share devices).
+        backend = os.environ.get('SSTTS_DIST_BACKEND', 'nccl')
+        n_dev = max(1, torch.cuda.device_count())
+        if backend != 'nccl':
+            local_rank = local_rank % n_dev
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     sstts = importlib.import_module('single-speaker-tts_amd')
     P = importlib.import_module('single-speaker-tts_amd.tacotron.params')
@@ -120,7 +126,8 @@ def main():
     else:
         blob = np.empty(n_floats, np.float32)
     if world > 1:
-        blob = shard.broadcast_blob(blob, src=0, device='cuda:{}'.format(local_rank))
+        bdev = 'cuda:{}'.format(local_rank) if dist.get_backend() == 'nccl' else 'cpu'
+        blob = shard.broadcast_blob(blob, src=0, device=bdev)
     eng = sstts.Engine(hp, device_id=local_rank)
     eng.load_weights_blob(blob)
     if args.pipeline is not None:
@@ -160,7 +167,8 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda:{}'.format(local_rank))
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device='cuda:{}'.format(local_rank) if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -172,6 +180,15 @@ def main():
         launches[st] = n // max(1, args.steps)
     w = wav.to_host()
     assert np.isfinite(w).all()
+    # the dominant kernel alone (no overlapping stream), for reference next to the in-pipeline figure
+    eng.synchronize()
+    eng.profile_reset()
+    mag_alone = eng.empty((B, F, T))
+    eng.lib.tts_memset(eng.handle, mag_alone.ptr, 0, mag_alone.nbytes)
+    eng.griffin_lim(mag_alone, 8, WIN, HOP, N_FFT, init_phase=init, want_mse=False)
+    ms_alone, n_alone = eng.profile_get('gl_iter')
+    gl_alone_ms = ms_alone / max(1, n_alone)
+    mag_alone.free()
 
     if rank == 0:
         frames_total = world * B_PER_GPU * T
@@ -209,7 +226,8 @@ def main():
             'stage_ms': stage_ms,
             'roofline': {'kernel': 'gl_iter_kernel<0> (one Griffin-Lim iteration, iSTFT+STFT fused)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'launch_ms': gl_launch_ms, 'algorithmic_bytes_per_launch': alg_bytes},
+                         'traffic': traffic, 'launch_ms': gl_launch_ms, 'launch_ms_alone': gl_alone_ms,
+                         'algorithmic_bytes_per_launch': alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(weights, hp)

@@ -221,7 +221,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
 
     if (tid < GL_NW) ola_done[tid] = 0;
     for (int i = tid; i < win; i += GL_THREADS) wtab[i] = p.window[i];
+#ifndef GL_ABL_NOZERO
     for (int i = tid; i < span; i += GL_THREADS) sig[i] = 0.f;
+#endif
     for (int i = tid; i < 1024; i += GL_THREADS) twR[i] = p.tw2048[i];
     for (int i = tid; i < 15 * 64; i += GL_THREADS) twA[i] = p.tw1024[(i & 63) * ((i >> 6) + 1)];
     FftTw tw;
@@ -309,6 +311,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     // ---------------- window-sum-square normalisation (librosa istft: divide where wss > tiny)
     const int ybase = (t0 - halo) * hop + wpad - MH;   // trimmed-signal index of sig[0]
     const int wss_len = NFFT + hop * (p.T - 1);
+#ifndef GL_ABL_NONORM
     for (int i = tid; i < span; i += GL_THREADS) {
         const int mfull = ybase + i + MH;
         if (mfull >= 0 && mfull < wss_len) {
@@ -316,6 +319,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             if (ws > 1.17549435e-38f) sig[i] = sig[i] / ws;
         }
     }
+#endif
     __syncthreads();
 
     if (MODE == 1) {

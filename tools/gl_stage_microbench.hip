@@ -5,6 +5,12 @@
 #include <vector>
 using namespace tts;
 
+struct MbFrameRegs {   // the raw-row prefetch of the first kernel generation (|S| and phase rows)
+    float4 m[4];
+    float4 pa[4], pb[4];
+    float mn, pn;
+};
+
 // PHASE 0 = B (forward), 1 = A (inverse); STAGE selects how much of the frame pipeline runs
 template <int PHASE, int STAGE>
 __global__ __launch_bounds__(GL_THREADS) void stage_kernel(const cf* tw1024, const cf* tw2048, const float* window,
@@ -57,6 +63,58 @@ __global__ __launch_bounds__(GL_THREADS) void stage_kernel(const cf* tw1024, con
                 }
             }
             fft1024(v, ex, tw, lane);
+            if (STAGE == 7 || STAGE == 8 || STAGE == 9) {
+                // mirror Z[M-k] through ds_bpermute (no LDS writes): lane l reg c <- lane (64-l)&63 reg 15-c,
+                // lane 0 <- own reg (16-c)&15
+                cf* orow = out + (row0 + (it % 40)) * FP;
+                const int src = ((64 - lane) & 63) << 2;
+                cf xo[16];
+                if (STAGE == 9) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
+                    wave_lds_sync();
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int k = lane + 64 * c;
+                    const cf zk = v[c];
+                    if (STAGE == 9) {
+                        const cf zm = cconj(ex[(MH - k) & (MH - 1)]);
+                        const cf e = cadd(zk, zm);
+                        const cf o = cmul(twR[k], csub(zk, zm));
+                        xo[c] = unit_phasor(cadd(e, cmul_mi(o)));
+                        continue;
+                    }
+                    float mx = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, v[15 - c].x)));
+                    float my = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, v[15 - c].y)));
+                    if (lane == 0) { mx = v[(16 - c) & 15].x; my = v[(16 - c) & 15].y; }
+                    const cf zm = cmk(mx, -my);
+                    const cf e = cadd(zk, zm);
+                    const cf o = cmul(twR[k], csub(zk, zm));
+                    const cf x = cadd(e, cmul_mi(o));
+                    xo[c] = unit_phasor(x);
+                }
+                if (STAGE == 9) wave_lds_sync();
+                if (STAGE == 7) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) orow[lane + 64 * c] = xo[c];
+                } else {
+                    // 16-byte stores: lane pairs exchange so that even lanes own (k, k+1) of row c and odd
+                    // lanes (k-1, k) of row c+1
+                    const bool odd = lane & 1;
+#pragma unroll
+                    for (int c = 0; c < 16; c += 2) {
+                        const cf give = odd ? xo[c] : xo[c + 1];        // what the partner needs from me
+                        cf got;
+                        got.x = __shfl_xor(give.x, 1);
+                        got.y = __shfl_xor(give.y, 1);
+                        const cf mine = odd ? xo[c + 1] : xo[c];
+                        float4 st = odd ? make_float4(got.x, got.y, mine.x, mine.y) : make_float4(mine.x, mine.y, got.x, got.y);
+                        const int kk = (odd ? lane - 1 : lane) + 64 * (odd ? c + 1 : c);
+                        *reinterpret_cast<float4*>(orow + kk) = st;
+                    }
+                }
+            } else
             if (STAGE >= 2) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
@@ -80,7 +138,7 @@ __global__ __launch_bounds__(GL_THREADS) void stage_kernel(const cf* tw1024, con
             }
         }
     } else {
-        GlFrameRegs nxt;
+        MbFrameRegs nxt;
         float touch = 0.f;
         const size_t rbase = (STAGE == 4) ? 0 : row0;
         auto load_frame = [&](int f) {
@@ -204,6 +262,9 @@ int main() {
     run<0, 1>("B1: + windowed loads from LDS signal", d1, d2, dw, mag, ph, out, sink);
     run<0, 2>("B2: + mirror exchange + split pass", d1, d2, dw, mag, ph, out, sink);
     run<0, 3>("B3: + unit phasor + global stores", d1, d2, dw, mag, ph, out, sink);
+    run<0, 7>("B7: bpermute mirror + dwordx2 stores", d1, d2, dw, mag, ph, out, sink);
+    run<0, 8>("B8: bpermute mirror + dwordx4 stores", d1, d2, dw, mag, ph, out, sink);
+    run<0, 9>("B9: LDS mirror + dwordx4 stores", d1, d2, dw, mag, ph, out, sink);
     run<1, 0>("A0: FFT only", d1, d2, dw, mag, ph, out, sink);
     run<1, 1>("A1: + X exchange + merge pass", d1, d2, dw, mag, ph, out, sink);
     run<1, 2>("A2: + window scale + overlap-add RMW", d1, d2, dw, mag, ph, out, sink);
