@@ -111,6 +111,7 @@ struct tts_handle_s {
         float* wss = nullptr;
         float2* tw1024 = nullptr;
         float2* tw2048 = nullptr;
+        float2* tables = nullptr;
         bool configured = false;
     } gl;
 
@@ -659,6 +660,13 @@ int gl_tables(tts_handle_t h) {
     HIPCHK(h, hipMalloc(&g.tw2048, 1024 * sizeof(float2)));
     HIPCHK(h, hipMemcpy(g.tw1024, t1.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(g.tw2048, t2.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
+    {
+        std::vector<float2> tb(1024 + 15 * 64);
+        for (int k = 0; k < 1024; ++k) tb[k] = t2[k];
+        for (int i = 0; i < 15 * 64; ++i) tb[1024 + i] = t1[(i & 63) * ((i >> 6) + 1)];
+        HIPCHK(h, hipMalloc(&g.tables, tb.size() * sizeof(float2)));
+        HIPCHK(h, hipMemcpy(g.tables, tb.data(), tb.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
     g.configured = true;
     return TTS_OK;
 }
@@ -755,6 +763,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     p.wss = h->gl.wss;
     p.tw1024 = h->gl.tw1024;
     p.tw2048 = h->gl.tw2048;
+    p.tables = h->gl.tables;
     p.T = T; p.FP = FP; p.win = win; p.hop = hop;
     p.ncol = (win + hop - 1) / hop;
     p.C = 8 * p.ncol - 2 * (p.ncol - 1);
@@ -870,6 +879,7 @@ int tts_destroy(tts_handle_t h) {
     if (h->gl.wss) hipFree(h->gl.wss);
     if (h->gl.tw1024) hipFree(h->gl.tw1024);
     if (h->gl.tw2048) hipFree(h->gl.tw2048);
+    if (h->gl.tables) hipFree(h->gl.tables);
     if (h->an.window) hipFree(h->an.window);
     if (h->an.mel_wt) hipFree(h->an.mel_wt);
     if (h->an.flag) hipFree(h->an.flag);

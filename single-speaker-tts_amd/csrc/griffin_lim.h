@@ -18,6 +18,7 @@ struct GlParams {
     const float* wss;        // [n_fft + hop*(T-1)] window sum-square (librosa window_sumsquare)
     const float2* tw1024;    // exp(-2 pi i k / 1024), k < 1024
     const float2* tw2048;    // exp(-2 pi i k / 2048), k < 1024
+    const float2* tables;    // [tw2048 (1024) | W1024^{lane*k2} as [k2-1][lane] (15*64)]: the kernel's LDS image
     int T, FP, win, hop;
     int B;                   // utterances
     int C;                   // frames owned per workgroup

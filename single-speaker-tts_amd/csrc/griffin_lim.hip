@@ -176,6 +176,19 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     cf* ex = ex_all + wave * EX_CPLX;
+#ifdef GL_STAMPS
+    unsigned long long stamps[16];
+    int nst = 0;
+#define GL_STAMP() stamps[nst++] = __builtin_amdgcn_s_memrealtime()
+    GL_STAMP();
+#else
+#define GL_STAMP()
+#endif
+#ifdef GL_SETPRIO
+    // the second-dispatched half of the waves loses issue arbitration on its SIMD (MI355X_MICROARCH.md,
+    // 'Two waves per SIMD', item 4): a static priority raise evens the two halves out
+    if (__builtin_amdgcn_readfirstlane(wave) >= GL_NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     // frames owned per workgroup: 8*ncol - 2*halo (= 32 for the reference configuration)
     const int C = (WIN_CT && HOP_CT) ? (GL_NW * ncol - 2 * (ncol - 1) > 32 ? 32 : GL_NW * ncol - 2 * (ncol - 1)) : p.C;
     // 1-D grid, utterance index fastest; the (short) partial last chunks of all utterances get the
@@ -220,33 +233,44 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     GL_LOAD_FRAME(0 + ncol * wave)   // round 0's frame, in flight during the prologue
 
     if (tid < GL_NW) ola_done[tid] = 0;
-    for (int i = tid; i < win; i += GL_THREADS) wtab[i] = p.window[i];
 #ifndef GL_ABL_NOZERO
     for (int i = tid; i < span; i += GL_THREADS) sig[i] = 0.f;
 #endif
-    for (int i = tid; i < 1024; i += GL_THREADS) twR[i] = p.tw2048[i];
-    for (int i = tid; i < 15 * 64; i += GL_THREADS) twA[i] = p.tw1024[(i & 63) * ((i >> 6) + 1)];
+    // twiddle tables: one contiguous pre-formatted blob [twR (1024) | twA (15*64)] copied with
+    // 16-byte loads; every global load of the prologue is issued before the first use
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.tables);
+        float4* dst = reinterpret_cast<float4*>(twR);
+        for (int i = tid; i < (1024 + 15 * 64) / 2; i += GL_THREADS) dst[i] = src[i];
+    }
     FftTw tw;
 #pragma unroll
     for (int d = 1; d < 4; ++d) tw.b[d - 1] = p.tw1024[16 * (lane & 15) * d];
     tw.a = twA + lane;
-    __syncthreads();
-    // this lane's window samples (n = 2*(lane + 64 c) + {0,1}); wreg carries the iFFT scale 1/(2*MH)
-    // (the forward FFT of phase B uses the same scaled window: unit phasors do not depend on scale)
+    // this lane's window samples (n = 2*(lane + 64 c) + {0,1}) straight from global memory; wreg
+    // carries the iFFT scale 1/(2*MH) (the forward FFT of phase B uses the same scaled window:
+    // unit phasors do not depend on scale)
     float wreg[16][2];
 #pragma unroll
     for (int c = 0; c < 16; ++c)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int nw = 2 * (lane + 64 * c) + e - wpad;
-            wreg[c][e] = (nw >= 0 && nw < win) ? wtab[nw] * (0.5f / (float)MH) : 0.f;
+            const bool in = nw >= 0 && nw < win;
+            const float wv = p.window[in ? nw : 0];   // unconditional load, masked below
+            wreg[c][e] = in ? wv * (0.5f / (float)MH) : 0.f;
         }
+    __syncthreads();
+    GL_STAMP();   // 1: prologue done
 
     // ---------------- phase A: inverse FFT + windowed overlap-add into LDS
 #ifndef GL_NO_UNROLL_A
 #pragma unroll
 #endif
     for (int r = 0; r < ncol; ++r) {
+#ifndef GL_NO_ALTPRIO
+        if ((r + (wave >= GL_NW / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         const int fa = r + ncol * wave;
         const bool ok = frame_valid(fa);
         cf v[16];
@@ -305,22 +329,39 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         }
         asm volatile("" ::: "memory");
         if (lane == 0) *reinterpret_cast<volatile int*>(ola_done + wave) = r + 1;
+        GL_STAMP();   // 2..6: end of A round r
     }
     __syncthreads();
+    GL_STAMP();   // 7: all overlap-adds done
 
     // ---------------- window-sum-square normalisation (librosa istft: divide where wss > tiny)
+    // All of a thread's wss loads are issued back to back (one L2 round trip for the whole pass
+    // instead of one per element), then the LDS read-modify-writes run from registers.
     const int ybase = (t0 - halo) * hop + wpad - MH;   // trimmed-signal index of sig[0]
     const int wss_len = NFFT + hop * (p.T - 1);
 #ifndef GL_ABL_NONORM
-    for (int i = tid; i < span; i += GL_THREADS) {
-        const int mfull = ybase + i + MH;
-        if (mfull >= 0 && mfull < wss_len) {
-            const float ws = p.wss[mfull];
-            if (ws > 1.17549435e-38f) sig[i] = sig[i] / ws;
+    {
+        constexpr int NBATCH = 24;   // one batch covers the reference chunk (11,827 samples / 512 threads)
+        for (int i0 = tid; i0 < span; i0 += GL_THREADS * NBATCH) {
+            float ws[NBATCH];
+#pragma unroll
+            for (int j = 0; j < NBATCH; ++j) {
+                const int mfull = ybase + i0 + j * GL_THREADS + MH;
+                // unconditional load of a clamped index (a load under a divergent branch makes hipcc
+                // drain vmcnt at the join); out-of-range elements are masked below
+                ws[j] = p.wss[mfull < 0 ? 0 : (mfull >= wss_len ? wss_len - 1 : mfull)];
+            }
+#pragma unroll
+            for (int j = 0; j < NBATCH; ++j) {
+                const int i = i0 + j * GL_THREADS;
+                const int mfull = ybase + i + MH;
+                if (i < span && mfull >= 0 && mfull < wss_len && ws[j] > 1.17549435e-38f) sig[i] = sig[i] / ws[j];
+            }
         }
     }
 #endif
     __syncthreads();
+    GL_STAMP();   // 8: normalised
 
     if (MODE == 1) {
         // owned samples: y in [t0*hop, (t0+C)*hop) intersected with [0, L)
@@ -357,6 +398,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
 #pragma unroll
 #endif
     for (int r = 0; r < nB; ++r) {
+#ifndef GL_NO_ALTPRIO
+        if ((r + (wave >= GL_NW / 2 ? 0 : 1)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         const int fb = wave + GL_NW * r;
         const int t = t0 + fb;
         if (fb >= C || t >= p.T) continue;   // wave-uniform
@@ -431,7 +475,14 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             }
         }
         wave_lds_sync();
+        GL_STAMP();   // 9..12: end of B round
     }
+#ifdef GL_STAMPS
+    if (lane == 0 && p.mse_partial == nullptr && blockIdx.x % 97 == 0) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.wav) + ((size_t)(blockIdx.x / 97) * GL_NW + wave) * 16;
+        for (int i = 0; i < 16; ++i) dst[i] = i < nst ? stamps[i] : 0;
+    }
+#endif
     if (MSE) {
         __syncthreads();   // all waves done with their exchange buffers
 #pragma unroll
