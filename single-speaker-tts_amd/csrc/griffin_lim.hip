@@ -232,7 +232,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     }
     GL_LOAD_FRAME(0 + ncol * wave)   // round 0's frame, in flight during the prologue
 
-    if (tid < GL_NW) ola_done[tid] = 0;
+    if (tid < GL_NW + 1) ola_done[tid] = 0;   // wave progress flags + phase-B frame counter
 #ifndef GL_ABL_NOZERO
     for (int i = tid; i < span; i += GL_THREADS) sig[i] = 0.f;
 #endif
@@ -331,32 +331,39 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         if (lane == 0) *reinterpret_cast<volatile int*>(ola_done + wave) = r + 1;
         GL_STAMP();   // 2..6: end of A round r
     }
-    __syncthreads();
-    GL_STAMP();   // 7: all overlap-adds done
-
     // ---------------- window-sum-square normalisation (librosa istft: divide where wss > tiny)
-    // All of a thread's wss loads are issued back to back (one L2 round trip for the whole pass
-    // instead of one per element), then the LDS read-modify-writes run from registers.
+    // All of a thread's wss loads are issued back to back BEFORE the barrier that ends phase A, so
+    // their latency hides behind the wait for the slowest wave; the LDS read-modify-writes then run
+    // from registers.
     const int ybase = (t0 - halo) * hop + wpad - MH;   // trimmed-signal index of sig[0]
     const int wss_len = NFFT + hop * (p.T - 1);
+    constexpr int NBATCH = 24;   // one batch covers the reference chunk (11,827 samples / 512 threads)
+    float ws[NBATCH];
 #ifndef GL_ABL_NONORM
-    {
-        constexpr int NBATCH = 24;   // one batch covers the reference chunk (11,827 samples / 512 threads)
-        for (int i0 = tid; i0 < span; i0 += GL_THREADS * NBATCH) {
-            float ws[NBATCH];
+#pragma unroll
+    for (int j = 0; j < NBATCH; ++j) {
+        const int mfull = ybase + tid + j * GL_THREADS + MH;
+        // unconditional load of a clamped index (a load under a divergent branch makes hipcc
+        // drain vmcnt at the join); out-of-range elements are masked below
+        ws[j] = p.wss[mfull < 0 ? 0 : (mfull >= wss_len ? wss_len - 1 : mfull)];
+    }
+#endif
+    __syncthreads();
+    GL_STAMP();   // 7: all overlap-adds done
+#ifndef GL_ABL_NONORM
+    for (int i0 = tid; i0 < span; i0 += GL_THREADS * NBATCH) {
+        if (i0 != tid) {   // spans longer than one batch (non-reference window/hop)
 #pragma unroll
             for (int j = 0; j < NBATCH; ++j) {
                 const int mfull = ybase + i0 + j * GL_THREADS + MH;
-                // unconditional load of a clamped index (a load under a divergent branch makes hipcc
-                // drain vmcnt at the join); out-of-range elements are masked below
                 ws[j] = p.wss[mfull < 0 ? 0 : (mfull >= wss_len ? wss_len - 1 : mfull)];
             }
+        }
 #pragma unroll
-            for (int j = 0; j < NBATCH; ++j) {
-                const int i = i0 + j * GL_THREADS;
-                const int mfull = ybase + i + MH;
-                if (i < span && mfull >= 0 && mfull < wss_len && ws[j] > 1.17549435e-38f) sig[i] = sig[i] / ws[j];
-            }
+        for (int j = 0; j < NBATCH; ++j) {
+            const int i = i0 + j * GL_THREADS;
+            const int mfull = ybase + i + MH;
+            if (i < span && mfull >= 0 && mfull < wss_len && ws[j] > 1.17549435e-38f) sig[i] = sig[i] / ws[j];
         }
     }
 #endif
@@ -393,17 +400,20 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     // ---------------- phase B: forward FFT of the owned frames, new unit phasors
     cf* pob = p.phase_out + (size_t)b * p.T * p.FP;
     float mse_acc = 0.f;
-    const int nB = (C + GL_NW - 1) / GL_NW;
-#ifdef GL_UNROLL_B
-#pragma unroll
-#endif
-    for (int r = 0; r < nB; ++r) {
+    // frames are handed out dynamically (LDS counter): the wave that wins issue arbitration on its
+    // SIMD takes more of them, so both waves of a SIMD finish together
+    int* b_next = ola_done + GL_NW;
+    for (int r = 0;; ++r) {
 #ifndef GL_NO_ALTPRIO
         if ((r + (wave >= GL_NW / 2 ? 0 : 1)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
-        const int fb = wave + GL_NW * r;
+        int fb = wave + GL_NW * r;   // static map when the per-wave mse sums must have a fixed order
+        if (!MSE) {
+            if (lane == 0) fb = atomicAdd(b_next, 1);
+            fb = __builtin_amdgcn_readfirstlane(fb);
+        }
         const int t = t0 + fb;
-        if (fb >= C || t >= p.T) continue;   // wave-uniform
+        if (fb >= C || t >= p.T) break;   // wave-uniform
         cf v[16];
         // target magnitudes of this frame (needed only after the FFT: the loads fly meanwhile)
         const float* mrow = magb + (size_t)t * p.FP;
