@@ -323,8 +323,15 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             for (int c = 0; c < 16; ++c) {
                 const int n = 2 * (lane + 64 * c);
                 const int nw0 = n - wpad, nw1 = n + 1 - wpad;
+#ifdef GL_OLA_ATOMIC
+                // LDS float add without return (ds_add_f32): one DS op instead of read + add + write.
+                // Still deterministic: all adds to one address are ordered by the wave-progress flags.
+                if (nw0 >= 0 && nw0 < win) __hip_atomic_fetch_add(&sf[nw0], v[c].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (nw1 >= 0 && nw1 < win) __hip_atomic_fetch_add(&sf[nw1], v[c].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
                 if (nw0 >= 0 && nw0 < win) sf[nw0] += v[c].x;
                 if (nw1 >= 0 && nw1 < win) sf[nw1] += v[c].y;
+#endif
             }
         }
         asm volatile("" ::: "memory");

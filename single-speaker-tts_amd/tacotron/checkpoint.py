@@ -1,0 +1,229 @@
+"""TensorFlow checkpoint importer without TensorFlow (host logic).
+
+The reference restores its weights with ``tf.train.Saver().restore(session, checkpoint_file)``
+where ``checkpoint_file`` is either an explicit prefix or ``tf.train.latest_checkpoint(dir)``
+(tacotron/inference.py:44-55, 71).  TF 1.8 writes "V2" checkpoints = a *tensor bundle*:
+
+  ``<prefix>.index``                 an SSTable (LevelDB table format, uncompressed blocks) mapping
+                                     ``""`` -> BundleHeaderProto and every variable name ->
+                                     BundleEntryProto (dtype, shape, shard_id, offset, size, crc32c)
+  ``<prefix>.data-0000k-of-0000n``   the raw little-endian tensor bytes
+  ``checkpoint``                     a text CheckpointState: ``model_checkpoint_path: "<prefix>"``
+
+This module parses those three files with the standard library + numpy and maps the variables onto
+the manifest of :mod:`.weights`.  No checkpoint ships with the reference (README.md:357-361), so the
+parser is validated against a writer of the same published format in the tests, not against a file
+produced by TensorFlow.
+"""
+import os
+import re
+import struct
+
+import numpy as np
+
+from .params import ModelParams
+from .weights import manifest
+
+TABLE_MAGIC = 0xdb4775248b80fb57
+_DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64}   # tensorflow/core/framework/types.proto
+
+
+# ------------------------------------------------------------------------------------------ varints / protobuf
+def _varint(buf, pos):
+    result = shift = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        result |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return result, pos
+        shift += 7
+
+
+def _proto_fields(buf):
+    """Yield (field_number, wire_type, value) of one protobuf message (value: int or bytes)."""
+    pos = 0
+    while pos < len(buf):
+        key, pos = _varint(buf, pos)
+        field, wt = key >> 3, key & 7
+        if wt == 0:
+            val, pos = _varint(buf, pos)
+        elif wt == 1:
+            val = buf[pos:pos + 8]
+            pos += 8
+        elif wt == 2:
+            n, pos = _varint(buf, pos)
+            val = buf[pos:pos + n]
+            pos += n
+        elif wt == 5:
+            val = buf[pos:pos + 4]
+            pos += 4
+        else:
+            raise ValueError('unsupported protobuf wire type {}'.format(wt))
+        yield field, wt, val
+
+
+def _parse_shape(buf):
+    dims = []
+    for f, _wt, v in _proto_fields(buf):
+        if f == 2:                                   # TensorShapeProto.dim
+            size = 0
+            for f2, _w2, v2 in _proto_fields(v):
+                if f2 == 1:
+                    size = v2
+            dims.append(int(size))
+    return tuple(dims)
+
+
+def _parse_bundle_entry(buf):
+    e = dict(dtype=0, shape=(), shard_id=0, offset=0, size=0, crc32c=None, sliced=False)
+    for f, _wt, v in _proto_fields(buf):
+        if f == 1:
+            e['dtype'] = v
+        elif f == 2:
+            e['shape'] = _parse_shape(v)
+        elif f == 3:
+            e['shard_id'] = v
+        elif f == 4:
+            e['offset'] = v
+        elif f == 5:
+            e['size'] = v
+        elif f == 6:
+            e['crc32c'] = struct.unpack('<I', v)[0]
+        elif f == 7:
+            e['sliced'] = True
+    return e
+
+
+# ------------------------------------------------------------------------------------------ SSTable
+def _block_handle(buf, pos):
+    off, pos = _varint(buf, pos)
+    size, pos = _varint(buf, pos)
+    return off, size, pos
+
+
+def _read_block(data, off, size):
+    block = data[off:off + size]
+    ctype = data[off + size]
+    if ctype != 0:
+        raise NotImplementedError('compressed SSTable blocks are not supported (TF writes the bundle index uncompressed)')
+    n_restarts = struct.unpack('<I', block[-4:])[0]
+    limit = len(block) - 4 - 4 * n_restarts
+    entries = []
+    pos = 0
+    key = b''
+    while pos < limit:
+        shared, pos = _varint(block, pos)
+        non_shared, pos = _varint(block, pos)
+        vlen, pos = _varint(block, pos)
+        key = key[:shared] + block[pos:pos + non_shared]
+        pos += non_shared
+        entries.append((key, block[pos:pos + vlen]))
+        pos += vlen
+    return entries
+
+
+def read_table(path):
+    """All (key, value) pairs of a LevelDB-format table file, in key order."""
+    with open(path, 'rb') as f:
+        data = f.read()
+    if len(data) < 48 or struct.unpack('<Q', data[-8:])[0] != TABLE_MAGIC:
+        raise ValueError('{} is not an SSTable (bad magic)'.format(path))
+    footer = data[-48:]
+    _mo, _ms, pos = _block_handle(footer, 0)
+    io, isz, _ = _block_handle(footer, pos)
+    out = []
+    for _key, handle in _read_block(data, io, isz):
+        bo, bs, _ = _block_handle(handle, 0)
+        out.extend(_read_block(data, bo, bs))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ tensor bundle
+def read_tensor_bundle(prefix):
+    """{variable name: ndarray} of a TF V2 checkpoint ``prefix`` (no TensorFlow needed)."""
+    entries = read_table(prefix + '.index')
+    num_shards = 1
+    tensors = {}
+    metas = []
+    for key, val in entries:
+        if key == b'':
+            for f, _wt, v in _proto_fields(val):      # BundleHeaderProto
+                if f == 1:
+                    num_shards = v
+                elif f == 2 and v != 0:
+                    raise NotImplementedError('big-endian tensor bundles are not supported')
+            continue
+        metas.append((key.decode('utf-8'), _parse_bundle_entry(val)))
+    shards = {}
+    for name, e in metas:
+        if e['sliced']:
+            raise NotImplementedError('partitioned variable {} (tensor slices) is not supported'.format(name))
+        if e['dtype'] not in _DTYPES:
+            continue                                   # strings etc. are of no use here
+        sid = e['shard_id']
+        if sid not in shards:
+            shards[sid] = np.memmap('{}.data-{:05d}-of-{:05d}'.format(prefix, sid, num_shards), dtype=np.uint8, mode='r')
+        dt = np.dtype(_DTYPES[e['dtype']]).newbyteorder('<')
+        raw = shards[sid][e['offset']:e['offset'] + e['size']]
+        arr = np.frombuffer(raw.tobytes(), dtype=dt).reshape(e['shape'])
+        tensors[name] = arr
+    return tensors
+
+
+def latest_checkpoint(checkpoint_dir):
+    """tf.train.latest_checkpoint: the prefix named by ``model_checkpoint_path`` in ``<dir>/checkpoint``
+    (relative paths are resolved against the directory); None if there is no usable state."""
+    state = os.path.join(checkpoint_dir, 'checkpoint')
+    if not os.path.isfile(state):
+        return None
+    with open(state) as f:
+        m = re.search(r'^model_checkpoint_path:\s*"([^"]*)"', f.read(), flags=re.M)
+    if not m:
+        return None
+    path = m.group(1)
+    if not os.path.isabs(path):
+        path = os.path.join(checkpoint_dir, path)
+    return path if os.path.exists(path + '.index') else None
+
+
+_SLOT = re.compile(r'/(Adam(_\d+)?|Momentum|RMSProp(_\d+)?|ExponentialMovingAverage)$')
+
+
+def select_model_variables(tensors, hparams=None, aliases=None):
+    """Pick the manifest's variables out of a checkpoint's tensors.
+
+    Optimizer slots (``.../Adam``, ``.../Adam_1``), ``global_step`` and the ``beta?_power``
+    accumulators that training checkpoints carry are ignored.  ``aliases`` ({checkpoint name:
+    manifest name}) lets a caller adapt scope spellings; shapes are checked against the manifest."""
+    hp = hparams or ModelParams()
+    m = manifest(hp)
+    aliases = aliases or {}
+    out = {}
+    for name, arr in tensors.items():
+        if _SLOT.search(name) or name in ('global_step', 'beta1_power', 'beta2_power'):
+            continue
+        key = aliases.get(name, name)
+        if key in m:
+            if tuple(arr.shape) != tuple(m[key]):
+                raise ValueError('checkpoint variable {} has shape {}, the model needs {}'.format(name, arr.shape, m[key]))
+            out[key] = np.ascontiguousarray(arr, dtype=np.float32)
+    missing = [k for k in m if k not in out]
+    if missing:
+        hint = ''
+        if any('cudnn' in n.lower() for n in tensors):
+            hint = (' (the checkpoint holds CudnnGRU opaque parameters: re-save it with '
+                    'CudnnCompatibleGRUCell variables, force_cudnn=True)')
+        raise KeyError('checkpoint lacks {} model variables, e.g. {}{}'.format(len(missing), missing[:3], hint))
+    return out
+
+
+def load_checkpoint(path, hparams=None, aliases=None):
+    """``path``: a checkpoint prefix or a run directory (then its latest checkpoint, as the reference
+    resolves it at tacotron/inference.py:49-53).  Returns {manifest name: float32 array}."""
+    prefix = path
+    if os.path.isdir(path):
+        prefix = latest_checkpoint(path)
+        if prefix is None:
+            raise FileNotFoundError('no checkpoint state in {}'.format(path))
+    return select_model_variables(read_tensor_bundle(prefix), hparams, aliases)
