@@ -94,8 +94,12 @@ __device__ __forceinline__ void fft16(cf (&v)[16]) {
     for (int i = 0; i < 16; ++i) v[i] = o[i];
 }
 
+#ifndef E1S
 #define E1S 80   // row stride (complex) of the first exchange image: 2*E1S = 32 (mod 64) banks
+#endif
+#ifndef E2S
 #define E2S 17
+#endif
 #define EX_CPLX 1280
 
 struct FftTw {

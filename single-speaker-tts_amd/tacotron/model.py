@@ -81,11 +81,15 @@ class Tacotron(object):
 
     # ------------------------------------------------------------------ weights
     def restore(self, weights):
-        """weights: dict of arrays, a flat float32 blob in manifest order, or a path to an
-        ``.npz`` holding the manifest's variable names."""
+        """weights: dict of arrays, a flat float32 blob in manifest order, a path to an ``.npz`` holding
+        the manifest's variable names, or a TensorFlow checkpoint prefix / run directory."""
         if isinstance(weights, str):
-            with np.load(weights) as z:
-                weights = {k: z[k] for k in z.files}
+            if weights.endswith('.npz'):
+                with np.load(weights) as z:
+                    weights = {k: z[k] for k in z.files}
+            else:   # a TensorFlow checkpoint prefix or run directory (tacotron/inference.py:44-55,71)
+                from .checkpoint import load_checkpoint
+                weights = load_checkpoint(weights, self.hparams)
         if isinstance(weights, dict):
             self.engine.load_weights(weights)
         else:
