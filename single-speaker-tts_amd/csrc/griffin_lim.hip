@@ -9,25 +9,36 @@
 //   librosa.output.write_wav(norm=True)    reference audio/io.py:53 (peak normalisation)
 //   linear_scale_spectrogram / mel         reference audio/features.py:5-86, 116-145
 //
-// Internal layout: frame-major.  mag [B][T][FP] float, phase [B][T][FP] float2 (unit phasors),
-// FP = 1028 (F = 1025 padded so that every row is 16-byte aligned).  One frame's spectrum is a
-// contiguous row, which is also how the network produces it (B,T,F): the reference's (F,T)
-// transpose exists only at the C ABI.
+// Internal layout: frame-major.  mag [B][T][FP] float and a ping-pong pair of float2 spectrum
+// estimates X = |S| e^{i phi} [B][T][FP], FP = 1028 (F = 1025 padded so that every row is 16-byte
+// aligned).  One frame's spectrum is a contiguous row, which is also how the network produces it
+// (B,T,F): the reference's (F,T) transpose exists only at the C ABI.
 //
-// One Griffin-Lim iteration is ONE kernel: a 512-thread workgroup owns a chunk of C frames of one
-// utterance.  Phase A inverse-FFTs the chunk plus a halo of `ncol-1` frames either side
-// (ncol = ceil(win/hop) = 5) and overlap-adds them, window-weighted, into a time-domain buffer
-// that lives only in LDS; frames are processed in `ncol` rounds so that the 8 waves of a round
-// touch disjoint samples (no atomics, fixed summation order => bit-reproducible).  After the
-// window-sum-square normalisation, phase B forward-FFTs the C owned frames straight from LDS
-// (reflect padding at the utterance edges is an index map) and stores the new unit phasors.  The
-// time-domain signal never goes to HBM; per bin and iteration the algorithmic traffic is
-// 4 B |S| + 8 B phase in + 8 B phase out.
+// One Griffin-Lim iteration is ONE kernel: a 512-thread workgroup owns a chunk of C = 32 frames of
+// one utterance.
+//   Phase A inverse-FFTs the chunk plus a halo of `ncol-1` frames either side (ncol = ceil(win/hop)
+//   = 5) and overlap-adds them, window-weighted, into a time-domain buffer that lives only in LDS.
+//   Frame fa = r + ncol*wave is processed by `wave` in round r; frames of one round touch disjoint
+//   samples, and the only cross-wave hazard (wave w round r vs wave w+1 rounds < r) is ordered by
+//   per-wave progress flags in LDS, so there are no atomics, no workgroup barriers inside the
+//   phase, and the summation order of every sample is fixed (bit-reproducible).  The next round's
+//   spectrum row is prefetched into registers while the current frame's FFT runs.
+//   After the window-sum-square normalisation (loads hoisted above the barrier), phase B
+//   forward-FFTs the C owned frames straight from LDS (reflect padding at the utterance edges is an
+//   index map; frames handed out dynamically so both waves of a SIMD finish together) and stores
+//   the next estimate X = |S| * unit phasor.
+// The time-domain signal never goes to HBM; per bin and iteration the algorithmic traffic is
+// 8 B X in + 4 B |S| + 8 B X out.
 //
 // FFT: real 2048-point transforms as 1024-point complex FFTs with a split/merge pass.  One wave
 // per FFT, 16 points per lane: radix-16 in registers -> LDS transpose -> radix-4 -> LDS transpose
-// -> radix-16, twiddles held in registers for the whole kernel.  Index math validated against
-// numpy in tests/test_fft_emulation.py.
+// -> radix-16; twiddle tables in LDS, this lane's window samples (with the iFFT scale folded in)
+// in registers.  Index math validated against numpy in tests/test_host_logic.py
+// (test_fft_decomposition_emulation).
+//
+// Compile-time switches used by the tools/ micro-benchmarks only: GL_STAMPS (per-wave time stamps),
+// GL_ABL_NOZERO / GL_ABL_NONORM (timing ablations, wrong results), GL_OLA_ATOMIC (ds_add_f32
+// overlap-add: 1.8x slower), GL_NO_ALTPRIO, GL_NO_UNROLL_A, E1S / E2S (exchange strides).
 #include "tts_common.h"
 #include "griffin_lim.h"
 
