@@ -65,7 +65,16 @@ typedef struct tts_config {
     int32_t reduction;           /* 5   */
     int32_t n_fft;               /* 2048 */
     int32_t force_cudnn;         /* 0: tf GRUCell (TF-CPU parity target); 1: CudnnCompatibleGRUCell */
+    /* model_params.attention (tacotron/params/model.py:112-128).  The local mechanism is the reference's
+     * experimental LocalLuongAttention (tacotron/attention.py:109-342) in its default sub-mode:
+     * AttentionMode.MONOTONIC + AttentionScore.DOT; PREDICTIVE needs extra variables and its window
+     * padding is inconsistent in the reference, GENERAL/CONCAT raise NotImplementedError there. */
+    int32_t attention_mechanism; /* TTS_ATTENTION_LUONG (default) | TTS_ATTENTION_LOCAL_LUONG */
+    int32_t luong_local_window_d;/* 10: window = 2D+1 memory positions around the decoder step index */
+    int32_t luong_force_gaussian;/* 1: reported alignments are gaussian-weighted (attention.py:73-80) */
 } tts_config_t;
+
+enum tts_attention { TTS_ATTENTION_LUONG = 0, TTS_ATTENTION_LOCAL_LUONG = 1 };
 
 /* ---- lifecycle ------------------------------------------------------------------------ */
 const char* tts_version(void);

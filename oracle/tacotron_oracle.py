@@ -182,12 +182,47 @@ def softmax_lastaxis(s):
     return e / e.sum(-1, keepdims=True)
 
 
+def local_luong_monotonic(query, keys, values, time, d, force_gaussian):
+    """LocalLuongAttention (MONOTONIC + DOT, scale=False) for one decoder step.
+
+    reference tacotron/attention.py:
+      * 263-286  p = min(max(time, D), T_s - (D+1)); start = floor(p) - D; stop = floor(p) + D + 1,
+                 clipped to the memory (window_start / window_stop) with zero padding up to 2D+1;
+      * 308-328  the (zero-padded) key window is scored with the dot product and soft-maxed over the
+                 2D+1 window positions -- padded positions score 0 and DO take softmax mass;
+      * 52-71    context = window alignments @ (zero-padded) value window -- NOT gaussian weighted;
+      * 73-92    reported alignments: window alignments * exp(-(pos - p)**2 / 2 * (D/2)**2) (the
+                 expression as written there, i.e. multiplied by (D/2)^2) when force_gaussian, then
+                 zero-padded back to the memory length;
+      * 563      `time` is the AttentionWrapperState.time of the step (AdvancedAttentionWrapper).
+    Returns (context (B, units), padded alignments (B, T_s))."""
+    B, Ts, _ = keys.shape
+    dt = keys.dtype
+    p = min(max(int(time), d), Ts - (d + 1))
+    start, stop = p - d, p + d + 1
+    w_start, w_stop = max(0, start), min(Ts, stop)
+    pre, post = abs(w_start - start), abs(w_stop - stop)
+    kwin = np.pad(keys[:, w_start:w_stop], ((0, 0), (pre, post), (0, 0)))
+    vwin = np.pad(values[:, w_start:w_stop], ((0, 0), (pre, post), (0, 0)))
+    a = softmax_lastaxis(np.einsum('bd,bwd->bw', query, kwin))
+    ctx = np.einsum('bw,bwd->bd', a, vwin)
+    if force_gaussian:
+        dist = np.arange(w_start, w_stop, dtype=dt) - dt.type(p)
+        # shapes differ (and TF fails) when the window was padded; the reference never gets there with
+        # T_s >= 2D+1 in monotonic mode
+        a = a * np.exp(-(dist ** 2) / 2 * dt.type((d / 2) ** 2))
+    full = np.pad(a, ((0, 0), (abs(start), abs(stop - Ts))))
+    return ctx, full
+
+
 def decoder(memory, w, hp, n_steps=None, trace=None):
     """reference tacotron/model.py:175-334 in Mode.PREDICT (S7, S8).
 
     LuongAttention(scale=False, no memory_sequence_length): keys = memory W_mem (no bias),
     values = memory; AttentionWrapper(output_attention=True, attention_layer_size=256,
     cell_input_fn = concat([inputs, attention])); PrenetWrapper (wrappers.py:122-124);
+    (hp.attention.mechanism == 'LocalLuongAttention': AdvancedAttentionWrapper + the windowed
+    mechanism, model.py:210-245, see local_luong_monotonic);
     two ResidualWrapper(GRUCell); OutputProjectionWrapper(r*80); TacotronInferenceHelper
     (helpers.py:83-110,161-205): GO frame zeros, next input = last 80 of the 400 outputs,
     never finished -> maximum_iterations // reduction steps (model.py:309).
@@ -200,6 +235,10 @@ def decoder(memory, w, hp, n_steps=None, trace=None):
     S = n_steps if n_steps is not None else dec.maximum_iterations // hp.reduction
     A = dec.n_attention_units
     U = dec.n_decoder_gru_units
+    att_hp = getattr(hp, 'attention', None)
+    local = att_hp is not None and att_hp.mechanism == 'LocalLuongAttention'
+    if local and (att_hp.luong_local_mode != 'monotonic' or att_hp.luong_local_score != 'dot'):
+        raise NotImplementedError('LocalLuongAttention: monotonic + dot only')
     keys = memory @ w['decoder2/memory_layer/kernel']
     x = np.zeros((B, dec.target_size), dtype=dt)
     att = np.zeros((B, A), dtype=dt)
@@ -211,9 +250,14 @@ def decoder(memory, w, hp, n_steps=None, trace=None):
         cell_in = np.concatenate([x, att], -1)
         p = pre_net(cell_in, w, _ATT + '/pre_net', dec.pre_net_layers)
         h_att = gru_cell(p, h_att, w, _ATT + '/gru_cell', cudnn)
-        score = np.einsum('bd,btd->bt', h_att, keys)
-        a = softmax_lastaxis(score)
-        ctx = np.einsum('bt,btd->bd', a, memory)
+        if local:
+            score = None
+            ctx, a = local_luong_monotonic(h_att, keys, memory, t, att_hp.luong_local_window_D,
+                                           att_hp.luong_force_gaussian)
+        else:
+            score = np.einsum('bd,btd->bt', h_att, keys)
+            a = softmax_lastaxis(score)
+            ctx = np.einsum('bt,btd->bd', a, memory)
         att = np.concatenate([h_att, ctx], -1) @ w[_ATT + '/attention_layer/kernel']
         y = att
         for i in range(dec.n_gru_layers):

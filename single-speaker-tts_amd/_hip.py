@@ -41,6 +41,7 @@ class TtsConfig(ctypes.Structure):
         ('dec_prenet_units', c_int32 * 2), ('n_attention_units', c_int32),
         ('n_decoder_gru_units', c_int32), ('n_decoder_gru_layers', c_int32), ('n_mels', c_int32),
         ('reduction', c_int32), ('n_fft', c_int32), ('force_cudnn', c_int32),
+        ('attention_mechanism', c_int32), ('luong_local_window_d', c_int32), ('luong_force_gaussian', c_int32),
     ]
 
 
@@ -187,6 +188,15 @@ class Engine(object):
             cfg.n_decoder_gru_layers = dec.n_gru_layers
             cfg.n_mels, cfg.reduction, cfg.n_fft = hparams.n_mels, hparams.reduction, hparams.n_fft
             cfg.force_cudnn = 1 if hparams.force_cudnn else 0
+            att = hparams.attention
+            if att.mechanism not in ('LuongAttention', 'LocalLuongAttention'):
+                raise NotImplementedError('attention mechanism {!r}'.format(att.mechanism))
+            if att.mechanism == 'LocalLuongAttention' and (att.luong_local_mode != 'monotonic' or
+                                                           att.luong_local_score != 'dot'):
+                raise NotImplementedError('LocalLuongAttention: only monotonic + dot is implemented')
+            cfg.attention_mechanism = 1 if att.mechanism == 'LocalLuongAttention' else 0
+            cfg.luong_local_window_d = att.luong_local_window_D
+            cfg.luong_force_gaussian = 1 if att.luong_force_gaussian else 0
         self.cfg = cfg
         h = c_void_p()
         rc = self.lib.tts_create(byref(cfg), device_id, byref(h))

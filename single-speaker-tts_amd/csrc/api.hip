@@ -826,6 +826,9 @@ int tts_default_config(tts_config_t* c) {
     c->dec_prenet_units[0] = 256; c->dec_prenet_units[1] = 128;
     c->n_attention_units = 256; c->n_decoder_gru_units = 256; c->n_decoder_gru_layers = 2;
     c->n_mels = 80; c->reduction = 5; c->n_fft = 2048; c->force_cudnn = 0;
+    c->attention_mechanism = TTS_ATTENTION_LUONG;
+    c->luong_local_window_d = 10;
+    c->luong_force_gaussian = 1;
     return TTS_OK;
 }
 
@@ -847,6 +850,10 @@ int tts_create(const tts_config_t* cfg, int device_id, tts_handle_t* out) {
         return fail(nullptr, TTS_ERR_UNSUPPORTED, "layer widths must be multiples of 16 (filters: 32)");
     if (c.enc_proj_filters[1] != c.enc_prenet_units[1] || c.post_proj_filters[1] != c.n_mels)
         return fail(nullptr, TTS_ERR_INVALID, "last projection must match the CBHG input width (residual)");
+    if (c.attention_mechanism != TTS_ATTENTION_LUONG && c.attention_mechanism != TTS_ATTENTION_LOCAL_LUONG)
+        return fail(nullptr, TTS_ERR_UNSUPPORTED, "attention_mechanism must be TTS_ATTENTION_LUONG or TTS_ATTENTION_LOCAL_LUONG");
+    if (c.attention_mechanism == TTS_ATTENTION_LOCAL_LUONG && c.luong_local_window_d < 1)
+        return fail(nullptr, TTS_ERR_INVALID, "luong_local_window_d must be >= 1");
     if (c.enc_n_banks < 1 || c.post_n_banks < 1 || c.reduction < 1 || c.vocabulary_size < 1 || c.n_highway_layers < 0)
         return fail(nullptr, TTS_ERR_INVALID, "bad counts");
     if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, TTS_ERR_HIP, "hipSetDevice failed");
@@ -1094,6 +1101,8 @@ int tts_finalize_weights(tts_handle_t h) {
         d.gru[i] = {base + o_dg[i].gates_wt, base + o_dg[i].gates_b, base + o_dg[i].cand_wt, base + o_dg[i].cand_b};
     d.out_wt = base + o_ow; d.out_b = base + o_ob;
     d.n_layers = c.n_decoder_gru_layers; d.att_units = att; d.dec_units = U; d.mem_units = mem;
+    d.local_d = c.attention_mechanism == TTS_ATTENTION_LOCAL_LUONG ? c.luong_local_window_d : 0;
+    d.local_gaussian = c.luong_force_gaussian != 0;
     d.n_mels = c.n_mels; d.reduction = c.reduction;
     d.prenet1_units = c.dec_prenet_units[0]; d.prenet2_units = c.dec_prenet_units[1];
     h->dense_wt = base + o_dw;
@@ -1162,6 +1171,10 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
     if (rc) return rc;
     if (!memory || !mel || B < 1 || Ts < 1 || n_steps < 1) return fail(h, TTS_ERR_INVALID, "decoder_forward: bad arguments");
     const tts_config_t& c = h->cfg;
+    if (h->dec.local_d > 0 && Ts < 2 * h->dec.local_d + 1)
+        return fail(h, TTS_ERR_UNSUPPORTED,
+                    "LocalLuongAttention: the memory must hold at least 2*D+1 positions (the reference's window "
+                    "padding for shorter inputs is not implemented)");
     const int A = c.n_attention_units, U = c.n_decoder_gru_units, mem = 2 * c.n_gru_units;
     const int NL = c.n_decoder_gru_layers;
     WS(h, "dec.keys", float, (size_t)B * Ts * A, keys);

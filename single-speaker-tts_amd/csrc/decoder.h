@@ -46,6 +46,8 @@ struct DecoderWeights {
     Gru gru[4];
     const float* out_wt; const float* out_b;             // [r*n_mels][U]
     int n_layers, att_units, dec_units, mem_units, n_mels, reduction, prenet1_units, prenet2_units;
+    int local_d;         // > 0: LocalLuongAttention (monotonic, dot) with window 2*local_d + 1
+    int local_gaussian;  // luong_force_gaussian (affects the reported alignments only)
 };
 
 struct DecoderScratch {

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const float* __restr
                                                             float* __restrict__ e_out,         // [B][Ts] of this step
                                                             float* __restrict__ parts,         // [PARTS][B][D]
                                                             float* __restrict__ stats,         // [B][PARTS][2] of this step
-                                                            int B, int Ts, int Tp) {
+                                                            int B, int Ts, int Tp, int w_lo, int w_n) {
     constexpr int D = 256;
     __shared__ __attribute__((aligned(16))) float qs[D];
     extern __shared__ float sc[];   // Tp scores
@@ -202,8 +202,9 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const float* __restr
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int j_lo = part * Tp;
-    const int nj = min(Tp, Ts - j_lo);   // may be <= 0 for an empty slice
+    // the scored positions are [w_lo, w_lo + w_n): the whole memory, or the local window
+    const int j_lo = w_lo + part * Tp;
+    const int nj = min(Tp, w_lo + w_n - j_lo);   // may be <= 0 for an empty slice
     qs[tid] = query[(size_t)b * D + tid];
     __syncthreads();
 
@@ -272,10 +273,29 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const float* __restr
     parts[((size_t)part * B + b) * D + tid] = (c0 + c1) + (c2 + c3);
 }
 
-// alignment_history[t][b][j] = e * exp(m_part - m) / sum, for all steps at once (off the critical path)
+// Window of LocalLuongAttention in MONOTONIC mode at decoder step t (reference attention.py:263-286):
+// p = min(max(t, D), Ts - (D + 1)), window [p - D, p + D + 1).  Needs Ts >= 2D + 1 (checked by the caller).
+__host__ __device__ static inline int local_center(int t, int Ts, int D) {
+    int p = t > D ? t : D;
+    const int hi = Ts - (D + 1);
+    return p < hi ? p : hi;
+}
+
+// alignment_history[t][b][j] = e * exp(m_part - m) / sum, for all steps at once (off the critical path).
+// local_d > 0: positions outside the step's window are 0 (the reference pads the 2D+1 window back to
+// the memory length, attention.py:85-92) and, with `gaussian`, the window is weighted by
+// exp(-(j - p)^2 / 2 * (D/2)^2) -- the reference's expression as written (attention.py:73-80); the
+// context vector uses the UNweighted window softmax (attention.py:69-71).
 __global__ void dec_align_finalize_kernel(const float* __restrict__ e, const float* __restrict__ stats,
-                                          float* __restrict__ align, int Ts, int Tp) {
+                                          float* __restrict__ align, int B, int Ts, int Tp, int local_d,
+                                          int gaussian) {
     const size_t tb = blockIdx.x;   // t * B + b
+    int w_lo = 0, pc = 0;
+    if (local_d > 0) {
+        pc = local_center((int)(tb / B), Ts, local_d);
+        w_lo = pc - local_d;
+    }
+    const float gk = 0.5f * (0.5f * local_d) * (0.5f * local_d);
     const float* st = stats + tb * TTS_ATT_PARTS * 2;
     float m = -INFINITY;
 #pragma unroll
@@ -289,11 +309,20 @@ __global__ void dec_align_finalize_kernel(const float* __restrict__ e, const flo
     }
     const float inv = 1.0f / sum;
     for (int j = threadIdx.x; j < Ts; j += blockDim.x) {
-        const int part = j / Tp;
-        float wp = w[0];
+        float a = 0.f;
+        const int jw = j - w_lo;
+        if (local_d == 0 || (jw >= 0 && jw <= 2 * local_d)) {
+            const int part = jw / Tp;
+            float wp = w[0];
 #pragma unroll
-        for (int i = 1; i < TTS_ATT_PARTS; ++i) wp = part == i ? w[i] : wp;
-        align[tb * Ts + j] = e[tb * Ts + j] * wp * inv;
+            for (int i = 1; i < TTS_ATT_PARTS; ++i) wp = part == i ? w[i] : wp;
+            a = e[tb * Ts + j] * wp * inv;
+            if (local_d > 0 && gaussian) {
+                const float dist = (float)(j - pc);
+                a *= __expf(-(dist * dist) * gk);
+            }
+        }
+        align[tb * Ts + j] = a;
     }
 }
 
@@ -342,7 +371,10 @@ hipError_t decoder_enqueue(hipStream_t s, const DecoderWeights& w, const Decoder
                            float* align, int cudnn) {
     const int A = w.att_units, U = w.dec_units, NM = w.n_mels;
     const int P1 = w.prenet1_units, P2 = w.prenet2_units;
-    const int Tp = (Ts + TTS_ATT_PARTS - 1) / TTS_ATT_PARTS;
+    const int LD = w.local_d;                       // 0: global LuongAttention
+    const int Wn = LD > 0 ? 2 * LD + 1 : Ts;        // scored positions per step
+    if (LD > 0 && Ts < Wn) return hipErrorInvalidValue;
+    const int Tp = (Wn + TTS_ATT_PARTS - 1) / TTS_ATT_PARTS;
     const int yld = n_steps * U;
     hipError_t e;
     // zero states (attention, cell states): TF zero_state
@@ -365,9 +397,13 @@ hipError_t decoder_enqueue(hipStream_t s, const DecoderWeights& w, const Decoder
         if ((e = run_gru(s, w.att_gru, sc, sc.p2, P2, P2, sc.h_att, nullptr, 0, nullptr, 0, B, A, cudnn)) != hipSuccess)
             return e;
         // Luong attention with the new cell output as query
+        // (LocalLuongAttention: AdvancedAttentionWrapper hands the step index to the mechanism,
+        //  reference attention.py:563, which then scores only the window around it)
         float* stats_t = sc.att_stats + (size_t)t * B * TTS_ATT_PARTS * 2;
+        const int w_lo = LD > 0 ? local_center(t, Ts, LD) - LD : 0;
         hipLaunchKernelGGL(dec_attention_kernel, dim3(TTS_ATT_PARTS, B), dim3(256), (size_t)Tp * sizeof(float), s,
-                           sc.h_att, keys, memory, e_buf + (size_t)t * B * Ts, sc.ctx_parts, stats_t, B, Ts, Tp);
+                           sc.h_att, keys, memory, e_buf + (size_t)t * B * Ts, sc.ctx_parts, stats_t, B, Ts, Tp, w_lo,
+                           Wn);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         // attention_layer(concat([cell_output, context])), no bias; context merged from the parts
         DecGemm al = mk(sc.h_att, A, A, sc.ctx_parts, w.mem_units, w.attn_layer_wt, nullptr, B, A, A + w.mem_units);
@@ -389,8 +425,8 @@ hipError_t decoder_enqueue(hipStream_t s, const DecoderWeights& w, const Decoder
         }
     }
     if (align) {
-        hipLaunchKernelGGL(dec_align_finalize_kernel, dim3(n_steps * B), dim3(64), 0, s, e_buf, sc.att_stats, align, Ts,
-                           Tp);
+        hipLaunchKernelGGL(dec_align_finalize_kernel, dim3(n_steps * B), dim3(64), 0, s, e_buf, sc.att_stats, align, B,
+                           Ts, Tp, LD, w.local_gaussian);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return hipSuccess;

@@ -44,6 +44,18 @@ class DecoderParams:
 
 
 @dataclass
+class AttentionParams:
+    """model_params.attention (reference tacotron/params/model.py:112-128).  ``mechanism`` is the class
+    name as a string; the enum values of AttentionMode / AttentionScore (reference
+    tacotron/attention.py:14-29) are spelled as lower-case strings."""
+    mechanism: str = 'LuongAttention'          # | 'LocalLuongAttention'
+    luong_local_score: str = 'dot'             # 'general' / 'concat' raise NotImplementedError in the reference
+    luong_local_mode: str = 'monotonic'        # 'predictive' is not implemented here
+    luong_force_gaussian: bool = True
+    luong_local_window_D: int = 10
+
+
+@dataclass
 class PostParams:
     n_banks: int = 8
     n_filters: int = 128
@@ -71,6 +83,7 @@ class ModelParams:
     force_cudnn: bool = False
     encoder: EncoderParams = field(default_factory=EncoderParams)
     decoder: DecoderParams = field(default_factory=DecoderParams)
+    attention: AttentionParams = field(default_factory=AttentionParams)
     post: PostParams = field(default_factory=PostParams)
 
 

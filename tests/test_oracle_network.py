@@ -146,3 +146,43 @@ def test_reference_shipped_alignments_have_the_modelled_properties():
     assert np.allclose(a.sum(1), 1.0, atol=5e-6)
     assert (a > 0).all()
     assert np.allclose(a[0, :, 0], a[0, :, 0].mean(), rtol=0.2)   # first step is near-uniform
+
+
+@pytest.mark.parametrize('t,Ts,D', [(0, 40, 10), (17, 40, 10), (39, 40, 10), (5, 21, 10), (3, 9, 2)])
+def test_local_luong_window_equals_masked_softmax(t, Ts, D):
+    """Independent formulation of LocalLuongAttention (reference tacotron/attention.py:263-328,52-92):
+    a softmax over the in-memory window == a softmax over the whole memory with -inf outside it."""
+    rng = np.random.default_rng(t + Ts)
+    B, U = 3, 16
+    q = rng.standard_normal((B, U))
+    keys = rng.standard_normal((B, Ts, U))
+    values = rng.standard_normal((B, Ts, U))
+    for gaussian in (False, True):
+        ctx, al = O.local_luong_monotonic(q, keys, values, t, D, gaussian)
+        p = min(max(t, D), Ts - (D + 1))
+        score = torch.einsum('bd,btd->bt', torch.from_numpy(q), torch.from_numpy(keys))
+        mask = torch.full((Ts,), float('-inf'), dtype=torch.float64)
+        mask[p - D:p + D + 1] = 0.0
+        a = torch.softmax(score + mask, -1)
+        ctx_t = torch.einsum('bt,btd->bd', a, torch.from_numpy(values)).numpy()
+        assert rel_l2(ctx, ctx_t) < 1e-12
+        exp = a.numpy()
+        if gaussian:
+            exp = exp * np.exp(-((np.arange(Ts) - p) ** 2) / 2 * (D / 2) ** 2)
+        np.testing.assert_allclose(al, exp, atol=1e-14)
+        assert al.shape == (B, Ts)
+
+
+def test_local_luong_decoder_reduces_to_global_when_window_is_the_memory(weights64, hparams):
+    import copy
+    hp = copy.deepcopy(hparams)
+    hp.attention.mechanism = 'LocalLuongAttention'
+    hp.attention.luong_local_window_D = 4
+    hp.attention.luong_force_gaussian = False
+    mem = np.random.default_rng(0).standard_normal((2, 9, 256))
+    a, al_a = O.decoder(mem, weights64, hp, n_steps=5)
+    b, al_b = O.decoder(mem, weights64, hparams, n_steps=5)
+    assert rel_l2(a, b) < 1e-12 and np.abs(al_a - al_b).max() < 1e-14
+    hp.attention.luong_local_mode = 'predictive'
+    with pytest.raises(NotImplementedError):
+        O.decoder(mem, weights64, hp, n_steps=1)
