@@ -738,6 +738,8 @@ int gl_prepare(tts_handle_t h, int T, int win, int hop, int n_fft) {
             if (idx < n) wss[idx] = (float)((double)wss[idx] + wd[j] * wd[j]);
         }
     }
+    // the kernels multiply: 1 / wss where librosa's istft divides (wss > tiny(float32)), 1 elsewhere
+    for (size_t i = 0; i < n; ++i) wss[i] = wss[i] > 1.17549435e-38f ? (float)(1.0 / (double)wss[i]) : 1.0f;
     HIPCHK(h, hipMalloc(&g.window, win * sizeof(float)));
     HIPCHK(h, hipMalloc(&g.wss, n * sizeof(float)));
     HIPCHK(h, hipMemcpy(g.window, wf.data(), win * sizeof(float), hipMemcpyHostToDevice));
@@ -760,7 +762,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     std::memset(&p, 0, sizeof(p));
     p.mag = mag_int;
     p.window = h->gl.window;
-    p.wss = h->gl.wss;
+    p.rwss = h->gl.wss;
     p.tw1024 = h->gl.tw1024;
     p.tw2048 = h->gl.tw2048;
     p.tables = h->gl.tables;

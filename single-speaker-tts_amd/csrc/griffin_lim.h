@@ -15,7 +15,7 @@ struct GlParams {
     float* mse_partial;      // [B][nchunks] or null
     float* peak_partial;     // [B][nchunks] or null (final iSTFT: per-chunk max |wav|)
     const float* window;     // [win] periodic hann
-    const float* wss;        // [n_fft + hop*(T-1)] window sum-square (librosa window_sumsquare)
+    const float* rwss;       // [n_fft + hop*(T-1)] 1 / window sum-square (librosa window_sumsquare) where it is > tiny, else 1
     const float2* tw1024;    // exp(-2 pi i k / 1024), k < 1024
     const float2* tw2048;    // exp(-2 pi i k / 2048), k < 1024
     const float2* tables;    // [tw2048 (1024) | W1024^{lane*k2} as [k2-1][lane] (15*64)]: the kernel's LDS image

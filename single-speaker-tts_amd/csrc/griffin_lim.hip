@@ -111,27 +111,72 @@ __device__ __forceinline__ void fft16(cf (&v)[16]) {
 #ifndef E2S
 #define E2S 17
 #endif
+#ifndef EX_CPLX
 #define EX_CPLX 1280
+#endif
 
 struct FftTw {
     const cf* a;   // LDS table: a[(k2-1)*64] = W1024^{lane*k2}, k2 = 1..15 (already offset by lane)
     cf b[3];       // W64^{(lane&15)*d}, d = 1..3
+    __device__ __forceinline__ cf a_at(int k2) const { return a[(k2 - 1) * 64]; }
+};
+struct FftTwReg {  // the same twiddles held in registers for the whole kernel (no LDS reads inside the FFT)
+    cf a[15];
+    cf b[3];
+    __device__ __forceinline__ cf a_at(int k2) const { return a[k2 - 1]; }
 };
 
 // forward 1024-point complex FFT across one wave.  in: v[j] = z[lane + 64 j]; out: v[c] = Z[lane + 64 c].
-__device__ __forceinline__ void fft1024(cf (&v)[16], cf* ex, const FftTw& tw, int lane) {
+// Exchange a register-index bit with a lane-index bit, for the pair of complex registers (a, b):
+// v_permlane32_swap / v_permlane16_swap transpose the 2 x 2 block {a, b} x {lane bit 5 (or 4) = 0, 1}:
+// afterwards a holds [a.lo | b.lo] and b holds [a.hi | b.hi] (halves of 32 lanes, or rows of 16).
+__device__ __forceinline__ void swap_bit5(cf& a, cf& b) {
+    auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = cmk(__uint_as_float(rx[0]), __uint_as_float(ry[0]));
+    b = cmk(__uint_as_float(rx[1]), __uint_as_float(ry[1]));
+}
+__device__ __forceinline__ void swap_bit4(cf& a, cf& b) {
+    auto rx = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    auto ry = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = cmk(__uint_as_float(rx[0]), __uint_as_float(ry[0]));
+    b = cmk(__uint_as_float(rx[1]), __uint_as_float(ry[1]));
+}
+
+// forward 1024-point complex FFT across one wave.  in: v[j] = z[lane + 64 j]; out: v[c] = Z[lane + 64 c].
+// Index split n = lane + 64 j, k = k2 + 16 k1', ...: radix-16 over j in registers, twiddle, then the
+// element (row k2, column lane) has to reach lane (a = lane & 15, kq = k2 & 3) register (k2 >> 2, lane >> 4):
+// a 4 x 4 transpose between the two low register-index bits and the two high lane bits, done with
+// 32 permlane swaps (no LDS); radix-4; the second exchange (a 16 x 16 transpose inside each row of 16
+// lanes) goes through the wave's LDS buffer; radix-16.
+template <typename TW>
+__device__ __forceinline__ void fft1024(cf (&v)[16], cf* ex, const TW& tw, int lane) {
     fft16(v);
 #pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) v[k2] = cmul(v[k2], tw.a[(k2 - 1) * 64]);
+    for (int k2 = 1; k2 < 16; ++k2) v[k2] = cmul(v[k2], tw.a_at(k2));
+#ifdef GL_FFT_LDS_STAGE1
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) ex[k2 * E1S + lane] = v[k2];
     wave_lds_sync();
-    const int a = lane & 15, kq = lane >> 4;
+    {
+        const int a = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) v[4 * i + b] = ex[(kq + 4 * i) * E1S + a + 16 * b];
+            for (int b = 0; b < 4; ++b) v[4 * i + b] = ex[(kq + 4 * i) * E1S + a + 16 * b];
+    }
     wave_lds_sync();
+#else
+    // new v[4 i + b] at lane (a, kq) = old v[4 i + kq] at lane (a, b)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        swap_bit4(v[4 * i + 0], v[4 * i + 1]);
+        swap_bit4(v[4 * i + 2], v[4 * i + 3]);
+        swap_bit5(v[4 * i + 0], v[4 * i + 2]);
+        swap_bit5(v[4 * i + 1], v[4 * i + 3]);
+    }
+#endif
+    const int a = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         r4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
@@ -179,12 +224,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     const int win = WIN_CT ? WIN_CT : p.win;
     const int hop = HOP_CT ? HOP_CT : p.hop;
     const int ncol = (WIN_CT && HOP_CT) ? (WIN_CT + HOP_CT - 1) / (HOP_CT ? HOP_CT : 1) : p.ncol;
-    // carve: [exchange: GL_NW * EX_CPLX cf][twR: 1024 cf][twA: 15*64 cf][window][signal]
+    // carve: [exchange: GL_NW * EX_CPLX cf][flags: 16 int][signal]
     cf* ex_all = reinterpret_cast<cf*>(smem_raw);
-    cf* twR = ex_all + GL_NW * EX_CPLX;
-    cf* twA = twR + 1024;
-    float* wtab = reinterpret_cast<float*>(twA + 15 * 64);
-    int* ola_done = reinterpret_cast<int*>(wtab + ((win + 3) & ~3));   // overlap-add progress per wave (16 ints)
+    int* ola_done = reinterpret_cast<int*>(ex_all + GL_NW * EX_CPLX);   // overlap-add progress per wave (16 ints)
     float* sig = reinterpret_cast<float*>(ola_done + 16);
 
     const int tid = threadIdx.x;
@@ -194,10 +236,18 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
 #ifdef GL_STAMPS
     unsigned long long stamps[16];
     int nst = 0;
+#ifdef GL_STAMPS_FINE   // intra-round stamps of A round 2 and B round 1 instead of the per-round ones
+#define GL_STAMP()
+#define GL_FSTAMP(cond) if (cond) stamps[nst++] = __builtin_amdgcn_s_memrealtime()
+    stamps[nst++] = __builtin_amdgcn_s_memrealtime();
+#else
 #define GL_STAMP() stamps[nst++] = __builtin_amdgcn_s_memrealtime()
+#define GL_FSTAMP(cond)
     GL_STAMP();
+#endif
 #else
 #define GL_STAMP()
+#define GL_FSTAMP(cond)
 #endif
 #ifdef GL_SETPRIO
     // the second-dispatched half of the waves loses issue arbitration on its SIMD (MI355X_MICROARCH.md,
@@ -225,25 +275,21 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         const int tf = t0 - halo + fa;
         return fa < nA && tf >= 0 && tf < p.T;
     };
-    // Prefetch registers for one frame's spectrum row (k = 4*lane + 256*jj + 0..3).  Plain locals and
-    // UNCONDITIONAL loads (the frame index is clamped instead of branching): a struct filled under a
-    // branch stays in scratch memory, and hipcc then waits for the loads right after issuing them.
-    float4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
-    float xn;
+    // Prefetch registers for one frame's spectrum row, already in the layout the split pass wants:
+    // gk[j] = X[lane + 64 j] and gm[j] = X[MH - (lane + 64 j)] (the mirrored bins; lane 0 / j 0 is the
+    // Nyquist bin).  Both are coalesced 512-byte wave loads of the same 8 KB row, so the second set hits
+    // in cache, and the row never has to be staged through LDS.  UNCONDITIONAL loads (the frame index is
+    // clamped instead of branching): registers filled under a branch stay in scratch memory, and hipcc
+    // then waits for the loads right after issuing them.
+    cf gk[16], gm[16];
 #define GL_LOAD_FRAME(FA)                                                                  \
     {                                                                                      \
         int tf_ = t0 - halo + (FA);                                                        \
         tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                  \
-        const cf* prow_ = phb + (size_t)tf_ * p.FP + 4 * lane;                             \
-        pa0 = *reinterpret_cast<const float4*>(prow_);                                     \
-        pb0 = *reinterpret_cast<const float4*>(prow_ + 2);                                 \
-        pa1 = *reinterpret_cast<const float4*>(prow_ + 256);                               \
-        pb1 = *reinterpret_cast<const float4*>(prow_ + 258);                               \
-        pa2 = *reinterpret_cast<const float4*>(prow_ + 512);                               \
-        pb2 = *reinterpret_cast<const float4*>(prow_ + 514);                               \
-        pa3 = *reinterpret_cast<const float4*>(prow_ + 768);                               \
-        pb3 = *reinterpret_cast<const float4*>(prow_ + 770);                               \
-        xn = phb[(size_t)tf_ * p.FP + MH].x; /* Nyquist bin: same address in every lane */ \
+        const cf* prow_ = phb + (size_t)tf_ * p.FP + lane;                                 \
+        const cf* mrow_ = phb + (size_t)tf_ * p.FP + (MH - lane);                          \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gk[j_] = prow_[64 * j_];         \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gm[j_] = mrow_[-64 * j_];        \
     }
     GL_LOAD_FRAME(0 + ncol * wave)   // round 0's frame, in flight during the prologue
 
@@ -251,17 +297,17 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
 #ifndef GL_ABL_NOZERO
     for (int i = tid; i < span; i += GL_THREADS) sig[i] = 0.f;
 #endif
-    // twiddle tables: one contiguous pre-formatted blob [twR (1024) | twA (15*64)] copied with
-    // 16-byte loads; every global load of the prologue is issued before the first use
-    {
-        const float4* src = reinterpret_cast<const float4*>(p.tables);
-        float4* dst = reinterpret_cast<float4*>(twR);
-        for (int i = tid; i < (1024 + 15 * 64) / 2; i += GL_THREADS) dst[i] = src[i];
-    }
-    FftTw tw;
+    // All twiddles live in registers for the whole kernel (every lane uses the same 34 values for every
+    // frame): twr[j] = W2048^{lane + 64 j} for the real-FFT split / merge passes, tw.a[k2-1] =
+    // W1024^{lane k2} and tw.b for the FFT itself.  No table in LDS, no LDS read latency inside a round.
+    cf twr[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) twr[j] = p.tw2048[lane + 64 * j];
+    FftTwReg tw;
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) tw.a[k2 - 1] = p.tw1024[(lane * k2) & 1023];
 #pragma unroll
     for (int d = 1; d < 4; ++d) tw.b[d - 1] = p.tw1024[16 * (lane & 15) * d];
-    tw.a = twA + lane;
     // this lane's window samples (n = 2*(lane + 64 c) + {0,1}) straight from global memory; wreg
     // carries the iFFT scale 1/(2*MH) (the forward FFT of phase B uses the same scaled window:
     // unit phasors do not depend on scale)
@@ -289,35 +335,27 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         const int fa = r + ncol * wave;
         const bool ok = frame_valid(fa);
         cf v[16];
+        GL_FSTAMP(r == 2);   // F1: A round start
         if (ok) {
-            {
-                float4* exq = reinterpret_cast<float4*>(ex + 4 * lane);
-                exq[0] = pa0; exq[1] = pb0;
-                exq[128] = pa1; exq[129] = pb1;
-                exq[256] = pa2; exq[257] = pb2;
-                exq[384] = pa3; exq[385] = pb3;
-            }
-            if (lane == 0) ex[MH] = cmk(xn, 0.f);
-        }
-        // the raw rows are consumed: fetch the next round's frame into the same registers now, it
-        // lands while this frame's FFT runs
-        if (r + 1 < ncol) GL_LOAD_FRAME(fa + 1)
-        if (ok) {
-            wave_lds_sync();
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int k = lane + 64 * j;
-                cf xk = ex[k];
-                cf xm = cconj(ex[MH - k]);
-                if (k == 0) { xk.y = 0.f; xm.y = 0.f; }
+                cf xk = gk[j];
+                cf xm = cconj(gm[j]);
+                if (j == 0 && lane == 0) { xk.y = 0.f; xm.y = 0.f; }   // DC and Nyquist bins are real
                 // Zin = E + i O, E = (xk + xm)/2, O = conj(twr) (xk - xm)/2 ; feed conj(Zin).
                 // The two 1/2 factors are folded into the output scale (the FFT is linear).
                 const cf e = cadd(xk, xm);
-                const cf o = cmul(cconj(twR[k]), csub(xk, xm));
+                const cf o = cmul(cconj(twr[j]), csub(xk, xm));
                 const cf zin = cadd(e, cmul_pi(o));
                 v[j] = cconj(zin);
             }
-            wave_lds_sync();
+        }
+        // the row is consumed: fetch the next round's frame into the same registers now, it lands
+        // while this frame's FFT runs
+        if (r + 1 < ncol) GL_LOAD_FRAME(fa + 1)
+        GL_FSTAMP(r == 2);   // F2: split pass done, next loads issued
+        if (ok) {
             fft1024(v, ex, tw, lane);
             // z[m] = conj(v)/MH, m = lane + 64 c: x[2m] = Re, x[2m+1] = Im
 #pragma unroll
@@ -327,11 +365,13 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         // the frames of OTHER waves, only frames of wave+1 from EARLIER rounds (distance
         // ncol + r' - r < ncol iff r' < r).  So wave w may accumulate round r once wave w+1 has
         // finished rounds < r; every overlapping pair is ordered => fixed summation order.
+        GL_FSTAMP(r == 2);   // F3: FFT + window done
         if (r > 0 && wave + 1 < GL_NW) {
             volatile int* flag = ola_done + wave + 1;
             while (*flag < r) __builtin_amdgcn_s_sleep(1);
         }
         asm volatile("" ::: "memory");
+        GL_FSTAMP(r == 2);   // F4: neighbour flag seen
         if (ok) {
             float* sf = sig + fa * hop;
 #pragma unroll
@@ -351,10 +391,12 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         }
         asm volatile("" ::: "memory");
         if (lane == 0) *reinterpret_cast<volatile int*>(ola_done + wave) = r + 1;
+        GL_FSTAMP(r == 2);   // F5: overlap-add done
         GL_STAMP();   // 2..6: end of A round r
     }
     // ---------------- window-sum-square normalisation (librosa istft: divide where wss > tiny)
-    // All of a thread's wss loads are issued back to back BEFORE the barrier that ends phase A, so
+    // p.rwss holds 1 / wss where wss > tiny and 1 elsewhere, so the pass is one multiply per sample.
+    // All of a thread's table loads are issued back to back BEFORE the barrier that ends phase A, so
     // their latency hides behind the wait for the slowest wave; the LDS read-modify-writes then run
     // from registers.
     const int ybase = (t0 - halo) * hop + wpad - MH;   // trimmed-signal index of sig[0]
@@ -367,7 +409,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         const int mfull = ybase + tid + j * GL_THREADS + MH;
         // unconditional load of a clamped index (a load under a divergent branch makes hipcc
         // drain vmcnt at the join); out-of-range elements are masked below
-        ws[j] = p.wss[mfull < 0 ? 0 : (mfull >= wss_len ? wss_len - 1 : mfull)];
+        ws[j] = p.rwss[mfull < 0 ? 0 : (mfull >= wss_len ? wss_len - 1 : mfull)];
     }
 #endif
     __syncthreads();
@@ -378,14 +420,14 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
 #pragma unroll
             for (int j = 0; j < NBATCH; ++j) {
                 const int mfull = ybase + i0 + j * GL_THREADS + MH;
-                ws[j] = p.wss[mfull < 0 ? 0 : (mfull >= wss_len ? wss_len - 1 : mfull)];
+                ws[j] = p.rwss[mfull < 0 ? 0 : (mfull >= wss_len ? wss_len - 1 : mfull)];
             }
         }
 #pragma unroll
         for (int j = 0; j < NBATCH; ++j) {
             const int i = i0 + j * GL_THREADS;
             const int mfull = ybase + i + MH;
-            if (i < span && mfull >= 0 && mfull < wss_len && ws[j] > 1.17549435e-38f) sig[i] = sig[i] / ws[j];
+            if (i < span && mfull >= 0 && mfull < wss_len) sig[i] *= ws[j];
         }
     }
 #endif
@@ -436,12 +478,17 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         }
         const int t = t0 + fb;
         if (fb >= C || t >= p.T) break;   // wave-uniform
+        GL_FSTAMP(r == 1);   // F6: B round start
         cf v[16];
         // target magnitudes of this frame (needed only after the FFT: the loads fly meanwhile)
         const float* mrow = magb + (size_t)t * p.FP;
         float mg[16];
 #pragma unroll
+#ifdef GL_ABL_NOMAG
+        for (int c = 0; c < 16; ++c) mg[c] = 1.0f + c;
+#else
         for (int c = 0; c < 16; ++c) mg[c] = fabsf(mrow[lane + 64 * c]);
+#endif
         const int ylo = t * hop + wpad - MH;          // y index of window sample 0
         const bool edge = ylo < 0 || ylo + win > L;   // wave-uniform: reflect padding needed
         if (!edge) {
@@ -476,24 +523,61 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 v[j] = cmk(x0, x1);
             }
         }
+        GL_FSTAMP(r == 1);   // F7: windowed frame in registers
         fft1024(v, ex, tw, lane);
+        GL_FSTAMP(r == 1);   // F8: FFT done
 #pragma unroll
         for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
         wave_lds_sync();
         cf* orow = pob + (size_t)t * p.FP;
+        // next estimate: target magnitude, new phase.  Fast path: x * (rsqrt(|x|^2) * |S|), valid while
+        // |x|^2 stays well inside the float range; the min / max of |x|^2 over the lane's bins are tracked
+        // and the (practically never taken) exact path below redoes the frame otherwise.
+        float s_min = 3.0e38f, s_max = 0.f;
+        cf zmr[16];   // all mirrored bins first: one LDS latency for the pass instead of one per bin
+#pragma unroll
+#ifdef GL_ABL_NOMIRROR
+        for (int c = 0; c < 16; ++c) zmr[c] = v[15 - c];
+#else
+        for (int c = 0; c < 16; ++c) zmr[c] = ex[(MH - (lane + 64 * c)) & (MH - 1)];
+#endif
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int k = lane + 64 * c;
             const cf zk = v[c];
-            const cf zm = cconj(ex[(MH - k) & (MH - 1)]);
+            const cf zm = cconj(zmr[c]);
             // 2 X[k] = (zk + zm) - i twr (zk - zm); the phase does not care about the factor 2
             const cf e = cadd(zk, zm);
-            const cf o = cmul(twR[k], csub(zk, zm));
+            const cf o = cmul(twr[c], csub(zk, zm));
             const cf x = cadd(e, cmul_mi(o));
-            orow[k] = cscale(unit_phasor(x), mg[c]);   // next estimate: target magnitude, new phase
+            const float s = fmaf(x.x, x.x, x.y * x.y);
+#ifdef GL_ABL_NORSQ
+            const float g = s * mg[c];
+#else
+            const float g = __builtin_amdgcn_rsqf(s) * mg[c];   // raw v_rsq_f32: s is range-checked below
+#endif
+#ifdef GL_ABL_NOSTORE
+            if (g == 123.456f)
+#endif
+            orow[k] = cmk(x.x * g, x.y * g);
+            s_min = fminf(s_min, s);
+            s_max = fmaxf(s_max, s);
             if (MSE) {
-                const float d = mg[c] - (float)MH * sqrtf(x.x * x.x + x.y * x.y);   // x = X / MH
+                const float d = mg[c] - (float)MH * sqrtf(s);   // x = X / MH
                 mse_acc += d * d;
+            }
+        }
+        if (__builtin_expect(__any(!(s_min > 1.0e-30f && s_max < 1.0e30f)), 0)) {
+            // exact path: zero / tiny / huge bins (angle(0) = 0, range-safe normalisation)
+#pragma unroll 1
+            for (int c = 0; c < 16; ++c) {
+                const int k = lane + 64 * c;
+                const cf zk = ex[k];
+                const cf zm = cconj(ex[(MH - k) & (MH - 1)]);
+                const cf e = cadd(zk, zm);
+                const cf o = cmul(p.tw2048[k], csub(zk, zm));
+                const cf x = cadd(e, cmul_mi(o));
+                orow[k] = cscale(unit_phasor(x), fabsf(mrow[k]));
             }
         }
         if (lane == 0) {
@@ -507,6 +591,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             }
         }
         wave_lds_sync();
+        GL_FSTAMP(r == 1);   // F9: merge pass + stores issued
         GL_STAMP();   // 9..12: end of B round
     }
 #ifdef GL_STAMPS
@@ -534,8 +619,7 @@ size_t gl_lds_bytes(const GlParams& p) {
     const int halo = p.ncol - 1;
     const int nA = p.C + 2 * halo;
     const int span = (nA - 1) * p.hop + p.win;
-    return (size_t)(GL_NW * EX_CPLX + 1024 + 15 * 64) * sizeof(cf) + (size_t)((p.win + 3) & ~3) * sizeof(float) +
-           16 * sizeof(int) + (size_t)((span + 3) & ~3) * sizeof(float);
+    return (size_t)(GL_NW * EX_CPLX) * sizeof(cf) + 16 * sizeof(int) + (size_t)((span + 3) & ~3) * sizeof(float);
 }
 
 template <int MODE, int W, int H, bool MSE>

@@ -61,5 +61,7 @@ int main() {
     run<8>(tw, out, 256, iters, 60 * 1024);    // 1 WG/CU, 2 waves per SIMD
     run<8>(tw, out, 512, iters, 60 * 1024);    // 2 rounds of WGs
     run<4>(tw, out, 512, iters, 20 * 1024);    // 2 WGs/CU of 4 waves
+    run<4>(tw, out, 768, iters, 4 * 1024);     // 3 WGs/CU of 4 waves: 3 waves per SIMD
+    run<8>(tw, out, 512, iters, 0);            // 2 WGs/CU of 8 waves = 4 waves per SIMD (fits only with -DE1S=72 -DEX_CPLX=1152)
     return 0;
 }
