@@ -108,11 +108,13 @@ struct tts_handle_s {
     struct {
         int win = 0, hop = 0, T = 0;
         float* window = nullptr;
-        float* wss = nullptr;
+        float* wss = nullptr;      // reciprocal window sum-square
+        float* wlane = nullptr;    // per-lane window images of the Griffin-Lim kernel
         float2* tw1024 = nullptr;
         float2* tw2048 = nullptr;
         float2* tables = nullptr;
         bool configured = false;
+        int n_cus = 0;
     } gl;
 
     // analysis-side tables (STFT window, mel basis)
@@ -667,9 +669,16 @@ int gl_tables(tts_handle_t h) {
         HIPCHK(h, hipMalloc(&g.tables, tb.size() * sizeof(float2)));
         HIPCHK(h, hipMemcpy(g.tables, tb.data(), tb.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+        g.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     g.configured = true;
     return TTS_OK;
 }
+
+static inline int device_cus(tts_handle_t h) { return h->gl.n_cus; }
 
 int stft_prepare(tts_handle_t h, int n, int win, int hop, int n_fft) {
     if (n_fft != TTS_GL_NFFT) return fail(h, TTS_ERR_UNSUPPORTED, "stft: only n_fft == 2048 is implemented");
@@ -719,7 +728,8 @@ int gl_prepare(tts_handle_t h, int T, int win, int hop, int n_fft) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (g.window) hipFree(g.window);
     if (g.wss) hipFree(g.wss);
-    g.window = g.wss = nullptr;
+    if (g.wlane) hipFree(g.wlane);
+    g.window = g.wss = g.wlane = nullptr;
     // periodic hann (scipy get_window('hann', win, fftbins=True)), float64 then float32
     std::vector<double> wd(win);
     std::vector<float> wf(win);
@@ -744,6 +754,12 @@ int gl_prepare(tts_handle_t h, int T, int win, int hop, int n_fft) {
     HIPCHK(h, hipMalloc(&g.wss, n * sizeof(float)));
     HIPCHK(h, hipMemcpy(g.window, wf.data(), win * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(g.wss, wss.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    {
+        std::vector<float> wl(2 * 16 * 2 * 64);
+        gl_build_wlane(wf.data(), wss.data(), win, hop, T, wl.data());
+        HIPCHK(h, hipMalloc(&g.wlane, wl.size() * sizeof(float)));
+        HIPCHK(h, hipMemcpy(g.wlane, wl.data(), wl.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     g.win = win;
     g.hop = hop;
     g.T = T;
@@ -763,17 +779,21 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     p.mag = mag_int;
     p.window = h->gl.window;
     p.rwss = h->gl.wss;
+    p.wlane = h->gl.wlane;
     p.tw1024 = h->gl.tw1024;
     p.tw2048 = h->gl.tw2048;
     p.tables = h->gl.tables;
     p.T = T; p.FP = FP; p.win = win; p.hop = hop;
     p.ncol = (win + hop - 1) / hop;
-    p.C = 8 * p.ncol - 2 * (p.ncol - 1);
-    if (p.C > 32) p.C = 32;
     p.B = B;
-    if (gl_lds_bytes(p) > 160 * 1024) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: chunk does not fit in LDS");
-    const int nchunks = (T + p.C - 1) / p.C;
+    if (gl_max_item_frames(win, hop) < 1) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: window does not fit in LDS");
+    const int n_cus = device_cus(h);
+    gl_plan_items(p, n_cus);
+    const int nchunks = p.slots_per_utt;
     WS(h, "gl.mse_partial", float, (size_t)B * nchunks, msep);
+    // one zeroed work counter per launch (the persistent workgroups draw their item ids from it)
+    WS(h, "gl.counters", unsigned, (size_t)n_iter + 1, counters);
+    HIPCHK(h, hipMemsetAsync(counters, 0, ((size_t)n_iter + 1) * sizeof(unsigned), h->stream));
     HIPCHK(h, launch_phase_init(h->stream, init_ft, seed, mag_int, ph0, B, F, T, FP));
     float2* cur = ph0;
     float2* nxt = ph1;
@@ -783,7 +803,8 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
             p.phase_in = cur;
             p.phase_out = nxt;
             p.mse_partial = (mse && it == n_iter - 1) ? msep : nullptr;
-            HIPCHK(h, launch_gl_iter(h->stream, p, B, 0));
+            p.work_counter = counters + it;
+            HIPCHK(h, launch_gl_iter(h->stream, p, n_cus, 0));
             std::swap(cur, nxt);
         }
     }
@@ -801,7 +822,8 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
         p.mse_partial = nullptr;
         p.wav = wav;
         p.peak_partial = peak_normalize ? msep : nullptr;   // the mse partials are consumed by now
-        HIPCHK(h, launch_gl_iter(h->stream, p, B, 1));
+        p.work_counter = counters + n_iter;
+        HIPCHK(h, launch_gl_iter(h->stream, p, n_cus, 1));
     }
     if (peak_normalize) HIPCHK(h, launch_peak_scale(h->stream, wav, B, hop * (T - 1), msep, nchunks));
     return TTS_OK;
@@ -886,6 +908,7 @@ int tts_destroy(tts_handle_t h) {
     if (h->arena) hipFree(h->arena);
     if (h->gl.window) hipFree(h->gl.window);
     if (h->gl.wss) hipFree(h->gl.wss);
+    if (h->gl.wlane) hipFree(h->gl.wlane);
     if (h->gl.tw1024) hipFree(h->gl.tw1024);
     if (h->gl.tw2048) hipFree(h->gl.tw2048);
     if (h->gl.tables) hipFree(h->gl.tables);

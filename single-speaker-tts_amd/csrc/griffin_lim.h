@@ -6,28 +6,41 @@ namespace tts {
 
 #define TTS_GL_FP 1028      // padded row length of the frame-major spectra (F = 1025)
 #define TTS_GL_NFFT 2048
+#define GL_MAX_CLASSES 4
 
 struct GlParams {
     const float* mag;        // [B][T][FP]
     const float2* phase_in;  // [B][T][FP] current spectrum estimate X = |S| * unit phasor
     float2* phase_out;       // [B][T][FP]       (iteration)
     float* wav;              // [B][hop*(T-1)]   (final iSTFT)
-    float* mse_partial;      // [B][nchunks] or null
-    float* peak_partial;     // [B][nchunks] or null (final iSTFT: per-chunk max |wav|)
+    float* mse_partial;      // [B][slots_per_utt] or null
+    float* peak_partial;     // [B][slots_per_utt] or null (final iSTFT: per-item max |wav|)
     const float* window;     // [win] periodic hann
+    const float* wlane;      // [2][64 lanes][16][2] per-lane window images (gl_build_wlane): analysis / interior synthesis
     const float* rwss;       // [n_fft + hop*(T-1)] 1 / window sum-square (librosa window_sumsquare) where it is > tiny, else 1
     const float2* tw1024;    // exp(-2 pi i k / 1024), k < 1024
     const float2* tw2048;    // exp(-2 pi i k / 2048), k < 1024
-    const float2* tables;    // [tw2048 (1024) | W1024^{lane*k2} as [k2-1][lane] (15*64)]: the kernel's LDS image
+    const float2* tables;    // [tw2048 (1024) | W1024^{lane*k2} as [k2-1][lane] (15*64)]: per-lane twiddles, coalesced
     int T, FP, win, hop;
     int B;                   // utterances
-    int C;                   // frames owned per workgroup
+    int C;                   // largest item (frames owned per work item): sizes the LDS signal buffer
     int ncol;                // ceil(win / hop): overlap-add colouring rounds, halo = ncol - 1
+    // work items of a launch (gl_plan_items): class k cuts cls_n[k] items of cls_C[k] frames out of every
+    // utterance, starting at frame cls_t0[k]; item ids are class-major, utterance index fastest:
+    // id = cls_first[k] + j * B + b  <->  utterance b, frames [cls_t0[k] + j C, + C), slot cls_slot0[k] + j
+    int n_classes, n_items, slots_per_utt;
+    int cls_C[GL_MAX_CLASSES], cls_n[GL_MAX_CLASSES], cls_t0[GL_MAX_CLASSES], cls_slot0[GL_MAX_CLASSES],
+        cls_first[GL_MAX_CLASSES];
+    unsigned* work_counter;  // zeroed counter of THIS launch: the persistent workgroups draw item ids from it
 };
 
 size_t gl_lds_bytes(const GlParams& p);
+int gl_max_item_frames(int win, int hop);
+// out[2*16*2*64]: set 0 = window[n] / n_fft, set 1 = set 0 * rwss at an interior frame; n = 2*(lane + 64 c) + e
+void gl_build_wlane(const float* window, const float* rwss, int win, int hop, int T, float* out);
+void gl_plan_items(GlParams& p, int n_cus);   // needs T, B, win, hop, ncol; sets C and the item classes
 hipError_t gl_configure();
-hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int B, int final_istft);
+hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int n_cus, int final_istft);
 hipError_t launch_gl_mse_reduce(hipStream_t s, const float* partial, int B, int nchunks, float denom, float* mse);
 hipError_t launch_mag_ft_to_tf(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP);
 hipError_t launch_tf_to_ft(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP);

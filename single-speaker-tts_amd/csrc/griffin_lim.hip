@@ -112,7 +112,11 @@ __device__ __forceinline__ void fft16(cf (&v)[16]) {
 #define E2S 17
 #endif
 #ifndef EX_CPLX
-#define EX_CPLX 1280
+#ifdef GL_FFT_LDS_STAGE1
+#define EX_CPLX 1280   // 16 rows of E1S
+#else
+#define EX_CPLX 1088   // 64 rows of E2S (the only exchange image) >= the 1024 bins of the merge pass
+#endif
 #endif
 
 struct FftTw {
@@ -210,78 +214,110 @@ __device__ __forceinline__ cf unit_phasor(cf z) {
     return cmk(ok ? x * r : 1.f, ok ? y * r : 0.f);
 }
 
-struct GlFrameRegs {   // one frame's spectrum estimate X = |S| * unit phasor, as loaded (k = 4*lane + 256*jj + 0..3)
-    float4 pa[4], pb[4];
-    float xn;          // Re X[Nyquist]
-};
+// LDS control words behind the exchange buffers
+enum { CT_FLAGS = 0 /* GL_NW overlap-add progress flags */, CT_BNEXT = 8, CT_NEXT_ITEM = 9, CT_WORDS = 16 };
 
-// MODE 0: iteration (phase_in -> phase_out); MODE 1: final iSTFT (phase_in -> wav).
+// One Griffin-Lim iteration (MODE 0: phase_in -> phase_out) or the final iSTFT (MODE 1: phase_in -> wav).
 // WIN_CT / HOP_CT: compile-time window / hop (0 = take them from the parameters); the reference
 // configuration 1102 / 275 gets its own instantiation so that all window-support tests fold away.
+//
+// PERSISTENT workgroups: the grid is one workgroup per compute unit; each keeps its twiddles and windows in
+// registers and pulls work items (utterance, first frame, frame count) from a global counter until the
+// launch's item list is exhausted.  Items are numbered class-major, classes in descending frame count, so
+// the big items go first and the small ones balance the tail (GlParams::cls_*).
 template <int MODE, int WIN_CT, int HOP_CT, bool MSE>
 __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int win = WIN_CT ? WIN_CT : p.win;
     const int hop = HOP_CT ? HOP_CT : p.hop;
     const int ncol = (WIN_CT && HOP_CT) ? (WIN_CT + HOP_CT - 1) / (HOP_CT ? HOP_CT : 1) : p.ncol;
-    // carve: [exchange: GL_NW * EX_CPLX cf][flags: 16 int][signal]
+    // carve: [exchange: GL_NW * EX_CPLX cf][control: CT_WORDS int][signal]
     cf* ex_all = reinterpret_cast<cf*>(smem_raw);
-    int* ola_done = reinterpret_cast<int*>(ex_all + GL_NW * EX_CPLX);   // overlap-add progress per wave (16 ints)
-    float* sig = reinterpret_cast<float*>(ola_done + 16);
+    int* ctrl = reinterpret_cast<int*>(ex_all + GL_NW * EX_CPLX);
+    float* sig = reinterpret_cast<float*>(ctrl + CT_WORDS);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     cf* ex = ex_all + wave * EX_CPLX;
-#ifdef GL_STAMPS
-    unsigned long long stamps[16];
-    int nst = 0;
-#ifdef GL_STAMPS_FINE   // intra-round stamps of A round 2 and B round 1 instead of the per-round ones
-#define GL_STAMP()
-#define GL_FSTAMP(cond) if (cond) stamps[nst++] = __builtin_amdgcn_s_memrealtime()
-    stamps[nst++] = __builtin_amdgcn_s_memrealtime();
-#else
-#define GL_STAMP() stamps[nst++] = __builtin_amdgcn_s_memrealtime()
-#define GL_FSTAMP(cond)
-    GL_STAMP();
-#endif
-#else
-#define GL_STAMP()
-#define GL_FSTAMP(cond)
-#endif
-#ifdef GL_SETPRIO
-    // the second-dispatched half of the waves loses issue arbitration on its SIMD (MI355X_MICROARCH.md,
-    // 'Two waves per SIMD', item 4): a static priority raise evens the two halves out
-    if (__builtin_amdgcn_readfirstlane(wave) >= GL_NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
-    // frames owned per workgroup: 8*ncol - 2*halo (= 32 for the reference configuration)
-    const int C = (WIN_CT && HOP_CT) ? (GL_NW * ncol - 2 * (ncol - 1) > 32 ? 32 : GL_NW * ncol - 2 * (ncol - 1)) : p.C;
-    // 1-D grid, utterance index fastest; the (short) partial last chunks of all utterances get the
-    // highest block ids, so they are dispatched last and fill the tail of the launch
-    const int nchunks = (p.T + C - 1) / C;
-    const int b = blockIdx.x % p.B;
-    const int chunk = blockIdx.x / p.B;
-    const int t0 = chunk * C;
     const int halo = ncol - 1;
-    const int nA = C + 2 * halo;
-    const int span = (nA - 1) * hop + win;
     const int wpad = (NFFT - win) >> 1;
     const int L = hop * (p.T - 1);
 
-    const float* magb = p.mag + (size_t)b * p.T * p.FP;
-    const cf* phb = p.phase_in + (size_t)b * p.T * p.FP;
+    // ---------------- one-time setup
+    if (tid == 0) ctrl[CT_NEXT_ITEM] = (int)atomicAdd(p.work_counter, 1u);
+    if (tid < CT_NEXT_ITEM) ctrl[tid] = 0;
+    // All twiddles live in registers for the whole kernel (every lane uses the same 34 values for every
+    // frame): twr[j] = W2048^{lane + 64 j} for the real-FFT split / merge passes, tw.a[k2-1] =
+    // W1024^{lane k2} and tw.b for the FFT itself.  No table in LDS, no LDS read latency inside a round.
+    cf twr[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) twr[j] = p.tw2048[lane + 64 * j];
+    FftTwReg tw;
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) tw.a[k2 - 1] = p.tables[1024 + (k2 - 1) * 64 + lane];
+#pragma unroll
+    for (int d = 1; d < 4; ++d) tw.b[d - 1] = p.tw1024[16 * (lane & 15) * d];
+    // This lane's window samples (n = 2*(lane + 64 c) + {0,1}) come from p.wlane, a per-lane image
+    // [set][lane][c][e] built by the host (gl_build_wlane; 128 contiguous bytes per lane and set):
+    //   set 0, analysis window of phase B: w[n] / (2 MH)  (the iFFT scale folded in; unit phasors do not
+    //          depend on scale),
+    //   set 1, synthesis window of phase A for INTERIOR frames: set 0 / window-sum-square.  librosa's istft
+    //          divides the overlap-added signal by the window sum-square; for a frame whose `halo`
+    //          neighbours either side all exist that sum depends on the window position only, so the
+    //          division folds into the window and the signal in LDS is final as soon as the overlap-add is.
+    //          (Frames near the utterance ends take 1 / wss per sample from p.rwss.)
+    // Only one set is live at a time: it is (re)loaded at the start of each phase, which keeps the kernel
+    // inside the 256-register budget of two waves per SIMD.
+    float wreg[16][2];
+#define GL_LOAD_WINDOW(SET)                                                                       \
+    {                                                                                             \
+        const float4* wl_ = reinterpret_cast<const float4*>(p.wlane + ((SET) * 64 + lane) * 32);  \
+        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                        \
+            const float4 w4_ = wl_[q_];   /* slots 2 q_, 2 q_ + 1 */                              \
+            wreg[2 * q_][0] = w4_.x; wreg[2 * q_][1] = w4_.y;                                     \
+            wreg[2 * q_ + 1][0] = w4_.z; wreg[2 * q_ + 1][1] = w4_.w;                             \
+        }                                                                                         \
+        _Pragma("unroll") for (int c_ = 0; c_ < 16; ++c_) {                                       \
+            /* slot statically outside the window support (lane 0's sample nw_, lane 63's nw_ + 126) */ \
+            const int nw_ = 128 * c_ - wpad;                                                      \
+            if (WIN_CT && (nw_ + 127 < 0 || nw_ >= win)) { wreg[c_][0] = 0.f; wreg[c_][1] = 0.f; } \
+        }                                                                                         \
+    }
+    __syncthreads();
+    int item = __builtin_amdgcn_readfirstlane(ctrl[CT_NEXT_ITEM]);   // wave-uniform: keep it (and all it decodes to) in SGPRs
 
-    auto frame_valid = [&](int fa) {
-        const int tf = t0 - halo + fa;
-        return fa < nA && tf >= 0 && tf < p.T;
-    };
-    // Prefetch registers for one frame's spectrum row, already in the layout the split pass wants:
-    // gk[j] = X[lane + 64 j] and gm[j] = X[MH - (lane + 64 j)] (the mirrored bins; lane 0 / j 0 is the
-    // Nyquist bin).  Both are coalesced 512-byte wave loads of the same 8 KB row, so the second set hits
-    // in cache, and the row never has to be staged through LDS.  UNCONDITIONAL loads (the frame index is
-    // clamped instead of branching): registers filled under a branch stay in scratch memory, and hipcc
-    // then waits for the loads right after issuing them.
-    cf gk[16], gm[16];
+    while (item < p.n_items) {
+        // ---------------- decode the work item (wave-uniform scalar code)
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < GL_MAX_CLASSES; ++q)
+            if (q < p.n_classes && item >= p.cls_first[q]) k = q;
+        const int C = p.cls_C[k];
+        const int rel = item - p.cls_first[k];
+        const int b = rel % p.B;
+        const int jc = rel / p.B;
+        const int t0 = p.cls_t0[k] + jc * C;
+        const int slot = p.cls_slot0[k] + jc;          // ordinal of the item inside its utterance
+        const int nA = C + 2 * halo;                   // frames inverse-transformed: owned + halo either side
+        const int Rr = (nA + GL_NW - 1) / GL_NW;
+        const int R = Rr > ncol ? Rr : ncol;           // overlap-add rounds; wave w owns frames [R w, R w + R)
+        const int span = (nA - 1) * hop + win;
+        const float* magb = p.mag + (size_t)b * p.T * p.FP;
+        const cf* phb = p.phase_in + (size_t)b * p.T * p.FP;
+        unsigned next_item_reg = 0;
+        if (tid == 0) {
+            next_item_reg = atomicAdd(p.work_counter, 1u);   // consumed before the barrier that ends phase A
+            ctrl[CT_BNEXT] = 0;                              // phase B of the previous item is over
+        }
+
+        // Prefetch registers for one frame's spectrum row, already in the layout the split pass wants:
+        // gk[j] = X[lane + 64 j] and gm[j] = X[MH - (lane + 64 j)] (the mirrored bins; lane 0 / j 0 is the
+        // Nyquist bin).  Both are coalesced 512-byte wave loads of the same 8 KB row, so the second set
+        // hits in cache, and the row never has to be staged through LDS.  UNCONDITIONAL loads (the frame
+        // index is clamped instead of branching): registers filled under a branch stay in scratch memory,
+        // and hipcc then waits for the loads right after issuing them.
+        cf gk[16], gm[16];
 #define GL_LOAD_FRAME(FA)                                                                  \
     {                                                                                      \
         int tf_ = t0 - halo + (FA);                                                        \
@@ -291,335 +327,336 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gk[j_] = prow_[64 * j_];         \
         _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gm[j_] = mrow_[-64 * j_];        \
     }
-    GL_LOAD_FRAME(0 + ncol * wave)   // round 0's frame, in flight during the prologue
+        GL_LOAD_FRAME(R * wave)
+        GL_LOAD_WINDOW(1)
 
-    if (tid < GL_NW + 1) ola_done[tid] = 0;   // wave progress flags + phase-B frame counter
-#ifndef GL_ABL_NOZERO
-    for (int i = tid; i < span; i += GL_THREADS) sig[i] = 0.f;
-#endif
-    // All twiddles live in registers for the whole kernel (every lane uses the same 34 values for every
-    // frame): twr[j] = W2048^{lane + 64 j} for the real-FFT split / merge passes, tw.a[k2-1] =
-    // W1024^{lane k2} and tw.b for the FFT itself.  No table in LDS, no LDS read latency inside a round.
-    cf twr[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) twr[j] = p.tw2048[lane + 64 * j];
-    FftTwReg tw;
-#pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) tw.a[k2 - 1] = p.tw1024[(lane * k2) & 1023];
-#pragma unroll
-    for (int d = 1; d < 4; ++d) tw.b[d - 1] = p.tw1024[16 * (lane & 15) * d];
-    // this lane's window samples (n = 2*(lane + 64 c) + {0,1}) straight from global memory; wreg
-    // carries the iFFT scale 1/(2*MH) (the forward FFT of phase B uses the same scaled window:
-    // unit phasors do not depend on scale)
-    float wreg[16][2];
-#pragma unroll
-    for (int c = 0; c < 16; ++c)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int nw = 2 * (lane + 64 * c) + e - wpad;
-            const bool in = nw >= 0 && nw < win;
-            const float wv = p.window[in ? nw : 0];   // unconditional load, masked below
-            wreg[c][e] = in ? wv * (0.5f / (float)MH) : 0.f;
-        }
-    __syncthreads();
-    GL_STAMP();   // 1: prologue done
-
-    // ---------------- phase A: inverse FFT + windowed overlap-add into LDS
-#ifndef GL_NO_UNROLL_A
-#pragma unroll
-#endif
-    for (int r = 0; r < ncol; ++r) {
+        // ---------------- phase A: inverse FFT + windowed overlap-add into LDS
+        // Frame fa = R*wave + r is processed by `wave` in round r.  Frames of one round are >= ncol apart
+        // (disjoint samples); frames of wave w and w+1 overlap only when r' < r - (R - ncol), so wave w
+        // accumulates round r once wave w+1 has finished that many rounds (progress flags in LDS): no
+        // atomics, no workgroup barriers inside the phase, fixed summation order.  Round 0 STORES (each
+        // wave also zeroes the rest of its own region), so the buffer needs no clearing pass.
+        for (int r = 0; r < R; ++r) {
 #ifndef GL_NO_ALTPRIO
-        if ((r + (wave >= GL_NW / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            if ((r + (wave >= GL_NW / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
-        const int fa = r + ncol * wave;
-        const bool ok = frame_valid(fa);
-        cf v[16];
-        GL_FSTAMP(r == 2);   // F1: A round start
-        if (ok) {
+            const int fa = r + R * wave;
+            const int tf = t0 - halo + fa;
+            const bool ok = fa < nA && tf >= 0 && tf < p.T;
+            cf v[16];
+            if (ok) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int k = lane + 64 * j;
-                cf xk = gk[j];
-                cf xm = cconj(gm[j]);
-                if (j == 0 && lane == 0) { xk.y = 0.f; xm.y = 0.f; }   // DC and Nyquist bins are real
-                // Zin = E + i O, E = (xk + xm)/2, O = conj(twr) (xk - xm)/2 ; feed conj(Zin).
-                // The two 1/2 factors are folded into the output scale (the FFT is linear).
-                const cf e = cadd(xk, xm);
-                const cf o = cmul(cconj(twr[j]), csub(xk, xm));
-                const cf zin = cadd(e, cmul_pi(o));
-                v[j] = cconj(zin);
+                for (int j = 0; j < 16; ++j) {
+                    cf xk = gk[j];
+                    cf xm = cconj(gm[j]);
+                    if (j == 0 && lane == 0) { xk.y = 0.f; xm.y = 0.f; }   // DC and Nyquist bins are real
+                    // Zin = E + i O, E = (xk + xm)/2, O = conj(twr) (xk - xm)/2 ; feed conj(Zin).
+                    // The two 1/2 factors are folded into the output scale (the FFT is linear).
+                    const cf e = cadd(xk, xm);
+                    const cf o = cmul(cconj(twr[j]), csub(xk, xm));
+                    const cf zin = cadd(e, cmul_pi(o));
+                    v[j] = cconj(zin);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = cmk(0.f, 0.f);
             }
-        }
-        // the row is consumed: fetch the next round's frame into the same registers now, it lands
-        // while this frame's FFT runs
-        if (r + 1 < ncol) GL_LOAD_FRAME(fa + 1)
-        GL_FSTAMP(r == 2);   // F2: split pass done, next loads issued
-        if (ok) {
-            fft1024(v, ex, tw, lane);
-            // z[m] = conj(v)/MH, m = lane + 64 c: x[2m] = Re, x[2m+1] = Im
+            // the row is consumed: fetch the next round's frame into the same registers now, it lands
+            // while this frame's FFT runs
+            if (r + 1 < R) GL_LOAD_FRAME(fa + 1)
+            if (ok) {
+                fft1024(v, ex, tw, lane);
+                // z[m] = conj(v)/MH, m = lane + 64 c: x[2m] = Re, x[2m+1] = Im
+                if (tf >= halo && tf + halo < p.T) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) v[c] = cmk(v[c].x * wreg[c][0], -v[c].y * wreg[c][1]);
-        }
-        // Overlap-add ordering without a workgroup barrier: frame fa = r + ncol*wave overlaps, among
-        // the frames of OTHER waves, only frames of wave+1 from EARLIER rounds (distance
-        // ncol + r' - r < ncol iff r' < r).  So wave w may accumulate round r once wave w+1 has
-        // finished rounds < r; every overlapping pair is ordered => fixed summation order.
-        GL_FSTAMP(r == 2);   // F3: FFT + window done
-        if (r > 0 && wave + 1 < GL_NW) {
-            volatile int* flag = ola_done + wave + 1;
-            while (*flag < r) __builtin_amdgcn_s_sleep(1);
-        }
-        asm volatile("" ::: "memory");
-        GL_FSTAMP(r == 2);   // F4: neighbour flag seen
-        if (ok) {
+                    for (int c = 0; c < 16; ++c) v[c] = cmk(v[c].x * wreg[c][0], -v[c].y * wreg[c][1]);
+                } else {
+                    // frame near an utterance end: fewer overlapping neighbours, take 1 / wss per sample
+                    // (rare path; four slots at a time so that its loads do not inflate the register budget)
+                    const float* rwp = p.rwss + (size_t)tf * hop + wpad;
+#pragma unroll
+                    for (int c0 = 0; c0 < 16; c0 += 4) {
+#pragma unroll
+                        for (int c = c0; c < c0 + 4; ++c) {
+                            const int nw0 = 2 * (lane + 64 * c) - wpad;
+                            const bool i0 = nw0 >= 0 && nw0 < win, i1 = nw0 + 1 >= 0 && nw0 + 1 < win;
+                            const float r0 = rwp[i0 ? nw0 : 0], r1 = rwp[i1 ? nw0 + 1 : 0];
+                            const float w0 = p.wlane[lane * 32 + 2 * c];
+                            const float w1 = p.wlane[lane * 32 + 2 * c + 1];
+                            v[c] = cmk(v[c].x * w0 * r0, -v[c].y * w1 * r1);
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+                }
+            }
+            const int need = r - (R - ncol);
+            if (need > 0 && wave + 1 < GL_NW) {
+                volatile int* flag = ctrl + CT_FLAGS + wave + 1;
+                while (*flag < need) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
             float* sf = sig + fa * hop;
+            if (r == 0) {
+                const int lo = fa * hop;
+                const int hi_w = (fa + R) * hop;
+                const int hi = (wave == GL_NW - 1 || hi_w > span) ? span : hi_w;
+                int zlo = lo;
+                if (fa < nA) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const int n = 2 * (lane + 64 * c);
-                const int nw0 = n - wpad, nw1 = n + 1 - wpad;
-#ifdef GL_OLA_ATOMIC
-                // LDS float add without return (ds_add_f32): one DS op instead of read + add + write.
-                // Still deterministic: all adds to one address are ordered by the wave-progress flags.
-                if (nw0 >= 0 && nw0 < win) __hip_atomic_fetch_add(&sf[nw0], v[c].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (nw1 >= 0 && nw1 < win) __hip_atomic_fetch_add(&sf[nw1], v[c].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-                if (nw0 >= 0 && nw0 < win) sf[nw0] += v[c].x;
-                if (nw1 >= 0 && nw1 < win) sf[nw1] += v[c].y;
-#endif
+                    for (int c = 0; c < 16; ++c) {
+                        const int nw0 = 2 * (lane + 64 * c) - wpad, nw1 = nw0 + 1;
+                        if (nw0 >= 0 && nw0 < win) sf[nw0] = v[c].x;
+                        if (nw1 >= 0 && nw1 < win) sf[nw1] = v[c].y;
+                    }
+                    zlo = lo + win;
+                }
+                for (int i = zlo + lane; i < hi; i += 64) sig[i] = 0.f;
+            } else if (ok) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int nw0 = 2 * (lane + 64 * c) - wpad, nw1 = nw0 + 1;
+                    if (nw0 >= 0 && nw0 < win) sf[nw0] += v[c].x;
+                    if (nw1 >= 0 && nw1 < win) sf[nw1] += v[c].y;
+                }
             }
+            asm volatile("" ::: "memory");
+            if (lane == 0) *reinterpret_cast<volatile int*>(ctrl + CT_FLAGS + wave) = r + 1;
         }
-        asm volatile("" ::: "memory");
-        if (lane == 0) *reinterpret_cast<volatile int*>(ola_done + wave) = r + 1;
-        GL_FSTAMP(r == 2);   // F5: overlap-add done
-        GL_STAMP();   // 2..6: end of A round r
-    }
-    // ---------------- window-sum-square normalisation (librosa istft: divide where wss > tiny)
-    // p.rwss holds 1 / wss where wss > tiny and 1 elsewhere, so the pass is one multiply per sample.
-    // All of a thread's table loads are issued back to back BEFORE the barrier that ends phase A, so
-    // their latency hides behind the wait for the slowest wave; the LDS read-modify-writes then run
-    // from registers.
-    const int ybase = (t0 - halo) * hop + wpad - MH;   // trimmed-signal index of sig[0]
-    const int wss_len = NFFT + hop * (p.T - 1);
-    constexpr int NBATCH = 24;   // one batch covers the reference chunk (11,827 samples / 512 threads)
-    float ws[NBATCH];
-#ifndef GL_ABL_NONORM
-#pragma unroll
-    for (int j = 0; j < NBATCH; ++j) {
-        const int mfull = ybase + tid + j * GL_THREADS + MH;
-        // unconditional load of a clamped index (a load under a divergent branch makes hipcc
-        // drain vmcnt at the join); out-of-range elements are masked below
-        ws[j] = p.rwss[mfull < 0 ? 0 : (mfull >= wss_len ? wss_len - 1 : mfull)];
-    }
-#endif
-    __syncthreads();
-    GL_STAMP();   // 7: all overlap-adds done
-#ifndef GL_ABL_NONORM
-    for (int i0 = tid; i0 < span; i0 += GL_THREADS * NBATCH) {
-        if (i0 != tid) {   // spans longer than one batch (non-reference window/hop)
-#pragma unroll
-            for (int j = 0; j < NBATCH; ++j) {
-                const int mfull = ybase + i0 + j * GL_THREADS + MH;
-                ws[j] = p.rwss[mfull < 0 ? 0 : (mfull >= wss_len ? wss_len - 1 : mfull)];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NBATCH; ++j) {
-            const int i = i0 + j * GL_THREADS;
-            const int mfull = ybase + i + MH;
-            if (i < span && mfull >= 0 && mfull < wss_len) sig[i] *= ws[j];
-        }
-    }
-#endif
-    __syncthreads();
-    GL_STAMP();   // 8: normalised
+        if (tid == 0) ctrl[CT_NEXT_ITEM] = (int)next_item_reg;
+        __syncthreads();   // all overlap-adds done (the signal is final), next item published
+        const int next_item = __builtin_amdgcn_readfirstlane(ctrl[CT_NEXT_ITEM]);
+        if (tid < GL_NW) ctrl[CT_FLAGS + tid] = 0;   // nobody looks at the phase-A flags before the next item
+        const int ybase = (t0 - halo) * hop + wpad - MH;   // trimmed-signal index of sig[0]
 
-    if (MODE == 1) {
-        // owned samples: y in [t0*hop, (t0+C)*hop) intersected with [0, L)
-        float* wb = p.wav + (size_t)b * L;
-        const int y0 = t0 * hop;
-        const int y1 = min((t0 + C) * hop, L);
-        float pk = 0.f;
-        for (int y = y0 + tid; y < y1; y += GL_THREADS) {
-            const float v = sig[y - ybase];
-            wb[y] = v;
-            pk = fmaxf(pk, fabsf(v));
-        }
-        if (p.peak_partial) {   // per-chunk max |wav| for the fused peak normalisation
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) pk = fmaxf(pk, __shfl_xor(pk, o));
-            float* red = reinterpret_cast<float*>(ex_all);   // exchange buffers are idle now
-            __syncthreads();
-            if (lane == 0) red[wave] = pk;
-            __syncthreads();
-            if (tid == 0) {
-                float m = 0.f;
-                for (int w = 0; w < GL_NW; ++w) m = fmaxf(m, red[w]);
-                p.peak_partial[(size_t)b * nchunks + chunk] = m;
+        if (MODE == 1) {
+            // owned samples: y in [t0*hop, (t0+C)*hop) intersected with [0, L)
+            float* wb = p.wav + (size_t)b * L;
+            const int y0 = t0 * hop;
+            const int y1 = min((t0 + C) * hop, L);
+            float pk = 0.f;
+            for (int y = y0 + tid; y < y1; y += GL_THREADS) {
+                const float v = sig[y - ybase];
+                wb[y] = v;
+                pk = fmaxf(pk, fabsf(v));
             }
-        }
-        return;
-    }
-
-    // ---------------- phase B: forward FFT of the owned frames, new unit phasors
-    cf* pob = p.phase_out + (size_t)b * p.T * p.FP;
-    float mse_acc = 0.f;
-    // frames are handed out dynamically (LDS counter): the wave that wins issue arbitration on its
-    // SIMD takes more of them, so both waves of a SIMD finish together
-    int* b_next = ola_done + GL_NW;
-    for (int r = 0;; ++r) {
-#ifndef GL_NO_ALTPRIO
-        if ((r + (wave >= GL_NW / 2 ? 0 : 1)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
-        int fb = wave + GL_NW * r;   // static map when the per-wave mse sums must have a fixed order
-        if (!MSE) {
-            if (lane == 0) fb = atomicAdd(b_next, 1);
-            fb = __builtin_amdgcn_readfirstlane(fb);
-        }
-        const int t = t0 + fb;
-        if (fb >= C || t >= p.T) break;   // wave-uniform
-        GL_FSTAMP(r == 1);   // F6: B round start
-        cf v[16];
-        // target magnitudes of this frame (needed only after the FFT: the loads fly meanwhile)
-        const float* mrow = magb + (size_t)t * p.FP;
-        float mg[16];
+            if (p.peak_partial) {   // per-item max |wav| for the fused peak normalisation
 #pragma unroll
-#ifdef GL_ABL_NOMAG
-        for (int c = 0; c < 16; ++c) mg[c] = 1.0f + c;
-#else
-        for (int c = 0; c < 16; ++c) mg[c] = fabsf(mrow[lane + 64 * c]);
-#endif
-        const int ylo = t * hop + wpad - MH;          // y index of window sample 0
-        const bool edge = ylo < 0 || ylo + win > L;   // wave-uniform: reflect padding needed
-        if (!edge) {
-            const float* sf = sig + (fb + halo) * hop;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int n = 2 * (lane + 64 * j);
-                const int nw0 = n - wpad, nw1 = n + 1 - wpad;
-                float x0 = 0.f, x1 = 0.f;
-                if (nw0 >= 0 && nw0 < win) x0 = wreg[j][0] * sf[nw0];
-                if (nw1 >= 0 && nw1 < win) x1 = wreg[j][1] * sf[nw1];
-                v[j] = cmk(x0, x1);
+                for (int o = 32; o > 0; o >>= 1) pk = fmaxf(pk, __shfl_xor(pk, o));
+                float* red = reinterpret_cast<float*>(ex_all);   // exchange buffers are idle now
+                if (lane == 0) red[wave] = pk;
+                __syncthreads();
+                if (tid == 0) {
+                    float m = 0.f;
+                    for (int w = 0; w < GL_NW; ++w) m = fmaxf(m, red[w]);
+                    p.peak_partial[(size_t)b * p.slots_per_utt + slot] = m;
+                }
             }
         } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int n = 2 * (lane + 64 * j);
-                float x0 = 0.f, x1 = 0.f;
-                const int nw0 = n - wpad, nw1 = n + 1 - wpad;
-                if (nw0 >= 0 && nw0 < win) {
-                    int y = ylo + nw0;
-                    y = y < 0 ? -y : y;
-                    y = y >= L ? 2 * (L - 1) - y : y;
-                    x0 = wreg[j][0] * sig[y - ybase];
+            // ---------------- phase B: forward FFT of the owned frames, new unit phasors
+            GL_LOAD_WINDOW(0)
+            cf* pob = p.phase_out + (size_t)b * p.T * p.FP;
+            float mse_acc = 0.f;
+            // frames are handed out dynamically (LDS counter): the wave that wins issue arbitration on
+            // its SIMD takes more of them, so both waves of a SIMD finish together
+            int* b_next = ctrl + CT_BNEXT;
+            for (int r = 0;; ++r) {
+#ifndef GL_NO_ALTPRIO
+                if ((r + (wave >= GL_NW / 2 ? 0 : 1)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+                int fb = wave + GL_NW * r;   // static map when the per-wave mse sums must have a fixed order
+                if (!MSE) {
+                    if (lane == 0) fb = atomicAdd(b_next, 1);
+                    fb = __builtin_amdgcn_readfirstlane(fb);
                 }
-                if (nw1 >= 0 && nw1 < win) {
-                    int y = ylo + nw1;
-                    y = y < 0 ? -y : y;
-                    y = y >= L ? 2 * (L - 1) - y : y;
-                    x1 = wreg[j][1] * sig[y - ybase];
+                const int t = t0 + fb;
+                if (fb >= C || t >= p.T) break;   // wave-uniform
+                cf v[16];
+                // target magnitudes of this frame (needed only after the FFT: the loads fly meanwhile)
+                const float* mrow = magb + (size_t)t * p.FP;
+                float mg[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) mg[c] = fabsf(mrow[lane + 64 * c]);
+                const int ylo = t * hop + wpad - MH;          // y index of window sample 0
+                const bool edge = ylo < 0 || ylo + win > L;   // wave-uniform: reflect padding needed
+                if (!edge) {
+                    const float* sf = sig + (fb + halo) * hop;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int n = 2 * (lane + 64 * j);
+                        const int nw0 = n - wpad, nw1 = n + 1 - wpad;
+                        float x0 = 0.f, x1 = 0.f;
+                        if (nw0 >= 0 && nw0 < win) x0 = wreg[j][0] * sf[nw0];
+                        if (nw1 >= 0 && nw1 < win) x1 = wreg[j][1] * sf[nw1];
+                        v[j] = cmk(x0, x1);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int n = 2 * (lane + 64 * j);
+                        float x0 = 0.f, x1 = 0.f;
+                        const int nw0 = n - wpad, nw1 = n + 1 - wpad;
+                        if (nw0 >= 0 && nw0 < win) {
+                            int y = ylo + nw0;
+                            y = y < 0 ? -y : y;
+                            y = y >= L ? 2 * (L - 1) - y : y;
+                            x0 = wreg[j][0] * sig[y - ybase];
+                        }
+                        if (nw1 >= 0 && nw1 < win) {
+                            int y = ylo + nw1;
+                            y = y < 0 ? -y : y;
+                            y = y >= L ? 2 * (L - 1) - y : y;
+                            x1 = wreg[j][1] * sig[y - ybase];
+                        }
+                        v[j] = cmk(x0, x1);
+                    }
                 }
-                v[j] = cmk(x0, x1);
-            }
-        }
-        GL_FSTAMP(r == 1);   // F7: windowed frame in registers
-        fft1024(v, ex, tw, lane);
-        GL_FSTAMP(r == 1);   // F8: FFT done
+                fft1024(v, ex, tw, lane);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
-        wave_lds_sync();
-        cf* orow = pob + (size_t)t * p.FP;
-        // next estimate: target magnitude, new phase.  Fast path: x * (rsqrt(|x|^2) * |S|), valid while
-        // |x|^2 stays well inside the float range; the min / max of |x|^2 over the lane's bins are tracked
-        // and the (practically never taken) exact path below redoes the frame otherwise.
-        float s_min = 3.0e38f, s_max = 0.f;
-        cf zmr[16];   // all mirrored bins first: one LDS latency for the pass instead of one per bin
+                for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
+                wave_lds_sync();
+                cf* orow = pob + (size_t)t * p.FP;
+                // next estimate: target magnitude, new phase.  Fast path: x * (rsq(|x|^2) * |S|), valid
+                // while |x|^2 stays well inside the float range; the min / max of |x|^2 over the lane's
+                // bins are tracked and the (practically never taken) exact path below redoes the frame
+                // otherwise.
+                float s_min = 3.0e38f, s_max = 0.f;
+                cf zmr[16];   // all mirrored bins first: one LDS latency for the pass instead of one per bin
 #pragma unroll
-#ifdef GL_ABL_NOMIRROR
-        for (int c = 0; c < 16; ++c) zmr[c] = v[15 - c];
-#else
-        for (int c = 0; c < 16; ++c) zmr[c] = ex[(MH - (lane + 64 * c)) & (MH - 1)];
-#endif
+                for (int c = 0; c < 16; ++c) zmr[c] = ex[(MH - (lane + 64 * c)) & (MH - 1)];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int k = lane + 64 * c;
-            const cf zk = v[c];
-            const cf zm = cconj(zmr[c]);
-            // 2 X[k] = (zk + zm) - i twr (zk - zm); the phase does not care about the factor 2
-            const cf e = cadd(zk, zm);
-            const cf o = cmul(twr[c], csub(zk, zm));
-            const cf x = cadd(e, cmul_mi(o));
-            const float s = fmaf(x.x, x.x, x.y * x.y);
-#ifdef GL_ABL_NORSQ
-            const float g = s * mg[c];
-#else
-            const float g = __builtin_amdgcn_rsqf(s) * mg[c];   // raw v_rsq_f32: s is range-checked below
-#endif
-#ifdef GL_ABL_NOSTORE
-            if (g == 123.456f)
-#endif
-            orow[k] = cmk(x.x * g, x.y * g);
-            s_min = fminf(s_min, s);
-            s_max = fmaxf(s_max, s);
-            if (MSE) {
-                const float d = mg[c] - (float)MH * sqrtf(s);   // x = X / MH
-                mse_acc += d * d;
-            }
-        }
-        if (__builtin_expect(__any(!(s_min > 1.0e-30f && s_max < 1.0e30f)), 0)) {
-            // exact path: zero / tiny / huge bins (angle(0) = 0, range-safe normalisation)
+                for (int c = 0; c < 16; ++c) {
+                    const int k = lane + 64 * c;
+                    const cf zk = v[c];
+                    const cf zm = cconj(zmr[c]);
+                    // 2 X[k] = (zk + zm) - i twr (zk - zm); the phase does not care about the factor 2
+                    const cf e = cadd(zk, zm);
+                    const cf o = cmul(twr[c], csub(zk, zm));
+                    const cf x = cadd(e, cmul_mi(o));
+                    const float s = fmaf(x.x, x.x, x.y * x.y);
+                    const float g = __builtin_amdgcn_rsqf(s) * mg[c];   // raw v_rsq_f32: s is range-checked below
+                    orow[k] = cmk(x.x * g, x.y * g);
+                    s_min = fminf(s_min, s);
+                    s_max = fmaxf(s_max, s);
+                    if (MSE) {
+                        const float d = mg[c] - (float)MH * sqrtf(s);   // x = X / MH
+                        mse_acc += d * d;
+                    }
+                }
+                if (__builtin_expect(__any(!(s_min > 1.0e-30f && s_max < 1.0e30f)), 0)) {
+                    // exact path: zero / tiny / huge bins (angle(0) = 0, range-safe normalisation)
 #pragma unroll 1
-            for (int c = 0; c < 16; ++c) {
-                const int k = lane + 64 * c;
-                const cf zk = ex[k];
-                const cf zm = cconj(ex[(MH - k) & (MH - 1)]);
-                const cf e = cadd(zk, zm);
-                const cf o = cmul(p.tw2048[k], csub(zk, zm));
-                const cf x = cadd(e, cmul_mi(o));
-                orow[k] = cscale(unit_phasor(x), fabsf(mrow[k]));
+                    for (int c = 0; c < 16; ++c) {
+                        const int k = lane + 64 * c;
+                        const cf zk = ex[k];
+                        const cf zm = cconj(ex[(MH - k) & (MH - 1)]);
+                        const cf e = cadd(zk, zm);
+                        const cf o = cmul(p.tw2048[k], csub(zk, zm));
+                        const cf x = cadd(e, cmul_mi(o));
+                        orow[k] = cscale(unit_phasor(x), fabsf(mrow[k]));
+                    }
+                }
+                if (lane == 0) {
+                    const cf z0 = v[0];
+                    const float xn = z0.x - z0.y;   // Nyquist bin, real
+                    const float mn = fabsf(mrow[MH]);
+                    orow[MH] = cmk(xn < 0.f ? -mn : mn, 0.f);
+                    if (MSE) {
+                        const float d = mn - (2.0f * MH) * fabsf(xn);   // xn = X[MH] / (2 MH)
+                        mse_acc += d * d;
+                    }
+                }
+                wave_lds_sync();
             }
-        }
-        if (lane == 0) {
-            const cf z0 = v[0];
-            const float xn = z0.x - z0.y;   // Nyquist bin, real
-            const float mn = fabsf(mrow[MH]);
-            orow[MH] = cmk(xn < 0.f ? -mn : mn, 0.f);
             if (MSE) {
-                const float d = mn - (2.0f * MH) * fabsf(xn);   // xn = X[MH] / (2 MH)
-                mse_acc += d * d;
+                __syncthreads();   // all waves done with their exchange buffers
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mse_acc += __shfl_xor(mse_acc, o);
+                float* red = reinterpret_cast<float*>(ex_all);
+                if (lane == 0) red[wave] = mse_acc;
+                __syncthreads();
+                if (tid == 0) {
+                    float s = 0.f;
+                    for (int w = 0; w < GL_NW; ++w) s += red[w];
+                    p.mse_partial[(size_t)b * p.slots_per_utt + slot] = s;
+                }
             }
         }
-        wave_lds_sync();
-        GL_FSTAMP(r == 1);   // F9: merge pass + stores issued
-        GL_STAMP();   // 9..12: end of B round
+        __syncthreads();   // everyone is done with the signal buffer: the next item may overwrite it
+        item = next_item;
     }
-#ifdef GL_STAMPS
-    if (lane == 0 && p.mse_partial == nullptr && blockIdx.x % 97 == 0) {
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.wav) + ((size_t)(blockIdx.x / 97) * GL_NW + wave) * 16;
-        for (int i = 0; i < 16; ++i) dst[i] = i < nst ? stamps[i] : 0;
-    }
-#endif
-    if (MSE) {
-        __syncthreads();   // all waves done with their exchange buffers
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mse_acc += __shfl_xor(mse_acc, o);
-        float* red = reinterpret_cast<float*>(ex_all);
-        if (lane == 0) red[wave] = mse_acc;
-        __syncthreads();
-        if (tid == 0) {
-            float s = 0.f;
-            for (int w = 0; w < GL_NW; ++w) s += red[w];
-            p.mse_partial[(size_t)b * nchunks + chunk] = s;
-        }
-    }
+#undef GL_LOAD_FRAME
+#undef GL_LOAD_WINDOW
 }
 
 size_t gl_lds_bytes(const GlParams& p) {
     const int halo = p.ncol - 1;
     const int nA = p.C + 2 * halo;
     const int span = (nA - 1) * p.hop + p.win;
-    return (size_t)(GL_NW * EX_CPLX) * sizeof(cf) + 16 * sizeof(int) + (size_t)((span + 3) & ~3) * sizeof(float);
+    return (size_t)(GL_NW * EX_CPLX) * sizeof(cf) + CT_WORDS * sizeof(int) + (size_t)((span + 3) & ~3) * sizeof(float);
+}
+
+void gl_build_wlane(const float* window, const float* rwss, int win, int hop, int T, float* out) {
+    const int wpad = (NFFT - win) / 2;
+    const int halo = (win + hop - 1) / hop - 1;
+    const int t_ref = halo < T ? halo : T - 1;   // an interior frame (all `halo` neighbours either side exist) if there is one
+    for (int c = 0; c < 16; ++c)
+        for (int e = 0; e < 2; ++e)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int nw = 2 * (lane + 64 * c) + e - wpad;
+                const bool in = nw >= 0 && nw < win;
+                const float w = in ? window[nw] * (0.5f / (float)MH) : 0.f;
+                const float rw = in ? rwss[(size_t)t_ref * hop + wpad + nw] : 0.f;
+                out[(0 * 64 + lane) * 32 + 2 * c + e] = w;
+                out[(1 * 64 + lane) * 32 + 2 * c + e] = w * rw;
+            }
+}
+
+// Largest item size (frames owned per work item) whose signal buffer fits in LDS, at most 64; sizes are
+// 8 R - 2 halo so that the overlap-add rounds of all eight waves are full.
+int gl_max_item_frames(int win, int hop) {
+    GlParams q;
+    q.win = win; q.hop = hop;
+    q.ncol = (win + hop - 1) / hop;
+    int best = 0;
+    for (int R = q.ncol; R <= 16; ++R) {
+        q.C = GL_NW * R - 2 * (q.ncol - 1);
+        if (q.C > 64) break;
+        if (q.C >= 1 && gl_lds_bytes(q) <= 160 * 1024) best = q.C;
+    }
+    return best;
+}
+
+// Work-item schedule of one launch: per utterance T frames are cut into items of cls_C[k] frames, class by
+// class in descending size; items are numbered class-major with the utterance index fastest.
+void gl_plan_items(GlParams& p, int n_cus) {
+    const int cmax = gl_max_item_frames(p.win, p.hop);
+    const int step = GL_NW;
+    // small batches: prefer more, smaller items so that every compute unit gets work
+    int C = cmax;
+    while (C - step >= step && (long long)p.B * ((p.T + C - 1) / C) < 2LL * n_cus) C -= step;
+    p.C = C;
+    int ncls = 0, t = 0, slot = 0, first = 0;
+    auto add = [&](int c, int n) {
+        if (n <= 0 || c <= 0) return;
+        p.cls_C[ncls] = c; p.cls_n[ncls] = n; p.cls_t0[ncls] = t; p.cls_slot0[ncls] = slot; p.cls_first[ncls] = first;
+        t += c * n; slot += n; first += n * p.B;
+        ++ncls;
+    };
+    const int n_big = p.T / C;
+    int rem = p.T - n_big * C;
+    add(C, n_big);
+    // the remainder goes last; a remainder of more than half an item is split in two so that the tail of
+    // the launch is made of small items
+    if (rem > C / 2 && rem >= 2 * step) {
+        const int half = ((rem / 2 + step - 1) / step) * step;
+        add(half, 1);
+        rem -= half;
+    }
+    add(rem, 1);
+    for (int k = ncls; k < GL_MAX_CLASSES; ++k) { p.cls_C[k] = 0; p.cls_n[k] = 0; p.cls_t0[k] = 0; p.cls_slot0[k] = 0; p.cls_first[k] = first; }
+    p.n_classes = ncls;
+    p.n_items = first;
+    p.slots_per_utt = slot;
 }
 
 template <int MODE, int W, int H, bool MSE>
@@ -638,10 +675,12 @@ hipError_t gl_configure() {
     return gl_set_attr<1, 1102, 275, false>();
 }
 
-hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int B, int final_istft) {
-    const int nchunks = (p.T + p.C - 1) / p.C;
-    dim3 grid(nchunks * B);
+// p.work_counter must point at a zeroed counter that no other launch uses.
+hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int n_cus, int final_istft) {
     const size_t lds = gl_lds_bytes(p);
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int nwg = p.n_items < n_cus * per_cu ? p.n_items : n_cus * per_cu;
+    dim3 grid(nwg);
     const bool ref_cfg = p.win == 1102 && p.hop == 275;   // the reference's 50 ms / 12.5 ms at 22.05 kHz
     const bool mse = p.mse_partial != nullptr;
 #define GL_LAUNCH(MODE, W, H, M) hipLaunchKernelGGL((gl_iter_kernel<MODE, W, H, M>), grid, dim3(GL_THREADS), lds, s, p)

@@ -89,12 +89,16 @@ def test_config4_griffin_lim_full_length(engine):
     e = rel_l2(wav.to_host()[0], ref_wav)
     print('config 4 GL T=1000, 3 iterations: wav rel-L2 {:.3e}, mse {} vs {}'.format(e, mse.to_host()[0], ref_mse))
     assert e < 1e-3 and abs(mse.to_host()[0] - ref_mse) < 1e-3 * ref_mse
-    # batch of 64 copies: every row identical to the single run (no cross-utterance coupling)
+    # batch of 64 copies: no cross-utterance coupling.  Rows of one batch are bitwise identical; against the
+    # single run only the partition into work items (hence the overlap-add summation order) may differ
     big = engine.to_device(np.broadcast_to(mag1, (64,) + mag1.shape).copy())
     init64 = engine.to_device(np.broadcast_to(init[0], (64,) + init[0].shape).copy())
     w64, m64 = engine.griffin_lim(big, 3, WIN, HOP, N_FFT, init_phase=init64)
     w64 = w64.to_host()
-    assert np.array_equal(w64[0], wav.to_host()[0]) and np.array_equal(w64[63], w64[0])
+    assert np.array_equal(w64[63], w64[0]) and np.array_equal(w64[31], w64[0])
+    assert rel_l2(w64[0], wav.to_host()[0]) < 1e-5
+    w64b, _ = engine.griffin_lim(big, 3, WIN, HOP, N_FFT, init_phase=init64)
+    assert np.array_equal(w64b.to_host(), w64)          # run-to-run bitwise reproducible
     # mse decreases with iterations; round trip: |STFT(iSTFT(S))| of a consistent S returns S
     _, m10 = engine.griffin_lim(mag1[None], 10, WIN, HOP, N_FFT, init_phase=init)
     assert m10.to_host()[0] < mse.to_host()[0]
