@@ -89,7 +89,7 @@ int tts_set_stream(tts_handle_t h, void* hip_stream);
  * per-stage HIP events, default 0), "pipeline" (default 1: tts_synthesize runs the encoder and
  * the decoder loop of a call on a second stream so that they overlap the Griffin-Lim iterations of
  * the PREVIOUS call still in flight; only while the library owns its stream, and inputs must be
- * complete when the call is made), "reserve_cus" (default 8: compute units kept free of
+ * complete when the call is made), "reserve_cus" (default 32: compute units kept free of
  * Griffin-Lim workgroups for that second stream, 0 = none). */
 int tts_set_option(tts_handle_t h, const char* key, int value);
 int tts_synchronize(tts_handle_t h);

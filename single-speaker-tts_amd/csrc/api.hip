@@ -65,14 +65,16 @@ struct tts_handle_s {
     // tts_synthesize pipelining: encoder + decoder (latency bound, few CUs) of call k+1 run on
     // `front` while post-net + Griffin-Lim (throughput bound) of call k run on `stream`.
     int pipeline = 1;      // on while the library owns its stream (see tts_synthesize); ~9 % on MI355X
-    int reserve_cus = 8;   // CUs held for the front stream by LDS-hogging sleeper workgroups (reserve.hip)
+    int reserve_cus = 32;  // CUs held for the front stream by LDS-hogging sleeper workgroups (reserve.hip)
     hipStream_t aux = nullptr;      // stream the sleepers run on
     int* hold_flags = nullptr;      // two flag words, alternating per call
     hipEvent_t ev_aux = nullptr;
     unsigned call_count = 0;
     hipStream_t front = nullptr;
-    hipEvent_t ev_front_done = nullptr, ev_post_done = nullptr;
-    bool post_pending = false;
+    hipEvent_t ev_front_done = nullptr;
+    hipEvent_t ev_post_done[2] = {nullptr, nullptr};   // post-net of the calls of even / odd parity
+    bool post_pending[2] = {false, false};
+    unsigned syn_calls = 0;
 
     std::vector<ManifestEntry> manifest;
     std::map<std::string, std::vector<float>> host_w;
@@ -788,7 +790,10 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     p.B = B;
     if (gl_max_item_frames(win, hop) < 1) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: window does not fit in LDS");
     const int n_cus = device_cus(h);
-    gl_plan_items(p, n_cus);
+    // workgroups that really run side by side: the pipelined tts_synthesize keeps `reserve_cus` compute units
+    // free of Griffin-Lim for its second stream
+    const int held = (h->pipeline && h->own_stream && h->reserve_cus > 0 && h->front) ? h->reserve_cus : 0;
+    gl_plan_items(p, n_cus - held > 16 ? n_cus - held : n_cus);
     const int nchunks = p.slots_per_utt;
     WS(h, "gl.mse_partial", float, (size_t)B * nchunks, msep);
     // one zeroed work counter per launch (the persistent workgroups draw their item ids from it)
@@ -926,7 +931,8 @@ int tts_destroy(tts_handle_t h) {
     if (h->hold_flags) hipFree(h->hold_flags);
     if (h->ev_aux) hipEventDestroy(h->ev_aux);
     if (h->ev_front_done) hipEventDestroy(h->ev_front_done);
-    if (h->ev_post_done) hipEventDestroy(h->ev_post_done);
+    for (int i = 0; i < 2; ++i)
+        if (h->ev_post_done[i]) hipEventDestroy(h->ev_post_done[i]);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return TTS_OK;
@@ -940,7 +946,7 @@ int tts_set_stream(tts_handle_t h, void* s) {
         int rc = sync_all(h);
         if (rc) return rc;
     }
-    h->post_pending = false;
+    h->post_pending[0] = h->post_pending[1] = false;
     if (h->dec_graph) {
         hipGraphExecDestroy(h->dec_graph);
         h->dec_graph = nullptr;
@@ -965,7 +971,7 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     } else if (!std::strcmp(key, "pipeline")) {
         int rc = sync_all(h);
         if (rc) return rc;
-        h->post_pending = false;
+        h->post_pending[0] = h->post_pending[1] = false;
         h->pipeline = value;
     }
     else return fail(h, TTS_ERR_INVALID, std::string("unknown option ") + key);
@@ -1436,10 +1442,14 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     if ((rc = denorm_check(h, sp->ref_db, sp->max_db))) return rc;
     if ((rc = gl_prepare(h, T, sp->win_length, sp->hop_length, c.n_fft))) return rc;
     WS(h, "syn.memory", float, (size_t)B * Ts * 2 * c.n_gru_units, memory);
+    // The decoder output is double-buffered by call parity: the encoder / decoder of call j+1 (second
+    // stream) may then run while the post-net of call j still reads its mel spectrogram.
+    const int parity = (int)(h->syn_calls++ & 1);
     float* mel = mel_out;
     if (!mel) {
-        WS(h, "syn.mel", float, (size_t)B * T * c.n_mels, melb);
-        mel = melb;
+        WS(h, "syn.mel0", float, (size_t)B * T * c.n_mels, melb0);
+        WS(h, "syn.mel1", float, (size_t)B * T * c.n_mels, melb1);
+        mel = parity ? melb1 : melb0;
     }
     float* linear = linear_out;
     if (!linear) {
@@ -1457,14 +1467,18 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
             HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->hold_flags), 2 * sizeof(int)));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_front_done, hipEventDisableTiming));
-            HIPCHK(h, hipEventCreateWithFlags(&h->ev_post_done, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_post_done[0], hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_post_done[1], hipEventDisableTiming));
         }
     }
     hipStream_t main_stream = h->stream;
     int* hold_flag = nullptr;
     if (pipelined) {
-        // the previous call's post-net still reads the shared mel / scratch the decoder writes
-        if (h->post_pending) HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_post_done, 0));
+        // the post-net of the call two back read the mel buffer this call's decoder writes; with a caller's
+        // mel buffer (possibly the same one every call) the previous call's post-net has to finish as well
+        if (h->post_pending[parity]) HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_post_done[parity], 0));
+        if (mel_out && h->post_pending[parity ^ 1])
+            HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_post_done[parity ^ 1], 0));
         if (h->reserve_cus > 0) {
             // reserve CUs for the front stream while the previous call's Griffin-Lim fills the rest
             hold_flag = h->hold_flags + (h->call_count++ & 1);
@@ -1489,8 +1503,8 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     }
     if ((rc = postnet_impl(h, mel, B, T, linear, magi, sp->ref_db, sp->max_db, sp->power))) return rc;
     if (pipelined) {
-        HIPCHK(h, hipEventRecord(h->ev_post_done, h->stream));
-        h->post_pending = true;
+        HIPCHK(h, hipEventRecord(h->ev_post_done[parity], h->stream));
+        h->post_pending[parity] = true;
     }
     return gl_run(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav, nullptr,
                   sp->peak_normalize != 0);

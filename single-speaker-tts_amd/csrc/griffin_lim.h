@@ -38,7 +38,7 @@ size_t gl_lds_bytes(const GlParams& p);
 int gl_max_item_frames(int win, int hop);
 // out[2*16*2*64]: set 0 = window[n] / n_fft, set 1 = set 0 * rwss at an interior frame; n = 2*(lane + 64 c) + e
 void gl_build_wlane(const float* window, const float* rwss, int win, int hop, int T, float* out);
-void gl_plan_items(GlParams& p, int n_cus);   // needs T, B, win, hop, ncol; sets C and the item classes
+void gl_plan_items(GlParams& p, int n_workers);   // needs T, B, win, hop, ncol; sets C and the item classes
 hipError_t gl_configure();
 hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int n_cus, int final_istft);
 hipError_t launch_gl_mse_reduce(hipStream_t s, const float* partial, int B, int nchunks, float denom, float* mse);

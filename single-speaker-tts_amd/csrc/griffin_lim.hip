@@ -41,6 +41,8 @@
 // overlap-add: 1.8x slower), GL_NO_ALTPRIO, GL_NO_UNROLL_A, E1S / E2S (exchange strides).
 #include "tts_common.h"
 #include "griffin_lim.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace tts {
 
@@ -626,35 +628,111 @@ int gl_max_item_frames(int win, int hop) {
     return best;
 }
 
-// Work-item schedule of one launch: per utterance T frames are cut into items of cls_C[k] frames, class by
-// class in descending size; items are numbered class-major with the utterance index fastest.
-void gl_plan_items(GlParams& p, int n_cus) {
+// Work-item schedule of one launch: per utterance the T frames are cut into items of cls_C[k] frames, class by
+// class in descending size; items are numbered class-major with the utterance index fastest, and the
+// persistent workgroups take them in that order.  The cut is chosen by simulating that list schedule on
+// `n_workers` workgroups with the measured item cost (gl_item_cost; only the ratios matter): big items amortise the fixed cost and the halo frames, small ones at the
+// end keep the last round of the launch full.
+namespace {
+struct GlCut { int nc; int c[GL_MAX_CLASSES]; int n[GL_MAX_CLASSES]; };
+
+// measured cost of one work item (us, MI355X, reference window / hop) against its owned frames
+double gl_item_cost(int frames) {
+    static const int xs[] = {0, 8, 16, 32, 40, 48, 56, 64};
+    static const double ys[] = {18.0, 24.0, 29.5, 45.0, 52.8, 61.0, 71.0, 81.0};
+    const int n = sizeof(xs) / sizeof(xs[0]);
+    if (frames >= xs[n - 1]) return ys[n - 1] + (frames - xs[n - 1]) * 1.25;
+    int i = 0;
+    while (i + 1 < n && frames > xs[i + 1]) ++i;
+    return ys[i] + (ys[i + 1] - ys[i]) * (frames - xs[i]) / (double)(xs[i + 1] - xs[i]);
+}
+
+double gl_simulate(const GlCut& cut, int B, int n_workers) {
+    std::vector<double> heap((size_t)n_workers, 0.0);   // min-heap of worker free times
+    auto cmp = [](double a, double b) { return a > b; };
+    for (int k = 0; k < cut.nc; ++k) {
+        const double cost = gl_item_cost(cut.c[k]);
+        const long long items = (long long)cut.n[k] * B;
+        for (long long i = 0; i < items; ++i) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            heap.back() += cost;
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+    }
+    return *std::max_element(heap.begin(), heap.end());
+}
+}  // namespace
+
+void gl_plan_items(GlParams& p, int n_workers) {
     const int cmax = gl_max_item_frames(p.win, p.hop);
     const int step = GL_NW;
-    // small batches: prefer more, smaller items so that every compute unit gets work
-    int C = cmax;
-    while (C - step >= step && (long long)p.B * ((p.T + C - 1) / C) < 2LL * n_cus) C -= step;
-    p.C = C;
-    int ncls = 0, t = 0, slot = 0, first = 0;
-    auto add = [&](int c, int n) {
-        if (n <= 0 || c <= 0) return;
-        p.cls_C[ncls] = c; p.cls_n[ncls] = n; p.cls_t0[ncls] = t; p.cls_slot0[ncls] = slot; p.cls_first[ncls] = first;
-        t += c * n; slot += n; first += n * p.B;
-        ++ncls;
-    };
-    const int n_big = p.T / C;
-    int rem = p.T - n_big * C;
-    add(C, n_big);
-    // the remainder goes last; a remainder of more than half an item is split in two so that the tail of
-    // the launch is made of small items
-    if (rem > C / 2 && rem >= 2 * step) {
-        const int half = ((rem / 2 + step - 1) / step) * step;
-        add(half, 1);
-        rem -= half;
+    GlCut best;
+    best.nc = 0;
+    bool forced = false;
+    if (const char* ov = getenv("SSTTS_GL_PLAN")) {   // experiments: "64x13,32x5,8x1" (must sum to T, sizes <= cmax)
+        int sum = 0;
+        GlCut cut;
+        cut.nc = 0;
+        bool good = true;
+        const char* q = ov;
+        while (*q && cut.nc < GL_MAX_CLASSES) {
+            char* end = nullptr;
+            const long c = strtol(q, &end, 10);
+            if (end == q || *end != 'x') { good = false; break; }
+            q = end + 1;
+            const long n = strtol(q, &end, 10);
+            if (end == q) { good = false; break; }
+            q = *end == ',' ? end + 1 : end;
+            if (c < 1 || c > cmax || n < 1) { good = false; break; }
+            cut.c[cut.nc] = (int)c; cut.n[cut.nc] = (int)n; sum += (int)(c * n); ++cut.nc;
+        }
+        if (good && *q == 0 && sum == p.T) { best = cut; forced = true; }
     }
-    add(rem, 1);
-    for (int k = ncls; k < GL_MAX_CLASSES; ++k) { p.cls_C[k] = 0; p.cls_n[k] = 0; p.cls_t0[k] = 0; p.cls_slot0[k] = 0; p.cls_first[k] = first; }
-    p.n_classes = ncls;
+    if (!forced) {
+        static std::map<std::vector<int>, GlCut> cache;   // the search is cheap but runs on every call otherwise
+        const std::vector<int> key = {p.T, p.B, p.win, p.hop, n_workers};
+        auto it = cache.find(key);
+        if (it != cache.end()) {
+            best = it->second;
+        } else {
+            double best_t = 1e300;
+            for (int cb = cmax; cb >= step; cb -= step) {
+                const int nb_max = p.T / cb;
+                for (int nb = nb_max; nb >= 0 && nb >= nb_max - 8; --nb) {
+                    const int rem = p.T - nb * cb;
+                    // the rest: a class of mid-size items (or none), then one item with what is left
+                    for (int cm = cb - step; cm >= 0; cm -= step) {
+                        GlCut cut;
+                        cut.nc = 0;
+                        if (nb > 0) { cut.c[cut.nc] = cb; cut.n[cut.nc] = nb; ++cut.nc; }
+                        int left = rem;
+                        if (cm > 0 && left >= cm) { cut.c[cut.nc] = cm; cut.n[cut.nc] = left / cm; ++cut.nc; left %= cm; }
+                        if (left > 0) {
+                            if (left > cmax || (cut.nc > 0 && left > cut.c[cut.nc - 1])) continue;   // descending sizes only
+                            cut.c[cut.nc] = left; cut.n[cut.nc] = 1; ++cut.nc;
+                        }
+                        if (cut.nc == 0) continue;
+                        const double t = gl_simulate(cut, p.B, n_workers);
+                        if (t < best_t) { best_t = t; best = cut; }
+                    }
+                }
+            }
+            cache[key] = best;
+        }
+    }
+    int t = 0, slot = 0, first = 0;
+    p.C = 0;
+    for (int k = 0; k < GL_MAX_CLASSES; ++k) {
+        const bool on = k < best.nc;
+        p.cls_C[k] = on ? best.c[k] : 0;
+        p.cls_n[k] = on ? best.n[k] : 0;
+        p.cls_t0[k] = t; p.cls_slot0[k] = slot; p.cls_first[k] = first;
+        if (on) {
+            if (best.c[k] > p.C) p.C = best.c[k];
+            t += best.c[k] * best.n[k]; slot += best.n[k]; first += best.n[k] * p.B;
+        }
+    }
+    p.n_classes = best.nc;
     p.n_items = first;
     p.slots_per_utt = slot;
 }
