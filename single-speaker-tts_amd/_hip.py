@@ -90,6 +90,7 @@ _PROTOTYPES = {
     'tts_profile_reset': (c_int, [c_void_p]),
     'tts_profile_get': (c_int, [c_void_p, c_char_p, POINTER(c_float), POINTER(c_int64)]),
     'tts_debug_workspace': (c_int, [c_void_p, c_char_p, POINTER(c_void_p), POINTER(c_size_t)]),
+    'tts_debug_hold': (c_int, [c_void_p, c_int, c_int, ctypes.c_double]),
 }
 
 _lib = None

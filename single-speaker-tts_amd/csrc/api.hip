@@ -1519,6 +1519,21 @@ int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* b
     return TTS_OK;
 }
 
+// Diagnostic: occupy `n_wgs` workgroup slots of `lds_kb` KB LDS each for `ms` milliseconds on a private
+// stream (to study how the other kernels behave on a partially occupied GPU).  Not part of the product path.
+int tts_debug_hold(tts_handle_t h, int n_wgs, int lds_kb, double ms) {
+    if (!h || n_wgs < 1 || lds_kb < 1 || lds_kb > 160) return TTS_ERR_INVALID;
+    static hipStream_t dbg = nullptr;
+    static int* never = nullptr;
+    if (!dbg) {
+        HIPCHK(h, hipStreamCreateWithFlags(&dbg, hipStreamNonBlocking));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&never), sizeof(int)));
+        HIPCHK(h, hipMemset(never, 0, sizeof(int)));
+    }
+    HIPCHK(h, launch_cu_hold(dbg, n_wgs, never, ms, lds_kb));
+    return TTS_OK;
+}
+
 int tts_profile_reset(tts_handle_t h) {
     if (!h) return TTS_ERR_INVALID;
     prof_collect(h);

@@ -26,9 +26,16 @@ __global__ __launch_bounds__(64) void cu_hold_kernel(const int* flag, unsigned l
     }
 }
 
-hipError_t launch_cu_hold(hipStream_t s, int n_cus, const int* flag, double timeout_ms) {
+hipError_t launch_cu_hold(hipStream_t s, int n_cus, const int* flag, double timeout_ms, int lds_kb) {
     const unsigned long long ticks = (unsigned long long)(timeout_ms * 1e5);
-    hipLaunchKernelGGL(cu_hold_kernel, dim3(n_cus), dim3(64), 64 * 1024, s, flag, ticks);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cu_hold_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(cu_hold_kernel, dim3(n_cus), dim3(64), (size_t)lds_kb * 1024, s, flag, ticks);
     return hipGetLastError();
 }
 

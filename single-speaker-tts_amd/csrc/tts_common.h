@@ -77,7 +77,7 @@ hipError_t launch_bigru(hipStream_t s, const float* xproj, int xld, const float*
 size_t bigru_wrec_floats(int H, int cudnn);
 
 // ----------------------------------------------------------------------------- CU reservation (reserve.hip)
-hipError_t launch_cu_hold(hipStream_t s, int n_cus, const int* flag, double timeout_ms);
+hipError_t launch_cu_hold(hipStream_t s, int n_cus, const int* flag, double timeout_ms, int lds_kb = 64);
 
 // ----------------------------------------------------------------------------- helpers
 struct DevBuf {
