@@ -194,6 +194,9 @@ int tts_profile_reset(tts_handle_t h);
 /* Test hook: device pointer and size of a named internal scratch buffer of the last call
  * ("enc.bank", "enc.p1", "post.xproj", ...); contents are only valid until the next call. */
 int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* bytes);
+/* Host-only: the Griffin-Lim work-item cut for T frames x B utterances on n_workers compute units.
+ * classes[8] = {frames, items per utterance} x 4 in execution order; returns the number of classes. */
+int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_workers, int* classes, int* max_item_frames);
 /* Diagnostic: keep n_wgs workgroup slots of lds_kb KB LDS busy for ms milliseconds on a private stream. */
 int tts_debug_hold(tts_handle_t h, int n_wgs, int lds_kb, double ms);
 int tts_profile_get(tts_handle_t h, const char* stage, float* ms_total, int64_t* launches);

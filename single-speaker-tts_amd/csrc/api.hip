@@ -1519,6 +1519,26 @@ int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* b
     return TTS_OK;
 }
 
+// Host-only view of the Griffin-Lim work-item planner (no GPU needed): classes[4][2] = {frames per item, items
+// per utterance} in execution order; returns the number of classes or a negative status.
+int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_workers, int* classes, int* max_item_frames) {
+    if (T < 1 || B < 1 || win_length < 2 || win_length > TTS_GL_NFFT || hop_length < 1 || n_workers < 1 || !classes)
+        return TTS_ERR_INVALID;
+    GlParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.T = T; p.B = B; p.win = win_length; p.hop = hop_length;
+    p.ncol = (win_length + hop_length - 1) / hop_length;
+    const int cmax = gl_max_item_frames(win_length, hop_length);
+    if (max_item_frames) *max_item_frames = cmax;
+    if (p.ncol > 8 || cmax < 1) return TTS_ERR_UNSUPPORTED;
+    gl_plan_items(p, n_workers);
+    for (int k = 0; k < GL_MAX_CLASSES; ++k) {
+        classes[2 * k] = p.cls_C[k];
+        classes[2 * k + 1] = p.cls_n[k];
+    }
+    return p.n_classes;
+}
+
 // Diagnostic: occupy `n_wgs` workgroup slots of `lds_kb` KB LDS each for `ms` milliseconds on a private
 // stream (to study how the other kernels behave on a partially occupied GPU).  Not part of the product path.
 int tts_debug_hold(tts_handle_t h, int n_wgs, int lds_kb, double ms) {

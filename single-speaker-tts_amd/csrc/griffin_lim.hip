@@ -14,31 +14,35 @@
 // aligned).  One frame's spectrum is a contiguous row, which is also how the network produces it
 // (B,T,F): the reference's (F,T) transpose exists only at the C ABI.
 //
-// One Griffin-Lim iteration is ONE kernel: a 512-thread workgroup owns a chunk of C = 32 frames of
-// one utterance.
-//   Phase A inverse-FFTs the chunk plus a halo of `ncol-1` frames either side (ncol = ceil(win/hop)
+// One Griffin-Lim iteration is ONE kernel of PERSISTENT workgroups (512 threads, one per compute unit) that
+// draw work items -- (utterance, first frame, frame count C <= 64) -- from a global counter.  For an item:
+//   Phase A inverse-FFTs the C frames plus a halo of `ncol-1` frames either side (ncol = ceil(win/hop)
 //   = 5) and overlap-adds them, window-weighted, into a time-domain buffer that lives only in LDS.
-//   Frame fa = r + ncol*wave is processed by `wave` in round r; frames of one round touch disjoint
-//   samples, and the only cross-wave hazard (wave w round r vs wave w+1 rounds < r) is ordered by
-//   per-wave progress flags in LDS, so there are no atomics, no workgroup barriers inside the
-//   phase, and the summation order of every sample is fixed (bit-reproducible).  The next round's
-//   spectrum row is prefetched into registers while the current frame's FFT runs.
-//   After the window-sum-square normalisation (loads hoisted above the barrier), phase B
-//   forward-FFTs the C owned frames straight from LDS (reflect padding at the utterance edges is an
+//   Wave w owns the R consecutive frames R*w .. R*w + R-1 and processes frame R*w + r in round r (R =
+//   max(ncol, ceil((C + 2 halo) / 8))); frames of one round touch disjoint samples, and the only cross-wave
+//   hazard (wave w round r vs wave w+1 rounds < r - (R - ncol)) is ordered by per-wave progress flags in
+//   LDS, so there are no atomics, no workgroup barriers inside the phase, and the summation order of every
+//   sample is fixed (bit-reproducible).  Round 0 stores instead of accumulating, so the buffer is never
+//   cleared.  The next round's spectrum row is prefetched into registers -- directly in the (k, 1024 - k)
+//   layout of the real-FFT split pass -- while the current frame's FFT runs.  The window-sum-square
+//   normalisation of librosa's istft is folded into the synthesis window (a per-sample table only for the
+//   frames at the utterance ends), so the signal is final when the overlap-add is.
+//   Phase B forward-FFTs the C owned frames straight from LDS (reflect padding at the utterance edges is an
 //   index map; frames handed out dynamically so both waves of a SIMD finish together) and stores
 //   the next estimate X = |S| * unit phasor.
 // The time-domain signal never goes to HBM; per bin and iteration the algorithmic traffic is
-// 8 B X in + 4 B |S| + 8 B X out.
+// 8 B X in + 4 B |S| + 8 B X out.  The cut of an utterance into items (big ones first, small ones to
+// balance the tail of the launch) is planned on the host: gl_plan_items.
 //
 // FFT: real 2048-point transforms as 1024-point complex FFTs with a split/merge pass.  One wave
-// per FFT, 16 points per lane: radix-16 in registers -> LDS transpose -> radix-4 -> LDS transpose
-// -> radix-16; twiddle tables in LDS, this lane's window samples (with the iFFT scale folded in)
-// in registers.  Index math validated against numpy in tests/test_host_logic.py
-// (test_fft_decomposition_emulation).
+// per FFT, 16 points per lane: radix-16 in registers -> 4x4 register/lane transpose (v_permlane16_swap /
+// v_permlane32_swap) -> radix-4 -> LDS transpose -> radix-16; all twiddles and this lane's window samples
+// (with the iFFT scale folded in) in registers.  Index math validated against numpy in
+// tests/test_host_logic.py (test_fft_decomposition_emulation).  This file is compiled with
+// -fno-slp-vectorize: packed f32 VALU ops are slower than the scalar pairs they replace on gfx950.
 //
-// Compile-time switches used by the tools/ micro-benchmarks only: GL_STAMPS (per-wave time stamps),
-// GL_ABL_NOZERO / GL_ABL_NONORM (timing ablations, wrong results), GL_OLA_ATOMIC (ds_add_f32
-// overlap-add: 1.8x slower), GL_NO_ALTPRIO, GL_NO_UNROLL_A, E1S / E2S (exchange strides).
+// Compile-time switches used by the tools/ micro-benchmarks only: GL_NO_ALTPRIO, GL_FFT_LDS_STAGE1 (first
+// exchange through LDS), GL_NO_STREAMING_HINT, E1S / E2S (exchange strides).
 #include "tts_common.h"
 #include "griffin_lim.h"
 #include <algorithm>

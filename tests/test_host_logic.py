@@ -157,3 +157,104 @@ def test_fft_decomposition_emulation():
     xx = np.empty(N)
     xx[0::2], xx[1::2] = z2.real, z2.imag
     assert np.abs(xx - np.fft.irfft(Xs, n=N)).max() < 1e-12
+
+
+def test_permlane_swap_transpose_emulation():
+    """The first FFT exchange is done in registers: swapping register-index bit 0 with lane bit 4
+    (v_permlane16_swap) and register-index bit 1 with lane bit 5 (v_permlane32_swap) must equal the LDS
+    transpose it replaced: new v[4 i + b] at lane (a, kq) = old v[4 i + kq] at lane (a, b)."""
+    lanes = np.arange(64)
+    old = np.arange(64 * 16).reshape(64, 16)                       # old[lane][reg] unique tags
+
+    def swap32(A, B):        # lanes 32-63 of A swap with lanes 0-31 of B
+        A2, B2 = A.copy(), B.copy()
+        A2[32:], B2[:32] = B[:32], A[32:]
+        return A2, B2
+
+    def swap16(A, B):        # odd rows (16 lanes) of A swap with even rows of B
+        A2, B2 = A.copy(), B.copy()
+        for row in (0, 2):
+            A2[16 * (row + 1):16 * (row + 2)] = B[16 * row:16 * (row + 1)]
+            B2[16 * row:16 * (row + 1)] = A[16 * (row + 1):16 * (row + 2)]
+        return A2, B2
+
+    v = [old[:, r].copy() for r in range(16)]
+    for i in range(4):
+        v[4 * i + 0], v[4 * i + 1] = swap16(v[4 * i + 0], v[4 * i + 1])
+        v[4 * i + 2], v[4 * i + 3] = swap16(v[4 * i + 2], v[4 * i + 3])
+        v[4 * i + 0], v[4 * i + 2] = swap32(v[4 * i + 0], v[4 * i + 2])
+        v[4 * i + 1], v[4 * i + 3] = swap32(v[4 * i + 1], v[4 * i + 3])
+    a, kq = lanes & 15, lanes >> 4
+    for i in range(4):
+        for b in range(4):
+            assert np.array_equal(v[4 * i + b], old[a + 16 * b, 4 * i + kq])
+
+
+def _gl_plan(T, B, win, hop, workers):
+    lib = pkg('_hip').load_library()
+    import ctypes
+    cls = (ctypes.c_int * 8)()
+    cmax = ctypes.c_int(0)
+    n = lib.tts_debug_gl_plan(T, B, win, hop, workers, cls, ctypes.byref(cmax))
+    assert n >= 1, n
+    return [(cls[2 * k], cls[2 * k + 1]) for k in range(n)], cmax.value
+
+
+@pytest.mark.parametrize('T,B,win,hop,workers', [
+    (1000, 64, 1102, 275, 256), (1000, 64, 1102, 275, 224), (1000, 1, 1102, 275, 256), (5, 2, 1102, 275, 256),
+    (37, 3, 1102, 275, 248), (1000, 512, 1102, 275, 256), (400, 16, 2048, 512, 256), (333, 7, 400, 160, 256),
+    (1000, 64, 551, 275, 224),
+])
+def test_griffin_lim_item_plan_covers_every_frame_once(T, B, win, hop, workers):
+    """Host planner of the persistent Griffin-Lim kernel: the item classes tile [0, T) exactly, sizes
+    descend (big items first) and never exceed what fits in LDS."""
+    classes, cmax = _gl_plan(T, B, win, hop, workers)
+    assert 1 <= len(classes) <= 4
+    assert sum(c * n for c, n in classes) == T
+    assert all(1 <= c <= cmax and n >= 1 for c, n in classes)
+    assert all(classes[i][0] >= classes[i + 1][0] for i in range(len(classes) - 1))
+    assert 1 <= cmax <= 64
+    # same inputs -> same cut (the waveform's summation order depends on it)
+    assert _gl_plan(T, B, win, hop, workers)[0] == classes
+
+
+@pytest.mark.parametrize('C,ncol', [(64, 5), (32, 5), (8, 5), (1, 5), (40, 5), (17, 3), (64, 2), (24, 8)])
+def test_overlap_add_round_schedule_is_race_free(C, ncol):
+    """Phase A of the Griffin-Lim kernel: wave w owns frames R w .. R w + R - 1 (round r = frame R w + r), R =
+    max(ncol, ceil(nA / 8)); frames fewer than ncol apart overlap.  Check on the frame level that (1) frames
+    of one round never overlap, (2) every overlapping pair of different waves is ordered by the flag rule
+    'wave w waits in round r until wave w+1 has finished r - (R - ncol) rounds', (3) frames more than one
+    wave apart never overlap, and (4) every sample region is initialised by exactly one round-0 store /
+    zero-fill before anything accumulates into it."""
+    NW, halo = 8, ncol - 1
+    nA = C + 2 * halo
+    R = max(ncol, -(-nA // NW))
+    frames = {(w, r): R * w + r for w in range(NW) for r in range(R)}
+    for (w, r), f in frames.items():
+        for (w2, r2), f2 in frames.items():
+            if (w, r) >= (w2, r2) or abs(f - f2) >= ncol:
+                continue                                             # not overlapping (or same pair twice)
+            if w == w2:
+                continue                                             # same wave: program order
+            assert r != r2                                           # (1)
+            assert abs(w - w2) == 1                                  # (3)
+            lo, hi = ((w, r), (w2, r2)) if w < w2 else ((w2, r2), (w, r))
+            need = lo[1] - (R - ncol)                                # rounds wave lo[0]+1 must have finished
+            assert need > 0 and hi[1] < need                         # (2): the upper wave's frame came first
+    # (4) in units of hop: wave w initialises [R w, R (w+1)) (the last wave up to the end of the buffer)
+    span_hops = nA - 1 + ncol
+    owner = np.full(span_hops, -1)
+    for w in range(NW):
+        lo = R * w
+        hi = span_hops if w == NW - 1 else min(R * (w + 1), span_hops)
+        assert np.all(owner[lo:hi] == -1)
+        owner[lo:hi] = w
+    assert np.all(owner >= 0)
+    for (w, r), f in frames.items():
+        if r == 0 or f >= nA:
+            continue
+        touched = owner[f:f + ncol]
+        for w2 in set(touched.tolist()):
+            if w2 == w:
+                continue                                             # own region: own round 0 came first
+            assert w2 == w + 1 and r - (R - ncol) >= 1               # neighbour's round 0 is awaited
