@@ -86,8 +86,8 @@ def _cpu_gl_job(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--pipeline', type=int, default=None, help='override the library default (stream pipelining)')
     ap.add_argument('--reserve-cus', type=int, default=None)

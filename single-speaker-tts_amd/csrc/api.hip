@@ -524,6 +524,14 @@ struct ProfScope {
 
 void prof_collect(tts_handle_t h) {
     sync_all(h);
+    if (!h->spans.empty() && getenv("SSTTS_TIMELINE")) {   // diagnostic: absolute stage times of every span
+        for (auto& s : h->spans) {
+            float t0 = 0.f, t1 = 0.f;
+            if (hipEventElapsedTime(&t0, h->spans[0].a, s.a) == hipSuccess &&
+                hipEventElapsedTime(&t1, h->spans[0].a, s.b) == hipSuccess)
+                fprintf(stderr, "timeline %-8s %9.3f -> %9.3f ms (%.3f)\n", kStageNames[s.stage], t0, t1, t1 - t0);
+        }
+    }
     for (auto& s : h->spans) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
