@@ -197,6 +197,9 @@ int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* b
 /* Host-only: the Griffin-Lim work-item cut for T frames x B utterances on n_workers compute units.
  * classes[8] = {frames, items per utterance} x 4 in execution order; returns the number of classes. */
 int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_workers, int* classes, int* max_item_frames);
+/* Diagnostic: one GEMM / conv1d launch on device buffers (A [M][Cin] rows of sequences of length T, Wt [N][ktaps*Cin]). */
+int tts_debug_gemm(tts_handle_t h, const float* A, const float* Wt, float* C, int M, int N, int Cin, int ktaps, int T,
+                   int pool);
 /* Diagnostic: keep n_wgs workgroup slots of lds_kb KB LDS busy for ms milliseconds on a private stream. */
 int tts_debug_hold(tts_handle_t h, int n_wgs, int lds_kb, double ms);
 int tts_profile_get(tts_handle_t h, const char* stage, float* ms_total, int64_t* launches);

@@ -604,12 +604,20 @@ int run_cbhg(tts_handle_t h, const CbhgWeights& w, const char* tag, const float*
         HIPCHK(h, launch_gemm(h->stream, b, ng));
         ++*launches;
     }
-    // projection 1: max-pool(2,1,SAME) fused into the loader, conv3 + relu + BN
+    // projection 1: max-pool(2,1,SAME) fused into the loader, conv3 + relu + BN.  With few output tiles (the
+    // encoder: 75 x 1 for 32 x 150 tokens, K = 6144) the K range is split over several workgroups per tile.
     {
         GemmGroup g = conv_group(bank, NB * NF, 3, T, w.proj_wt[0], w.proj_b[0], w.proj_scale[0], w.proj_shift[0], p1,
                                  w.proj_filters[0], 0, M, w.proj_filters[0], ACT_RELU, 1);
-        int rc = run_single(h, g);
-        if (rc) return rc;
+        const int slices = gemm_splitk_slices(g.K);
+        if (slices > 1) {
+            WS(h, (t + ".splitk").c_str(), float, (size_t)slices * M * g.N, part);
+            HIPCHK(h, launch_gemm_splitk(h->stream, g, slices, part));
+            ++*launches;
+        } else {
+            int rc = run_single(h, g);
+            if (rc) return rc;
+        }
         ++*launches;
     }
     // projection 2: conv3 + BN (linear) + residual with the CBHG input
@@ -1292,7 +1300,8 @@ static int postnet_impl(tts_handle_t h, const float* mel, int B, int T, float* l
                         float max_db, float power) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if (!mel || !linear || B < 1 || T < 1) return fail(h, TTS_ERR_INVALID, "postnet_forward: bad arguments");
+    // linear may be null when only the de-normalised magnitude is wanted (tts_synthesize without linear_out)
+    if (!mel || (!linear && !mag) || B < 1 || T < 1) return fail(h, TTS_ERR_INVALID, "postnet_forward: bad arguments");
     const tts_config_t& c = h->cfg;
     const int M = B * T, H2 = 2 * c.n_gru_units, F = 1 + c.n_fft / 2;
     WS(h, "post.gru", float, (size_t)M * H2, gru);
@@ -1315,6 +1324,7 @@ static int postnet_impl(tts_handle_t h, const float* mel, int B, int T, float* l
 }
 
 int tts_postnet_forward(tts_handle_t h, const float* mel, int B, int T, float* linear) {
+    if (!linear) return fail(h, TTS_ERR_INVALID, "postnet_forward: bad arguments");
     return postnet_impl(h, mel, B, T, linear, nullptr, 0.f, 0.f, 1.f);
 }
 
@@ -1459,11 +1469,8 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         WS(h, "syn.mel1", float, (size_t)B * T * c.n_mels, melb1);
         mel = parity ? melb1 : melb0;
     }
-    float* linear = linear_out;
-    if (!linear) {
-        WS(h, "syn.linear", float, (size_t)B * T * F, linb);
-        linear = linb;
-    }
+    float* linear = linear_out;   // null: the final Dense emits only the de-normalised magnitude (rows of 1028 floats;
+                                  // the 1025-float rows of the linear spectrogram cannot be written in whole cache lines)
     WS(h, "gl.mag", float, (size_t)B * T * FP, magi);
     const bool pipelined = h->pipeline && h->own_stream;   // inputs on a borrowed stream may still be in flight
     if (pipelined) {
@@ -1545,6 +1552,14 @@ int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_worker
         classes[2 * k + 1] = p.cls_n[k];
     }
     return p.n_classes;
+}
+
+// Diagnostic: one launch of the GEMM kernel, C[M][N] = conv(A)[M][ktaps*Cin] . Wt[N][K]^T (device pointers),
+// optionally with the max-pool loader; for tools/gemm_bench.py.
+int tts_debug_gemm(tts_handle_t h, const float* A, const float* Wt, float* C, int M, int N, int Cin, int ktaps, int T,
+                   int pool) {
+    if (!h || !A || !Wt || !C || M < 1 || N < 1 || Cin < 4 || (Cin & 3) || ktaps < 1 || T < 1 || M % T) return TTS_ERR_INVALID;
+    return run_single(h, conv_group(A, Cin, ktaps, T, Wt, nullptr, nullptr, nullptr, C, N, 0, M, N, ACT_NONE, pool));
 }
 
 // Diagnostic: occupy `n_wgs` workgroup slots of `lds_kb` KB LDS each for `ms` milliseconds on a private

@@ -13,6 +13,7 @@
 // The k index inside a tile is permuted (lane half h of MFMA step (q,j) uses k = 8q+4h+j) so
 // that each lane fetches its 4 consecutive k values with one ds_read_b128 for both operands.
 #include "tts_common.h"
+#include <cstring>
 
 namespace tts {
 
@@ -32,9 +33,17 @@ template <bool DENORM>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
     const GemmGroup& g = batch.g[blockIdx.z];
     const int M = g.M, N = g.N, K = g.K;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    if (n0 >= N) return;
+    // Workgroup -> tile map.  Workgroups are dealt round-robin over the 8 XCDs in launch order (x fastest),
+    // each XCD has its own L2, and all N-blocks of one M-block read the same rows of A: so the N-blocks of an
+    // M-block get consecutive slots of ONE XCD (launch ids lin, lin + 8, ...), and the activation rows are
+    // fetched from HBM once instead of once per N-block.
+    const int nyb = gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, seq = lin >> 3;
+    const int m_blk = (seq / nyb) * 8 + xcd;
+    const int m0 = m_blk * BM;
+    const int n0 = (seq % nyb) * BN;
+    if (n0 >= N || m0 >= M) return;
 
     __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
@@ -71,8 +80,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
     }
 
     float4 ra[4], rb[4];
+    // k order of a convolution whose channel count is a multiple of the tile depth: channel chunk outer, tap
+    // inner, so that the k+1 shifted copies of one activation chunk are loaded in consecutive tiles (they hit
+    // in L1 / L2) instead of Cin/BK tiles apart.  The weight tile follows the same map.
+    const int ktaps = K / g.Cin;
+    const bool tap_inner = ktaps > 1 && (g.Cin % BK) == 0;
     auto load_tile = [&](int kt) {
-        const int kk = kt + 4 * kq;
+        int kbase = kt;
+        if (tap_inner) {
+            const int it = kt / BK;
+            kbase = (it % ktaps) * g.Cin + (it / ktaps) * BK;
+        }
+        const int kk = kbase + 4 * kq;
         const bool kin = kk < K;
         const int tap = kk / g.Cin;  // all four floats share the tap (Cin % 4 == 0)
 #pragma unroll
@@ -106,11 +125,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    for (int kt = 0; kt < K; kt += BK) {
+    const int k_begin = g.kt1 > 0 ? g.kt0 : 0;
+    const int k_end = g.kt1 > 0 ? g.kt1 : K;
+    load_tile(k_begin);
+    for (int kt = k_begin; kt < k_end; kt += BK) {
         store_tile();
         __syncthreads();
-        if (kt + BK < K) load_tile(kt + BK);
+        if (kt + BK < k_end) load_tile(kt + BK);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 a[2], b[2];
@@ -183,7 +204,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
                     float v = apply_act(acc[tm][tn][r] + bv, g.act);
                     v = v * sc + sh;
                     if (g.R) v += g.R[(size_t)m * g.ldr + n];
-                    g.C[(size_t)m * g.ldc + g.coff + n] = v;
+                    if (!DENORM || g.C) g.C[(size_t)m * g.ldc + g.coff + n] = v;
                     if (DENORM && g.C2) g.C2[(size_t)m * g.ldc2 + n] = denorm_pow(v, g.d_ref, g.d_range, g.d_pow);
                 }
             }
@@ -193,11 +214,52 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
 hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups) {
     int max_n = 0;
     for (int i = 0; i < n_groups; ++i) max_n = b.g[i].N > max_n ? b.g[i].N : max_n;
-    dim3 grid((b.g[0].M + BM - 1) / BM, (max_n + BN - 1) / BN, n_groups);
+    const int m_blocks = (b.g[0].M + BM - 1) / BM;
+    dim3 grid((m_blocks + 7) / 8 * 8, (max_n + BN - 1) / BN, n_groups);   // M-blocks padded to the XCD count (see the tile map)
     bool denorm = false;
     for (int i = 0; i < n_groups; ++i) denorm = denorm || b.g[i].C2 != nullptr;
     if (denorm) hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, s, b);
     else hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+
+// out[m][n] = epilogue( sum_s partial[s][m][n] ), slices added in order (fixed summation order)
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int slices, GemmGroup g) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)g.M * g.N;
+    if (i >= total) return;
+    const int m = (int)(i / g.N), n = (int)(i % g.N);
+    float v = 0.f;
+    for (int s = 0; s < slices; ++s) v += partial[(size_t)s * total + i];
+    v = apply_act(v + (g.bias ? g.bias[n] : 0.f), g.act);
+    if (g.scale) v = v * g.scale[n] + g.shift[n];
+    if (g.R) v += g.R[(size_t)m * g.ldr + n];
+    g.C[(size_t)m * g.ldc + g.coff + n] = v;
+}
+
+// The slice count depends on the layer's K only -- never on the batch -- so that an utterance's result does
+// not depend on how many others share the batch (the summation order over k is part of the result).
+int gemm_splitk_slices(int K) { return K >= 4096 ? 4 : 1; }
+
+hipError_t launch_gemm_splitk(hipStream_t s, const GemmGroup& g, int slices, float* partial) {
+    if (slices < 2 || slices > TTS_GEMM_MAX_GROUPS || g.epi != EPI_STD || g.C2) return hipErrorInvalidValue;
+    GemmBatch b;
+    memset(&b, 0, sizeof(b));
+    const int k_tiles = (g.K + BK - 1) / BK;
+    for (int i = 0; i < slices; ++i) {
+        GemmGroup p = g;
+        p.bias = nullptr; p.scale = nullptr; p.shift = nullptr; p.R = nullptr; p.act = ACT_NONE;
+        p.C = partial + (size_t)i * g.M * g.N;
+        p.ldc = g.N; p.coff = 0;
+        p.kt0 = (int)((long long)k_tiles * i / slices) * BK;
+        p.kt1 = (int)((long long)k_tiles * (i + 1) / slices) * BK;
+        if (p.kt1 > g.K) p.kt1 = g.K;
+        b.g[i] = p;
+    }
+    hipError_t e = launch_gemm(s, b, slices);
+    if (e != hipSuccess) return e;
+    const size_t total = (size_t)g.M * g.N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, slices, g);
     return hipGetLastError();
 }
 

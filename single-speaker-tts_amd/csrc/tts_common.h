@@ -60,6 +60,9 @@ struct GemmGroup {
     float* C2;
     int ldc2, N2;
     float d_ref, d_range, d_pow;
+    // split-K: this group accumulates only the k tiles [kt0, kt1) (multiples of the tile depth 32; 0, 0 = all of
+    // K) and is launched with a plain epilogue into a partial-sum buffer; see launch_gemm_splitk
+    int kt0, kt1;
 };
 #define TTS_GEMM_MAX_GROUPS 16
 struct GemmBatch {
@@ -67,6 +70,11 @@ struct GemmBatch {
 };
 // Launches one grouped GEMM; all groups must share M (grid.x) and have N <= max_n.
 hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups);
+// One GEMM whose K range is cut into `slices` parts computed by separate workgroups (for problems with too
+// few output tiles to fill the GPU); `partial` holds slices*M*N floats.  The partial sums are added in slice
+// order and the group's epilogue (bias, activation, affine, residual) is applied by a second small kernel.
+hipError_t launch_gemm_splitk(hipStream_t s, const GemmGroup& g, int slices, float* partial);
+int gemm_splitk_slices(int K);   // 1 = not worth splitting; a function of the layer only, never of the batch
 
 // ----------------------------------------------------------------------------- bi-GRU (gru.hip)
 // xproj [B*T][xld]: per direction d a block of 3*H input projections (bias included) at column
