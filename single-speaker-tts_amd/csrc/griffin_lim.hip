@@ -315,6 +315,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     __syncthreads();
     int item = __builtin_amdgcn_readfirstlane(ctrl[CT_NEXT_ITEM]);   // wave-uniform: keep it (and all it decodes to) in SGPRs
 
+    float warm = 0.f, warm_acc = 0.f;   // see the end of the loop body
     while (item < p.n_items) {
         // ---------------- decode the work item (wave-uniform scalar code)
         int k = 0;
@@ -609,9 +610,32 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 }
             }
         }
+        // Warm the caches for the next item: one load per lane, each from a different 128-byte line of the
+        // spectrum row this wave will need first (its round-0 frame), so that the real loads at the top of the
+        // next item find the row in L2 instead of waiting for HBM with nothing else to run.  The value is only
+        // summed into a dummy, much later.
+        warm_acc += warm;
+#ifndef GL_NO_WARM
+        if (next_item < p.n_items) {
+            int k2 = 0;
+#pragma unroll
+            for (int q = 1; q < GL_MAX_CLASSES; ++q)
+                if (q < p.n_classes && next_item >= p.cls_first[q]) k2 = q;
+            const int C2 = p.cls_C[k2];
+            const int rel2 = next_item - p.cls_first[k2];
+            const int t02 = p.cls_t0[k2] + (rel2 / p.B) * C2;
+            const int nA2 = C2 + 2 * halo;
+            const int Rr2 = (nA2 + GL_NW - 1) / GL_NW;
+            int tf2 = t02 - halo + (Rr2 > ncol ? Rr2 : ncol) * wave;
+            tf2 = tf2 < 0 ? 0 : (tf2 >= p.T ? p.T - 1 : tf2);
+            const float* row2 = reinterpret_cast<const float*>(p.phase_in + ((size_t)(rel2 % p.B) * p.T + tf2) * p.FP);
+            warm = row2[32 * lane];   // 64 lanes x 128 B = the first 8 KB of the 8224-byte row
+        }
+#endif
         __syncthreads();   // everyone is done with the signal buffer: the next item may overwrite it
         item = next_item;
     }
+    if (warm_acc == 1.2345e30f) ctrl[CT_WORDS - 1] = 1;   // keeps the warming loads alive; never true in practice
 #undef GL_LOAD_FRAME
 #undef GL_LOAD_WINDOW
 }
