@@ -91,6 +91,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--pipeline', type=int, default=None, help='override the library default (stream pipelining)')
     ap.add_argument('--reserve-cus', type=int, default=None)
+    ap.add_argument('--hold-lds-kb', type=int, default=None)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -134,6 +135,8 @@ def main():
         eng.set_option('pipeline', args.pipeline)
     if args.reserve_cus is not None:
         eng.set_option('reserve_cus', args.reserve_cus)
+    if args.hold_lds_kb is not None:
+        eng.set_option('hold_lds_kb', args.hold_lds_kb)
 
     # ---- this rank's shard of the synthetic batch, resident in HBM
     lo, hi = shard.shard_range(world * B_PER_GPU, world, rank)

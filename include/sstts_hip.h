@@ -90,7 +90,8 @@ int tts_set_stream(tts_handle_t h, void* hip_stream);
  * the decoder loop of a call on a second stream so that they overlap the Griffin-Lim iterations of
  * the PREVIOUS call still in flight; only while the library owns its stream, and inputs must be
  * complete when the call is made), "reserve_cus" (default 32: compute units kept free of
- * Griffin-Lim workgroups for that second stream, 0 = none). */
+ * Griffin-Lim workgroups for that second stream, 0 = none), "hold_lds_kb" (default 64: LDS one sleeper workgroup
+ * of that reservation allocates). */
 int tts_set_option(tts_handle_t h, const char* key, int value);
 int tts_synchronize(tts_handle_t h);
 

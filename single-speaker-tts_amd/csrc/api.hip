@@ -66,6 +66,7 @@ struct tts_handle_s {
     // `front` while post-net + Griffin-Lim (throughput bound) of call k run on `stream`.
     int pipeline = 1;      // on while the library owns its stream (see tts_synthesize); ~9 % on MI355X
     int reserve_cus = 32;  // CUs held for the front stream by LDS-hogging sleeper workgroups (reserve.hip)
+    int hold_lds_kb = 64;  // LDS of one sleeper: > 80 KB guarantees one sleeper per CU
     hipStream_t aux = nullptr;      // stream the sleepers run on
     int* hold_flags = nullptr;      // two flag words, alternating per call
     hipEvent_t ev_aux = nullptr;
@@ -984,6 +985,9 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     else if (!std::strcmp(key, "profile")) h->profile = value;
     else if (!std::strcmp(key, "reserve_cus")) {
         h->reserve_cus = value;
+    } else if (!std::strcmp(key, "hold_lds_kb")) {
+        if (value < 1 || value > 160) return fail(h, TTS_ERR_INVALID, "hold_lds_kb must be 1..160");
+        h->hold_lds_kb = value;
     } else if (!std::strcmp(key, "pipeline")) {
         int rc = sync_all(h);
         if (rc) return rc;
@@ -1499,7 +1503,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
             hold_flag = h->hold_flags + (h->call_count++ & 1);
             HIPCHK(h, hipMemsetAsync(hold_flag, 0, sizeof(int), h->aux));
             HIPCHK(h, hipEventRecord(h->ev_aux, h->aux));
-            HIPCHK(h, launch_cu_hold(h->aux, h->reserve_cus, hold_flag, 100.0));
+            HIPCHK(h, launch_cu_hold(h->aux, h->reserve_cus, hold_flag, 100.0, h->hold_lds_kb));
             HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_aux, 0));
         }
         h->stream = h->front;
