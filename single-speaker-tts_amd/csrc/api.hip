@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -1572,6 +1573,8 @@ int tts_debug_hold(tts_handle_t h, int n_wgs, int lds_kb, double ms) {
     if (!h || n_wgs < 1 || lds_kb < 1 || lds_kb > 160) return TTS_ERR_INVALID;
     static hipStream_t dbg = nullptr;
     static int* never = nullptr;
+    static std::mutex dbg_mutex;
+    std::lock_guard<std::mutex> lock(dbg_mutex);
     if (!dbg) {
         HIPCHK(h, hipStreamCreateWithFlags(&dbg, hipStreamNonBlocking));
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&never), sizeof(int)));

@@ -46,6 +46,7 @@
 #include "tts_common.h"
 #include "griffin_lim.h"
 #include <algorithm>
+#include <mutex>
 #include <cstdlib>
 
 namespace tts {
@@ -740,6 +741,8 @@ void gl_plan_items(GlParams& p, int n_workers) {
     }
     if (!forced) {
         static std::map<std::vector<int>, GlCut> cache;   // the search is cheap but runs on every call otherwise
+        static std::mutex cache_mutex;                     // handles of different threads share the cache
+        std::lock_guard<std::mutex> lock(cache_mutex);
         const std::vector<int> key = {p.T, p.B, p.win, p.hop, n_workers};
         auto it = cache.find(key);
         if (it != cache.end()) {
@@ -892,13 +895,13 @@ __global__ __launch_bounds__(GL_THREADS) void stft_kernel(const float* __restric
 
 hipError_t launch_stft(hipStream_t s, const float* wav, int B, int n, int Tf, const float* window, int win, int hop,
                        const float2* tw1024, const float2* tw2048, float2* out, int FP) {
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static std::once_flag once;
+    static hipError_t attr_status = hipSuccess;
+    std::call_once(once, [] {
+        attr_status = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_status != hipSuccess) return attr_status;
     const size_t lds = (size_t)(GL_NW * EX_CPLX + 1024 + 15 * 64) * sizeof(cf) + (size_t)((win + 3) & ~3) * sizeof(float);
     dim3 grid((Tf + GL_NW - 1) / GL_NW, B);
     hipLaunchKernelGGL(stft_kernel, grid, dim3(GL_THREADS), lds, s, wav, n, Tf, window, win, hop, tw1024, tw2048, out, FP);
