@@ -1539,8 +1539,9 @@ int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* b
     return TTS_OK;
 }
 
-// Host-only view of the Griffin-Lim work-item planner (no GPU needed): classes[4][2] = {frames per item, items
-// per utterance} in execution order; returns the number of classes or a negative status.
+// Host-only view of the Griffin-Lim work-item planner (no GPU needed): classes[4][2] = {frames per run, runs
+// per utterance} in execution order, *max_item_frames = the chunk size the runs are processed in; returns the
+// number of classes or a negative status.
 int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_workers, int* classes, int* max_item_frames) {
     if (T < 1 || B < 1 || win_length < 2 || win_length > TTS_GL_NFFT || hop_length < 1 || n_workers < 1 || !classes)
         return TTS_ERR_INVALID;
@@ -1549,9 +1550,9 @@ int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_worker
     p.T = T; p.B = B; p.win = win_length; p.hop = hop_length;
     p.ncol = (win_length + hop_length - 1) / hop_length;
     const int cmax = gl_max_item_frames(win_length, hop_length);
-    if (max_item_frames) *max_item_frames = cmax;
     if (p.ncol > 8 || cmax < 1) return TTS_ERR_UNSUPPORTED;
     gl_plan_items(p, n_workers);
+    if (max_item_frames) *max_item_frames = p.chunk;
     for (int k = 0; k < GL_MAX_CLASSES; ++k) {
         classes[2 * k] = p.cls_C[k];
         classes[2 * k + 1] = p.cls_n[k];

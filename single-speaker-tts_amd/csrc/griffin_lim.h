@@ -23,14 +23,17 @@ struct GlParams {
     const float2* tables;    // [tw2048 (1024) | W1024^{lane*k2} as [k2-1][lane] (15*64)]: per-lane twiddles, coalesced
     int T, FP, win, hop;
     int B;                   // utterances
-    int C;                   // largest item (frames owned per work item): sizes the LDS signal buffer
+    int C;                   // = chunk: frames owned per chunk; sizes the LDS signal buffer
+    int chunk;               // work items (runs) are processed in chunks of this many frames
     int ncol;                // ceil(win / hop): overlap-add colouring rounds, halo = ncol - 1
-    // work items of a launch (gl_plan_items): class k cuts cls_n[k] items of cls_C[k] frames out of every
-    // utterance, starting at frame cls_t0[k]; item ids are class-major, utterance index fastest:
-    // id = cls_first[k] + j * B + b  <->  utterance b, frames [cls_t0[k] + j C, + C), slot cls_slot0[k] + j
+    // work items of a launch (gl_plan_items): class k cuts cls_n[k] RUNS of cls_C[k] consecutive frames out of
+    // every utterance, starting at frame cls_t0[k]; item ids are class-major, utterance index fastest:
+    // id = cls_first[k] + j * B + b  <->  utterance b, frames [cls_t0[k] + j L, + L), L = cls_C[k].  A run is
+    // processed in cls_chunks[k] chunks of `chunk` frames (the last one shorter); chunk q of the run has the
+    // per-utterance ordinal (slot) cls_slot0[k] + j * cls_chunks[k] + q.
     int n_classes, n_items, slots_per_utt;
     int cls_C[GL_MAX_CLASSES], cls_n[GL_MAX_CLASSES], cls_t0[GL_MAX_CLASSES], cls_slot0[GL_MAX_CLASSES],
-        cls_first[GL_MAX_CLASSES];
+        cls_first[GL_MAX_CLASSES], cls_chunks[GL_MAX_CLASSES];
     unsigned* work_counter;  // zeroed counter of THIS launch: the persistent workgroups draw item ids from it
 };
 

@@ -15,7 +15,9 @@
 // (B,T,F): the reference's (F,T) transpose exists only at the C ABI.
 //
 // One Griffin-Lim iteration is ONE kernel of PERSISTENT workgroups (512 threads, one per compute unit) that
-// draw work items -- (utterance, first frame, frame count C <= 64) -- from a global counter.  For an item:
+// draw work items from a global counter.  An item is a RUN of consecutive frames of one utterance, walked
+// in chunks of C <= 64 frames; the overlap-added signal of the frames two consecutive chunks share is carried
+// over in LDS, so only the first chunk of a run transforms halo frames.  For a chunk:
 //   Phase A inverse-FFTs the C frames plus a halo of `ncol-1` frames either side (ncol = ceil(win/hop)
 //   = 5) and overlap-adds them, window-weighted, into a time-domain buffer that lives only in LDS.
 //   Wave w owns the R consecutive frames R*w .. R*w + R-1 and processes frame R*w + r in round r (R =
@@ -31,8 +33,8 @@
 //   index map; frames handed out dynamically so both waves of a SIMD finish together) and stores
 //   the next estimate X = |S| * unit phasor.
 // The time-domain signal never goes to HBM; per bin and iteration the algorithmic traffic is
-// 8 B X in + 4 B |S| + 8 B X out.  The cut of an utterance into items (big ones first, small ones to
-// balance the tail of the launch) is planned on the host: gl_plan_items.
+// 8 B X in + 4 B |S| + 8 B X out.  The cut of an utterance into runs (as many as divide evenly over the
+// compute units actually available) is planned on the host: gl_plan_items.
 //
 // FFT: real 2048-point transforms as 1024-point complex FFTs with a split/merge pass.  One wave
 // per FFT, 16 points per lane: radix-16 in registers -> 4x4 register/lane transpose (v_permlane16_swap /
@@ -317,29 +319,39 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     int item = __builtin_amdgcn_readfirstlane(ctrl[CT_NEXT_ITEM]);   // wave-uniform: keep it (and all it decodes to) in SGPRs
 
     float warm = 0.f, warm_acc = 0.f;   // see the end of the loop body
+    const int carry_len = (2 * halo - 1) * hop + win;   // samples that consecutive chunks of a run share
     while (item < p.n_items) {
-        // ---------------- decode the work item (wave-uniform scalar code)
+        // ---------------- decode the work item (wave-uniform scalar code): a RUN of consecutive frames of one
+        // utterance, processed in chunks of p.chunk frames.  The first chunk inverse-transforms its `halo`
+        // neighbour frames either side; every further chunk inherits the overlap-added signal of the frames
+        // it shares with its predecessor (the buffer is shifted), so inside a run no frame is transformed twice.
         int k = 0;
 #pragma unroll
         for (int q = 1; q < GL_MAX_CLASSES; ++q)
             if (q < p.n_classes && item >= p.cls_first[q]) k = q;
-        const int C = p.cls_C[k];
+        const int run_len = p.cls_C[k];
         const int rel = item - p.cls_first[k];
         const int b = rel % p.B;
         const int jc = rel / p.B;
-        const int t0 = p.cls_t0[k] + jc * C;
-        const int slot = p.cls_slot0[k] + jc;          // ordinal of the item inside its utterance
-        const int nA = C + 2 * halo;                   // frames inverse-transformed: owned + halo either side
-        const int Rr = (nA + GL_NW - 1) / GL_NW;
-        const int R = Rr > ncol ? Rr : ncol;           // overlap-add rounds; wave w owns frames [R w, R w + R)
-        const int span = (nA - 1) * hop + win;
+        const int run_t0 = p.cls_t0[k] + jc * run_len;
+        const int slot0 = p.cls_slot0[k] + jc * p.cls_chunks[k];   // ordinal of the run's first chunk in its utterance
         const float* magb = p.mag + (size_t)b * p.T * p.FP;
         const cf* phb = p.phase_in + (size_t)b * p.T * p.FP;
         unsigned next_item_reg = 0;
-        if (tid == 0) {
-            next_item_reg = atomicAdd(p.work_counter, 1u);   // consumed before the barrier that ends phase A
-            ctrl[CT_BNEXT] = 0;                              // phase B of the previous item is over
-        }
+        if (tid == 0) next_item_reg = atomicAdd(p.work_counter, 1u);   // consumed before the first barrier below
+        int next_item = p.n_items;
+
+      for (int cq = 0, t0 = run_t0; t0 < run_t0 + run_len; ++cq) {
+        const int left = run_t0 + run_len - t0;
+        const int C = left < p.chunk ? left : p.chunk;   // frames owned by this chunk
+        const bool cont = cq > 0;                        // the signal of the shared frames is already in the buffer
+        const int fa0 = cont ? 2 * halo : 0;             // first frame (buffer-relative) still to be transformed
+        const int slot = slot0 + cq;
+        const int nA = C + 2 * halo;                     // frames the buffer spans: owned + halo either side
+        const int Rr = (nA - fa0 + GL_NW - 1) / GL_NW;
+        const int R = Rr > ncol ? Rr : ncol;             // overlap-add rounds; wave w owns frames [fa0 + R w, + R)
+        const int span = (nA - 1) * hop + win;
+        if (tid == 0) ctrl[CT_BNEXT] = 0;                // phase B of the previous chunk is over
 
         // Prefetch registers for one frame's spectrum row, already in the layout the split pass wants:
         // gk[j] = X[lane + 64 j] and gm[j] = X[MH - (lane + 64 j)] (the mirrored bins; lane 0 / j 0 is the
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gk[j_] = prow_[64 * j_];                  \
         _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gm[j_] = mrow_[-64 * j_];                 \
     }
-        GL_LOAD_FRAME(R * wave)
+        GL_LOAD_FRAME(fa0 + R * wave)
         GL_LOAD_WINDOW(1)
 
         // ---------------- phase A: inverse FFT + windowed overlap-add into LDS
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
 #ifndef GL_NO_ALTPRIO
             if ((r + (wave >= GL_NW / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
-            const int fa = r + R * wave;
+            const int fa = fa0 + r + R * wave;
             const int tf = t0 - halo + fa;
             const bool ok = fa < nA && tf >= 0 && tf < p.T;
             cf v[16];
@@ -430,17 +442,31 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 const int lo = fa * hop;
                 const int hi_w = (fa + R) * hop;
                 const int hi = (wave == GL_NW - 1 || hi_w > span) ? span : hi_w;
-                int zlo = lo;
-                if (fa < nA) {
+                if (cont && wave == 0) {
+                    // continuing chunk: [0, carry_len) holds the inherited signal, which reaches into this
+                    // wave's region only (R >= ncol): clear the rest of the region, then accumulate
+                    for (int i = carry_len + lane; i < hi; i += 64) sig[i] = 0.f;
+                    if (ok) {
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        const int nw0 = 2 * (lane + 64 * c) - wpad, nw1 = nw0 + 1;
-                        if (nw0 >= 0 && nw0 < win) sf[nw0] = v[c].x;
-                        if (nw1 >= 0 && nw1 < win) sf[nw1] = v[c].y;
+                        for (int c = 0; c < 16; ++c) {
+                            const int nw0 = 2 * (lane + 64 * c) - wpad, nw1 = nw0 + 1;
+                            if (nw0 >= 0 && nw0 < win) sf[nw0] += v[c].x;
+                            if (nw1 >= 0 && nw1 < win) sf[nw1] += v[c].y;
+                        }
                     }
-                    zlo = lo + win;
+                } else {
+                    int zlo = lo;
+                    if (fa < nA) {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            const int nw0 = 2 * (lane + 64 * c) - wpad, nw1 = nw0 + 1;
+                            if (nw0 >= 0 && nw0 < win) sf[nw0] = v[c].x;
+                            if (nw1 >= 0 && nw1 < win) sf[nw1] = v[c].y;
+                        }
+                        zlo = lo + win;
+                    }
+                    for (int i = zlo + lane; i < hi; i += 64) sig[i] = 0.f;
                 }
-                for (int i = zlo + lane; i < hi; i += 64) sig[i] = 0.f;
             } else if (ok) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
@@ -452,9 +478,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             asm volatile("" ::: "memory");
             if (lane == 0) *reinterpret_cast<volatile int*>(ctrl + CT_FLAGS + wave) = r + 1;
         }
-        if (tid == 0) ctrl[CT_NEXT_ITEM] = (int)next_item_reg;
+        if (tid == 0 && cq == 0) ctrl[CT_NEXT_ITEM] = (int)next_item_reg;
         __syncthreads();   // all overlap-adds done (the signal is final), next item published
-        const int next_item = __builtin_amdgcn_readfirstlane(ctrl[CT_NEXT_ITEM]);
+        if (cq == 0) next_item = __builtin_amdgcn_readfirstlane(ctrl[CT_NEXT_ITEM]);
         if (tid < GL_NW) ctrl[CT_FLAGS + tid] = 0;   // nobody looks at the phase-A flags before the next item
         const int ybase = (t0 - halo) * hop + wpad - MH;   // trimmed-signal index of sig[0]
 
@@ -611,29 +637,61 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 }
             }
         }
-        // Warm the caches for the next item: one load per lane, each from a different 128-byte line of the
-        // spectrum row this wave will need first (its round-0 frame), so that the real loads at the top of the
-        // next item find the row in L2 instead of waiting for HBM with nothing else to run.  The value is only
-        // summed into a dummy, much later.
+        // Warm the caches for what comes next (the next chunk of this run, or the first chunk of the next
+        // item): one load per lane, each from a different 128-byte line of the spectrum row this wave will
+        // need first (its round-0 frame), so that the real loads at the top find the row in L2 instead of
+        // waiting for HBM with nothing else to run.  The value is only summed into a dummy, much later.
         warm_acc += warm;
+        const bool more = t0 + C < run_t0 + run_len;
 #ifndef GL_NO_WARM
-        if (next_item < p.n_items) {
-            int k2 = 0;
+        {
+            int bn = b, tfn = -1;
+            if (more) {
+                const int Cn = (run_t0 + run_len - (t0 + C)) < p.chunk ? (run_t0 + run_len - (t0 + C)) : p.chunk;
+                const int Rn = (Cn + GL_NW - 1) / GL_NW;
+                tfn = t0 + C - halo + 2 * halo + (Rn > ncol ? Rn : ncol) * wave;
+            } else if (next_item < p.n_items) {
+                int k2 = 0;
 #pragma unroll
-            for (int q = 1; q < GL_MAX_CLASSES; ++q)
-                if (q < p.n_classes && next_item >= p.cls_first[q]) k2 = q;
-            const int C2 = p.cls_C[k2];
-            const int rel2 = next_item - p.cls_first[k2];
-            const int t02 = p.cls_t0[k2] + (rel2 / p.B) * C2;
-            const int nA2 = C2 + 2 * halo;
-            const int Rr2 = (nA2 + GL_NW - 1) / GL_NW;
-            int tf2 = t02 - halo + (Rr2 > ncol ? Rr2 : ncol) * wave;
-            tf2 = tf2 < 0 ? 0 : (tf2 >= p.T ? p.T - 1 : tf2);
-            const float* row2 = reinterpret_cast<const float*>(p.phase_in + ((size_t)(rel2 % p.B) * p.T + tf2) * p.FP);
-            warm = row2[32 * lane];   // 64 lanes x 128 B = the first 8 KB of the 8224-byte row
+                for (int q = 1; q < GL_MAX_CLASSES; ++q)
+                    if (q < p.n_classes && next_item >= p.cls_first[q]) k2 = q;
+                const int L2 = p.cls_C[k2];
+                const int rel2 = next_item - p.cls_first[k2];
+                const int C2 = L2 < p.chunk ? L2 : p.chunk;
+                const int Rr2 = (C2 + 2 * halo + GL_NW - 1) / GL_NW;
+                bn = rel2 % p.B;
+                tfn = p.cls_t0[k2] + (rel2 / p.B) * L2 - halo + (Rr2 > ncol ? Rr2 : ncol) * wave;
+                tfn = tfn < 0 ? 0 : tfn;
+            }
+            if (tfn >= 0) {
+                tfn = tfn >= p.T ? p.T - 1 : tfn;
+                const float* row2 = reinterpret_cast<const float*>(p.phase_in + ((size_t)bn * p.T + tfn) * p.FP);
+                warm = row2[32 * lane];   // 64 lanes x 128 B = the first 8 KB of the 8224-byte row
+            }
         }
 #endif
-        __syncthreads();   // everyone is done with the signal buffer: the next item may overwrite it
+        __syncthreads();   // everyone is done with the signal buffer
+        if (more) {
+            // shift the signal of the frames shared with the next chunk to the front of the buffer
+            // (source [C hop, C hop + carry_len) and destination [0, carry_len) do not overlap: the host
+            // plans chunks of at least 3 ncol frames)
+            float cv[8];
+            const int src = C * hop;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = tid + q * GL_THREADS;
+                cv[q] = i < carry_len ? sig[src + i] : 0.f;
+            }
+            for (int i = tid + 8 * GL_THREADS; i < carry_len; i += GL_THREADS) sig[i] = sig[src + i];   // (generic windows)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = tid + q * GL_THREADS;
+                if (i < carry_len) sig[i] = cv[q];
+            }
+            __syncthreads();
+        }
+        t0 += C;
+      }   // chunks of the run
         item = next_item;
     }
     if (warm_acc == 1.2345e30f) ctrl[CT_WORDS - 1] = 1;   // keeps the warming loads alive; never true in practice
@@ -679,16 +737,18 @@ int gl_max_item_frames(int win, int hop) {
     return best;
 }
 
-// Work-item schedule of one launch: per utterance the T frames are cut into items of cls_C[k] frames, class by
-// class in descending size; items are numbered class-major with the utterance index fastest, and the
-// persistent workgroups take them in that order.  The cut is chosen by simulating that list schedule on
-// `n_workers` workgroups with the measured item cost (gl_item_cost; only the ratios matter): big items amortise the fixed cost and the halo frames, small ones at the
-// end keep the last round of the launch full.
+// Work-item schedule of one launch.  Every utterance's T frames are cut into RUNS of consecutive frames
+// (classes of equal length, longest first); a persistent workgroup takes a run (ids are class-major with the
+// utterance index fastest) and walks through it in chunks of `chunk` frames, carrying the overlap-added signal
+// of the shared frames from chunk to chunk, so only a run's first chunk pays for the halo frames.  Chunk size
+// and run count are chosen by simulating that list schedule on `n_workers` workgroups with the measured chunk
+// cost (only the ratios matter): long runs amortise the halo, but the runs of a launch must also divide evenly
+// over the compute units.
 namespace {
-struct GlCut { int nc; int c[GL_MAX_CLASSES]; int n[GL_MAX_CLASSES]; };
+struct GlCut { int chunk; int nc; int c[GL_MAX_CLASSES]; int n[GL_MAX_CLASSES]; };
 
-// measured cost of one work item (us, MI355X, reference window / hop) against its owned frames
-double gl_item_cost(int frames) {
+// measured cost of a run's first chunk (us, MI355X, reference window / hop) against its owned frames
+double gl_chunk_cost(int frames) {
     static const int xs[] = {0, 8, 16, 32, 40, 48, 56, 64};
     static const double ys[] = {18.0, 24.0, 29.5, 45.0, 52.8, 61.0, 71.0, 81.0};
     const int n = sizeof(xs) / sizeof(xs[0]);
@@ -698,11 +758,21 @@ double gl_item_cost(int frames) {
     return ys[i] + (ys[i + 1] - ys[i]) * (frames - xs[i]) / (double)(xs[i + 1] - xs[i]);
 }
 
+double gl_run_cost(int frames, int chunk) {
+    double t = 0.0;
+    for (int done = 0; done < frames; done += chunk) {
+        const int c = std::min(chunk, frames - done);
+        // a continuing chunk saves the overlap-add round of the halo frames and pays for shifting the buffer
+        t += done == 0 ? gl_chunk_cost(c) : std::max(gl_chunk_cost(c) - 3.2, 0.6 * gl_chunk_cost(c));
+    }
+    return t;
+}
+
 double gl_simulate(const GlCut& cut, int B, int n_workers) {
     std::vector<double> heap((size_t)n_workers, 0.0);   // min-heap of worker free times
     auto cmp = [](double a, double b) { return a > b; };
     for (int k = 0; k < cut.nc; ++k) {
-        const double cost = gl_item_cost(cut.c[k]);
+        const double cost = gl_run_cost(cut.c[k], cut.chunk);
         const long long items = (long long)cut.n[k] * B;
         for (long long i = 0; i < items; ++i) {
             std::pop_heap(heap.begin(), heap.end(), cmp);
@@ -717,27 +787,35 @@ double gl_simulate(const GlCut& cut, int B, int n_workers) {
 void gl_plan_items(GlParams& p, int n_workers) {
     const int cmax = gl_max_item_frames(p.win, p.hop);
     const int step = GL_NW;
+    const int halo = p.ncol - 1;
+    // a chunk must be long enough for the carried samples not to overlap their destination
+    const int carry_len = (2 * halo - 1) * p.hop + p.win;
+    const int min_chunk = std::max(2 * step, (carry_len + p.hop - 1) / p.hop);
     GlCut best;
     best.nc = 0;
+    best.chunk = cmax;
     bool forced = false;
-    if (const char* ov = getenv("SSTTS_GL_PLAN")) {   // experiments: "64x13,32x5,8x1" (must sum to T, sizes <= cmax)
-        int sum = 0;
+    if (const char* ov = getenv("SSTTS_GL_PLAN")) {   // experiments: "48:144x6,136x1" = chunk : run frames x runs per utterance
         GlCut cut;
         cut.nc = 0;
         bool good = true;
-        const char* q = ov;
-        while (*q && cut.nc < GL_MAX_CLASSES) {
-            char* end = nullptr;
+        char* end = nullptr;
+        const long ch = strtol(ov, &end, 10);
+        const char* q = end;
+        if (end == ov || *q != ':' || ch < 1 || ch > cmax) good = false;
+        else ++q;
+        int sum = 0;
+        while (good && *q && cut.nc < GL_MAX_CLASSES) {
             const long c = strtol(q, &end, 10);
             if (end == q || *end != 'x') { good = false; break; }
             q = end + 1;
             const long n = strtol(q, &end, 10);
             if (end == q) { good = false; break; }
             q = *end == ',' ? end + 1 : end;
-            if (c < 1 || c > cmax || n < 1) { good = false; break; }
+            if (c < 1 || n < 1 || (c > ch && ch < min_chunk)) { good = false; break; }
             cut.c[cut.nc] = (int)c; cut.n[cut.nc] = (int)n; sum += (int)(c * n); ++cut.nc;
         }
-        if (good && *q == 0 && sum == p.T) { best = cut; forced = true; }
+        if (good && *q == 0 && sum == p.T) { cut.chunk = (int)ch; best = cut; forced = true; }
     }
     if (!forced) {
         static std::map<std::vector<int>, GlCut> cache;   // the search is cheap but runs on every call otherwise
@@ -749,40 +827,37 @@ void gl_plan_items(GlParams& p, int n_workers) {
             best = it->second;
         } else {
             double best_t = 1e300;
-            for (int cb = cmax; cb >= step; cb -= step) {
-                const int nb_max = p.T / cb;
-                for (int nb = nb_max; nb >= 0 && nb >= nb_max - 8; --nb) {
-                    const int rem = p.T - nb * cb;
-                    // the rest: a class of mid-size items (or none), then one item with what is left
-                    for (int cm = cb - step; cm >= 0; cm -= step) {
-                        GlCut cut;
-                        cut.nc = 0;
-                        if (nb > 0) { cut.c[cut.nc] = cb; cut.n[cut.nc] = nb; ++cut.nc; }
-                        int left = rem;
-                        if (cm > 0 && left >= cm) { cut.c[cut.nc] = cm; cut.n[cut.nc] = left / cm; ++cut.nc; left %= cm; }
-                        if (left > 0) {
-                            if (left > cmax || (cut.nc > 0 && left > cut.c[cut.nc - 1])) continue;   // descending sizes only
-                            cut.c[cut.nc] = left; cut.n[cut.nc] = 1; ++cut.nc;
-                        }
-                        if (cut.nc == 0) continue;
-                        const double t = gl_simulate(cut, p.B, n_workers);
-                        if (t < best_t) { best_t = t; best = cut; }
-                    }
+            for (int ch = cmax; ch >= step; ch -= step) {
+                const bool can_carry = ch >= min_chunk;
+                const int max_runs = (p.T + ch - 1) / ch;
+                for (int nr = 1; nr <= max_runs; ++nr) {
+                    // nr runs per utterance, as even as a multiple of 8 frames allows; without the carry a run is a chunk
+                    int L = ((p.T + nr - 1) / nr + step - 1) / step * step;
+                    if (!can_carry) { if (nr != max_runs) continue; L = ch; }
+                    GlCut cut;
+                    cut.chunk = ch;
+                    cut.nc = 0;
+                    const int n_full = p.T / L, rem = p.T - n_full * L;
+                    if (n_full > 0) { cut.c[cut.nc] = L; cut.n[cut.nc] = n_full; ++cut.nc; }
+                    if (rem > 0) { cut.c[cut.nc] = rem; cut.n[cut.nc] = 1; ++cut.nc; }
+                    const double t = gl_simulate(cut, p.B, n_workers);
+                    if (t < best_t - 1e-9) { best_t = t; best = cut; }
                 }
             }
             cache[key] = best;
         }
     }
     int t = 0, slot = 0, first = 0;
-    p.C = 0;
+    p.chunk = best.chunk;
+    p.C = best.chunk;
     for (int k = 0; k < GL_MAX_CLASSES; ++k) {
         const bool on = k < best.nc;
         p.cls_C[k] = on ? best.c[k] : 0;
         p.cls_n[k] = on ? best.n[k] : 0;
+        p.cls_chunks[k] = on ? (best.c[k] + best.chunk - 1) / best.chunk : 0;
         p.cls_t0[k] = t; p.cls_slot0[k] = slot; p.cls_first[k] = first;
         if (on) {
-            if (best.c[k] > p.C) p.C = best.c[k];
-            t += best.c[k] * best.n[k]; slot += best.n[k]; first += best.n[k] * p.B;
+            t += best.c[k] * best.n[k]; slot += best.n[k] * p.cls_chunks[k]; first += best.n[k] * p.B;
         }
     }
     p.n_classes = best.nc;

@@ -206,20 +206,26 @@ def _gl_plan(T, B, win, hop, workers):
     (1000, 64, 551, 275, 224),
 ])
 def test_griffin_lim_item_plan_covers_every_frame_once(T, B, win, hop, workers):
-    """Host planner of the persistent Griffin-Lim kernel: the item classes tile [0, T) exactly, sizes
-    descend (big items first) and never exceed what fits in LDS."""
-    classes, cmax = _gl_plan(T, B, win, hop, workers)
+    """Host planner of the persistent Griffin-Lim kernel: the runs tile [0, T) exactly, run lengths descend
+    (long runs first), the chunk the runs are walked in fits in LDS, and runs longer than a chunk (which carry
+    the overlap from chunk to chunk) only appear when a chunk is long enough for that shift to be well defined."""
+    classes, chunk = _gl_plan(T, B, win, hop, workers)
     assert 1 <= len(classes) <= 4
     assert sum(c * n for c, n in classes) == T
-    assert all(1 <= c <= cmax and n >= 1 for c, n in classes)
+    assert all(c >= 1 and n >= 1 for c, n in classes)
     assert all(classes[i][0] >= classes[i + 1][0] for i in range(len(classes) - 1))
-    assert 1 <= cmax <= 64
+    assert 1 <= chunk <= 64
+    ncol = -(-win // hop)
+    carry_len = (2 * (ncol - 1) - 1) * hop + win
+    if any(c > chunk for c, _ in classes):
+        assert chunk * hop >= carry_len
     # same inputs -> same cut (the waveform's summation order depends on it)
     assert _gl_plan(T, B, win, hop, workers)[0] == classes
 
 
-@pytest.mark.parametrize('C,ncol', [(64, 5), (32, 5), (8, 5), (1, 5), (40, 5), (17, 3), (64, 2), (24, 8)])
-def test_overlap_add_round_schedule_is_race_free(C, ncol):
+@pytest.mark.parametrize('cont', [False, True])
+@pytest.mark.parametrize('C,ncol', [(64, 5), (32, 5), (8, 5), (1, 5), (40, 5), (17, 3), (64, 2), (24, 8), (48, 5)])
+def test_overlap_add_round_schedule_is_race_free(C, ncol, cont):
     """Phase A of the Griffin-Lim kernel: wave w owns frames R w .. R w + R - 1 (round r = frame R w + r), R =
     max(ncol, ceil(nA / 8)); frames fewer than ncol apart overlap.  Check on the frame level that (1) frames
     of one round never overlap, (2) every overlapping pair of different waves is ordered by the flag rule
@@ -228,8 +234,12 @@ def test_overlap_add_round_schedule_is_race_free(C, ncol):
     zero-fill before anything accumulates into it."""
     NW, halo = 8, ncol - 1
     nA = C + 2 * halo
-    R = max(ncol, -(-nA // NW))
-    frames = {(w, r): R * w + r for w in range(NW) for r in range(R)}
+    # a continuing chunk of a run inherits the signal of its first 2*halo frames and transforms only the rest
+    fa0 = 2 * halo if cont else 0
+    if cont and C < 3 * ncol:
+        pytest.skip('the planner never continues a run over chunks this short')
+    R = max(ncol, -(-(nA - fa0) // NW))
+    frames = {(w, r): fa0 + R * w + r for w in range(NW) for r in range(R)}
     for (w, r), f in frames.items():
         for (w2, r2), f2 in frames.items():
             if (w, r) >= (w2, r2) or abs(f - f2) >= ncol:
@@ -241,12 +251,18 @@ def test_overlap_add_round_schedule_is_race_free(C, ncol):
             lo, hi = ((w, r), (w2, r2)) if w < w2 else ((w2, r2), (w, r))
             need = lo[1] - (R - ncol)                                # rounds wave lo[0]+1 must have finished
             assert need > 0 and hi[1] < need                         # (2): the upper wave's frame came first
-    # (4) in units of hop: wave w initialises [R w, R (w+1)) (the last wave up to the end of the buffer)
+    # (4) in units of hop: wave w initialises [fa0 + R w, fa0 + R (w+1)) (the last wave up to the end of the
+    # buffer); in a continuing chunk [0, carry) is inherited and reaches into wave 0's region only
     span_hops = nA - 1 + ncol
     owner = np.full(span_hops, -1)
+    if cont:
+        carry = 2 * halo - 1 + ncol
+        assert carry <= fa0 + R                                     # inherited samples stay inside wave 0's region
+        owner[:min(fa0, span_hops)] = 0                              # (never written by a new frame's round 0)
     for w in range(NW):
-        lo = R * w
-        hi = span_hops if w == NW - 1 else min(R * (w + 1), span_hops)
+        lo = fa0 + R * w
+        hi = span_hops if w == NW - 1 else min(fa0 + R * (w + 1), span_hops)
+        lo = min(lo, span_hops)
         assert np.all(owner[lo:hi] == -1)
         owner[lo:hi] = w
     assert np.all(owner >= 0)
