@@ -1565,7 +1565,14 @@ int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_worker
 int tts_debug_gemm(tts_handle_t h, const float* A, const float* Wt, float* C, int M, int N, int Cin, int ktaps, int T,
                    int pool) {
     if (!h || !A || !Wt || !C || M < 1 || N < 1 || Cin < 4 || (Cin & 3) || ktaps < 1 || T < 1 || M % T) return TTS_ERR_INVALID;
-    return run_single(h, conv_group(A, Cin, ktaps, T, Wt, nullptr, nullptr, nullptr, C, N, 0, M, N, ACT_NONE, pool));
+    GemmGroup g = conv_group(A, Cin, ktaps, T, Wt, nullptr, nullptr, nullptr, C, N, 0, M, N, ACT_NONE, pool);
+    const int slices = gemm_splitk_slices(g.K);   // same rule as the CBHG projections
+    if (slices > 1) {
+        WS(h, "debug.splitk", float, (size_t)slices * M * N, part);
+        HIPCHK(h, launch_gemm_splitk(h->stream, g, slices, part));
+        return TTS_OK;
+    }
+    return run_single(h, g);
 }
 
 // Diagnostic: occupy `n_wgs` workgroup slots of `lds_kb` KB LDS each for `ms` milliseconds on a private
