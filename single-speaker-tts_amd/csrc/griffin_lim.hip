@@ -319,6 +319,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     int item = __builtin_amdgcn_readfirstlane(ctrl[CT_NEXT_ITEM]);   // wave-uniform: keep it (and all it decodes to) in SGPRs
 
     float warm = 0.f, warm_acc = 0.f;   // see the end of the loop body
+    GL_LOAD_WINDOW(1)                   // synthesis window for the first chunk; reloaded at the end of every phase B
     const int carry_len = (2 * halo - 1) * hop + win;   // samples that consecutive chunks of a run share
     while (item < p.n_items) {
         // ---------------- decode the work item (wave-uniform scalar code): a RUN of consecutive frames of one
@@ -370,7 +371,6 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gm[j_] = mrow_[-64 * j_];                 \
     }
         GL_LOAD_FRAME(fa0 + R * wave)
-        GL_LOAD_WINDOW(1)
 
         // ---------------- phase A: inverse FFT + windowed overlap-add into LDS
         // Frame fa = R*wave + r is processed by `wave` in round r.  Frames of one round are >= ncol apart
@@ -478,6 +478,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             asm volatile("" ::: "memory");
             if (lane == 0) *reinterpret_cast<volatile int*>(ctrl + CT_FLAGS + wave) = r + 1;
         }
+        // this wave is done with the synthesis window: fetch the analysis window of phase B into the same
+        // registers now, so that the loads fly while the wave waits for the others at the barrier
+        if (MODE == 0) GL_LOAD_WINDOW(0)
         if (tid == 0 && cq == 0) ctrl[CT_NEXT_ITEM] = (int)next_item_reg;
         __syncthreads();   // all overlap-adds done (the signal is final), next item published
         if (cq == 0) next_item = __builtin_amdgcn_readfirstlane(ctrl[CT_NEXT_ITEM]);
@@ -509,7 +512,6 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             }
         } else {
             // ---------------- phase B: forward FFT of the owned frames, new unit phasors
-            GL_LOAD_WINDOW(0)
             cf* pob = p.phase_out + (size_t)b * p.T * p.FP;
             float mse_acc = 0.f;
             // frames are handed out dynamically (LDS counter): the wave that wins issue arbitration on
@@ -641,6 +643,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         // item): one load per lane, each from a different 128-byte line of the spectrum row this wave will
         // need first (its round-0 frame), so that the real loads at the top find the row in L2 instead of
         // waiting for HBM with nothing else to run.  The value is only summed into a dummy, much later.
+        if (MODE == 0) GL_LOAD_WINDOW(1)   // ... and the synthesis window back, under the wait at the end barrier
         warm_acc += warm;
         const bool more = t0 + C < run_t0 + run_len;
 #ifndef GL_NO_WARM
