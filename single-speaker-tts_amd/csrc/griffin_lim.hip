@@ -678,19 +678,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             // shift the signal of the frames shared with the next chunk to the front of the buffer
             // (source [C hop, C hop + carry_len) and destination [0, carry_len) do not overlap: the host
             // plans chunks of at least 3 ncol frames)
-            float cv[8];
             const int src = C * hop;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i = tid + q * GL_THREADS;
-                cv[q] = i < carry_len ? sig[src + i] : 0.f;
-            }
-            for (int i = tid + 8 * GL_THREADS; i < carry_len; i += GL_THREADS) sig[i] = sig[src + i];   // (generic windows)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i = tid + q * GL_THREADS;
-                if (i < carry_len) sig[i] = cv[q];
-            }
+#pragma unroll 1
+            for (int i = tid; i < carry_len; i += GL_THREADS) sig[i] = sig[src + i];
             __syncthreads();
         }
         t0 += C;
