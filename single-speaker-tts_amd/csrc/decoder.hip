@@ -29,7 +29,8 @@ namespace tts {
 #define DEC_NW 8
 #define DEC_THREADS (DEC_NW * 64)
 
-__global__ __launch_bounds__(DEC_THREADS) void dec_gemm_kernel(DecGemm p) {
+template <bool PARTS>
+__device__ __forceinline__ void dec_gemm_body(const DecGemm& p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_gemm_kernel(DecGemm p) {
     float coef[TTS_ATT_PARTS];
     const float* part_row = nullptr;
     size_t part_stride = 0;
-    if (p.parts) {
+    if (PARTS) {
         const float* st = p.stats + (size_t)rr * TTS_ATT_PARTS * 2;
         float m = -INFINITY;
 #pragma unroll
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_gemm_kernel(DecGemm p) {
                 if (row_ok) {
                     if (k < p.k0) {
                         av[i] = *reinterpret_cast<const float4*>(a0 + k);
-                    } else if (p.parts) {
+                    } else if (PARTS) {
                         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                         for (int pp = 0; pp < TTS_ATT_PARTS; ++pp) {
@@ -167,6 +168,12 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_gemm_kernel(DecGemm p) {
         } break;
     }
 }
+
+// Two entry points so that the common form (no attention merge in the loader) can be held to 64 VGPRs: four
+// 512-thread workgroups per CU instead of two, i.e. the 128 workgroups of the N = 512 layers fit the 32 CUs
+// the call pipeline reserves for the decoder in one round.
+__global__ __launch_bounds__(DEC_THREADS, 8) void dec_gemm_kernel(DecGemm p) { dec_gemm_body<false>(p); }
+__global__ __launch_bounds__(DEC_THREADS) void dec_gemm_merge_kernel(DecGemm p) { dec_gemm_body<true>(p); }
 
 // CudnnCompatibleGRUCell tail: c = tanh(xi + r*hh); h' = u h + (1-u) c; y = resid + h'
 __global__ void dec_gru_cudnn_combine(const float* r, const float* u, const float* hh, const float* xi, float* h,
@@ -328,7 +335,8 @@ __global__ void dec_align_finalize_kernel(const float* __restrict__ e, const flo
 
 static inline hipError_t run_gemm(hipStream_t s, const DecGemm& p) {
     dim3 grid((p.N + 15) / 16, (p.B + 15) / 16);
-    hipLaunchKernelGGL(dec_gemm_kernel, grid, dim3(DEC_THREADS), 0, s, p);
+    if (p.parts) hipLaunchKernelGGL(dec_gemm_merge_kernel, grid, dim3(DEC_THREADS), 0, s, p);
+    else hipLaunchKernelGGL(dec_gemm_kernel, grid, dim3(DEC_THREADS), 0, s, p);
     return hipGetLastError();
 }
 
