@@ -10,7 +10,10 @@
 // then sleeps.  A CU that hosts one can no longer admit a Griffin-Lim workgroup (147 KB LDS) but
 // still has room for the decoder's and encoder's workgroups (4-37 KB LDS, moderate registers).
 // `reserve_cus` such workgroups therefore reserve that many CUs for the front stream without any
-// driver support.  They poll one flag word with s_sleep between polls and ALWAYS terminate: either
+// driver support.  The dispatcher deals workgroups round-robin over the 32 shader engines (8 XCDs x 4 SEs of 8
+// CUs) and a launch stalls while ANY engine has no CU able to take its next workgroup, so the useful
+// reservations are multiples of 32 (one CU per engine: tools/cu_census.hip shows 32 sleepers landing exactly so;
+// with fewer free engines the decoder's launches wait for Griffin-Lim workgroups to exit).  They poll one flag word with s_sleep between polls and ALWAYS terminate: either
 // the flag is set (the decoder finished) or the wall-clock bound expires.
 #include "tts_common.h"
 #include <mutex>

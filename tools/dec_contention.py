@@ -12,7 +12,7 @@ rng = np.random.default_rng(0)
 mem = eng.to_device((rng.standard_normal((64, 150, 256)) * 0.5).astype(np.float32))
 mel, al = eng.decoder_forward(mem, 200)
 eng.synchronize()
-for hold, lds in [(0, 0), (224, 152), (240, 152), (248, 152)]:
+for hold, lds in [(0, 0), (224, 152), (228, 152), (248, 100)]:
     if hold:
         eng._check(eng.lib.tts_debug_hold(eng.handle, hold, lds, 80.0))
         time.sleep(0.005)
