@@ -788,7 +788,8 @@ int gl_prepare(tts_handle_t h, int T, int win, int hop, int n_fft) {
 
 // mag_int: internal [B][T][FP]; init_ft: reference-layout U[0,1) numbers or null.
 int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t seed, int B, int T, int n_iter,
-           int win, int hop, int n_fft, float* wav, float* mse, bool peak_normalize = false) {
+           int win, int hop, int n_fft, float* wav, float* mse, bool peak_normalize = false,
+           bool under_reservation = false) {
     int rc = gl_prepare(h, T, win, hop, n_fft);
     if (rc) return rc;
     const int F = 1 + n_fft / 2, FP = TTS_GL_FP;
@@ -810,7 +811,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     const int n_cus = device_cus(h);
     // workgroups that really run side by side: the pipelined tts_synthesize keeps `reserve_cus` compute units
     // free of Griffin-Lim for its second stream
-    const int held = (h->pipeline && h->own_stream && h->reserve_cus > 0 && h->front) ? h->reserve_cus : 0;
+    const int held = (under_reservation && h->reserve_cus > 0) ? h->reserve_cus : 0;
     gl_plan_items(p, n_cus - held > 16 ? n_cus - held : n_cus);
     const int nchunks = p.slots_per_utt;
     WS(h, "gl.mse_partial", float, (size_t)B * nchunks, msep);
@@ -1527,7 +1528,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         h->post_pending[parity] = true;
     }
     return gl_run(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav, nullptr,
-                  sp->peak_normalize != 0);
+                  sp->peak_normalize != 0, pipelined);
 }
 
 int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* bytes) {
