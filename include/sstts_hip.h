@@ -16,7 +16,9 @@
  *   - Every function returns 0 on success or a negative tts_status code and never throws.
  *     tts_last_error(handle) returns a human-readable description of the last failure.
  *   - A handle is bound to one device and one stream; calls on one handle must be
- *     serialised by the caller.  Distinct handles (one per GPU / process) are independent.
+ *     serialised by the caller.  Distinct handles (one per GPU / process) are independent:
+ *     every entry point that takes a handle switches to the handle's device for the call and
+ *     restores the caller's current device on return.
  *   - Calls are asynchronous on the handle's stream unless stated; tts_synchronize waits.
  *   - Same inputs (and the same init_phase / seed) give bit-identical outputs run to run:
  *     every reduction has a fixed order, no float atomics are used.
@@ -108,15 +110,21 @@ int tts_load_weights_blob(tts_handle_t h, const float* host_blob, size_t n_float
 int tts_finalize_weights(tts_handle_t h);
 
 /* ---- device memory helpers ---------------------------------------------------------- */
+/* tts_malloc / tts_free act on the device that is CURRENT on the calling thread; with more than one GPU in
+ * a process use the handle-bound pair, which allocates on the handle's device whatever is current. */
 int tts_malloc(void** dptr, size_t bytes);
 int tts_free(void* dptr);
+int tts_device_malloc(tts_handle_t h, void** dptr, size_t bytes);
+int tts_device_free(tts_handle_t h, void* dptr);
 int tts_memcpy_h2d(tts_handle_t h, void* dst, const void* src, size_t bytes);  /* synchronous */
 int tts_memcpy_d2h(tts_handle_t h, void* dst, const void* src, size_t bytes);  /* synchronous */
 int tts_memset(tts_handle_t h, void* dst, int value, size_t bytes);
 
 /* ---- network stages -------------------------------------------------------------------- */
 /* Tacotron.encoder (tacotron/model.py:124-173): embedding + pre-net + CBHG.
- * ids int32 [B*Ts] -> memory float [B*Ts*2*n_gru_units]. */
+ * ids int32 [B*Ts] -> memory float [B*Ts*2*n_gru_units].  An id outside [0, vocabulary_size) reads as
+ * a zero embedding row (TensorFlow's GPU kernel does the same; its CPU kernel raises, which the Python
+ * mirror reproduces for host arrays -- device-resident ids cannot be inspected without a sync). */
 int tts_encoder_forward(tts_handle_t h, const int32_t* ids, int B, int Ts, float* memory);
 /* Tacotron.decoder in Mode.PREDICT (tacotron/model.py:175-334; wrappers.py:94-124;
  * helpers.py:83-110,161-205): n_steps strictly sequential steps (reference: 1000//5 = 200).
@@ -132,7 +140,9 @@ int tts_postnet_forward(tts_handle_t h, const float* mel, int B, int T, float* l
 /* inference() post-step + synthesize() power (tacotron/inference.py:93-101,175;
  * audio/conversion.py:81-102, 32-53): per utterance transpose to (F,T),
  * db = (clip(x,0,1)-1)*(|ref|+|max|)+ref, mag = 10^(db/20), mag ** power.
- * linear [B*T*F] -> mag [B*F*T].  Returns TTS_ERR_DB_RANGE when ref - |ref| - |max| < -100. */
+ * linear [B*T*F] -> mag [B*F*T].  Returns TTS_ERR_DB_RANGE when some value de-normalises to less than
+ * -100 dB (decibel_to_magnitude's assertion; checked on the data, and only for constants that allow it:
+ * ref - |ref| - |max| < -100 -- the call then synchronises the stream). */
 int tts_denorm_power(tts_handle_t h, const float* linear, int B, int T, int F,
                      float ref_db, float max_db, float power, float* mag);
 

@@ -70,6 +70,8 @@ _PROTOTYPES = {
     'tts_finalize_weights': (c_int, [c_void_p]),
     'tts_malloc': (c_int, [POINTER(c_void_p), c_size_t]),
     'tts_free': (c_int, [c_void_p]),
+    'tts_device_malloc': (c_int, [c_void_p, POINTER(c_void_p), c_size_t]),
+    'tts_device_free': (c_int, [c_void_p, c_void_p]),
     'tts_memcpy_h2d': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     'tts_memcpy_d2h': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     'tts_memset': (c_int, [c_void_p, c_void_p, c_int, c_size_t]),
@@ -130,9 +132,10 @@ class DeviceArray(object):
         self.dtype = np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
         p = c_void_p()
-        rc = engine.lib.tts_malloc(byref(p), self.nbytes)
+        # allocated on the engine's device, whatever device is current on this thread
+        rc = engine.lib.tts_device_malloc(engine.handle, byref(p), self.nbytes)
         if rc != TTS_OK:
-            raise TtsError(rc, 'tts_malloc({}) failed'.format(self.nbytes))
+            raise TtsError(rc, 'tts_device_malloc({}) failed'.format(self.nbytes))
         self.ptr = p.value
 
     def data_ptr(self):
@@ -153,7 +156,10 @@ class DeviceArray(object):
 
     def free(self):
         if self.ptr:
-            self.engine.lib.tts_free(self.ptr)
+            if getattr(self.engine, 'handle', None):
+                self.engine.lib.tts_device_free(self.engine.handle, self.ptr)
+            else:   # the engine is gone (tts_destroy does not free caller-owned buffers)
+                self.engine.lib.tts_free(self.ptr)
             self.ptr = None
 
     def __del__(self):
@@ -206,6 +212,7 @@ class Engine(object):
         if rc != TTS_OK:
             raise TtsError(rc, (self.lib.tts_last_error(None) or b'').decode())
         self.handle = h
+        self._staging = {}
         if stream is not None:
             self._check(self.lib.tts_set_stream(self.handle, c_void_p(stream)))
 
@@ -219,6 +226,9 @@ class Engine(object):
 
     def close(self):
         if getattr(self, 'handle', None):
+            for d in self._staging.values():
+                d.free()
+            self._staging = {}
             self.lib.tts_destroy(self.handle)
             self.handle = None
 
@@ -241,14 +251,41 @@ class Engine(object):
         host = np.asarray(host)
         return DeviceArray(self, host.shape, dtype or host.dtype).copy_from(host)
 
-    def _in(self, x, dtype):
-        """-> (pointer, keepalive) for a host array or a device buffer."""
+    def _in(self, x, dtype, role=None):
+        """-> (pointer, keepalive) for a host array or a device buffer.
+
+        Host arrays are uploaded with tts_memcpy_h2d, which waits for the handle's stream: a call fed from
+        host memory therefore starts after the previous call's Griffin-Lim has finished, i.e. the stream
+        pipelining of tts_synthesize only overlaps calls whose inputs are device resident.  With a `role`
+        the staging buffer is kept and reused by later calls of the same size (a fresh buffer per call
+        would add a hipFree, which synchronises the whole device)."""
         if x is None:
             return None, None
         if _is_device(x):
             return x.data_ptr(), x
-        d = self.to_device(np.ascontiguousarray(x, dtype=dtype), dtype)
+        host = np.ascontiguousarray(x, dtype=dtype)
+        if role is None:
+            d = self.to_device(host, dtype)
+            return d.ptr, d
+        d = self._staging.get(role)
+        if d is None or d.nbytes != host.nbytes:
+            if d is not None:
+                d.free()
+            d = DeviceArray(self, host.shape, dtype)
+            self._staging[role] = d
+        d.shape = host.shape
+        d.copy_from(host)
         return d.ptr, d
+
+    def _check_ids(self, ids):
+        """tf.nn.embedding_lookup on the CPU raises for ids outside the table (reference
+        tacotron/model.py:154); device-resident ids cannot be inspected without a synchronisation, the
+        kernel reads them as a zero row (TF's GPU behaviour)."""
+        if isinstance(ids, np.ndarray) and ids.size:
+            lo, hi = int(ids.min()), int(ids.max())
+            if lo < 0 or hi >= self.cfg.vocabulary_size:
+                raise TtsError(TTS_ERR_INVALID, 'sentence ids must lie in [0, {}): got [{}, {}]'.format(
+                    self.cfg.vocabulary_size, lo, hi))
 
     # ------------------------------------------------------------------ weights
     def manifest(self):
@@ -280,7 +317,8 @@ class Engine(object):
     # ------------------------------------------------------------------ stages
     def encoder_forward(self, ids, out=None):
         B, Ts = ids.shape
-        p_ids, _k = self._in(ids, np.int32)
+        self._check_ids(ids)
+        p_ids, _k = self._in(ids, np.int32, 'ids')
         mem = out if out is not None else self.empty((B, Ts, 2 * self.cfg.n_gru_units))
         self._check(self.lib.tts_encoder_forward(self.handle, p_ids, B, Ts, mem.data_ptr()))
         return mem
@@ -332,8 +370,9 @@ class Engine(object):
         F = 1 + self.cfg.n_fft // 2
         sp = TtsSynthParams(n_steps, ref_db, max_db, power, n_iter, win_length, hop_length, seed,
                             1 if peak_normalize else 0)
-        p_ids, _k1 = self._in(ids, np.int32)
-        p_init, _k2 = self._in(init_phase, np.float32)
+        self._check_ids(ids)
+        p_ids, _k1 = self._in(ids, np.int32, 'ids')
+        p_init, _k2 = self._in(init_phase, np.float32, 'init_phase')
         wav = wav if wav is not None else self.empty((B, hop_length * (T - 1)))
         mel = self.empty((B, T, self.cfg.n_mels)) if want_mel else None
         ali = self.empty((n_steps, B, Ts)) if want_alignments else None

@@ -148,6 +148,23 @@ namespace {
         }                                                                                       \
     } while (0)
 
+// Every entry point that takes a handle runs on the handle's device, whatever device is current on the calling
+// thread (one process may hold handles on several GPUs, or a caller may have switched devices after tts_create);
+// the caller's current device is restored on return.
+struct DeviceScope {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceScope(tts_handle_t h) {
+        if (!h) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != h->device) changed = hipSetDevice(h->device) == hipSuccess;
+    }
+    ~DeviceScope() {
+        if (changed) hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 int fail(tts_handle_t h, int code, const std::string& msg) {
     if (h) h->err = msg;
     else g_create_error = msg;
@@ -828,9 +845,34 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
             p.phase_out = nxt;
             p.mse_partial = (mse && it == n_iter - 1) ? msep : nullptr;
             p.work_counter = counters + it;
+#ifdef GL_TIMELINE   // tools only: stamps of workgroup 0 during the last iteration
+            WS(h, "gl.timeline", unsigned long long, 64 * 16, tl);
+            if (it == n_iter - 1) {
+                HIPCHK(h, hipMemsetAsync(tl, 0, 64 * 16 * sizeof(unsigned long long), h->stream));
+                p.dbg = tl;
+            }
+#endif
             HIPCHK(h, launch_gl_iter(h->stream, p, n_cus, 0));
             std::swap(cur, nxt);
         }
+#ifdef GL_TIMELINE
+        if (n_iter > 0) {
+            std::vector<unsigned long long> host(64 * 16);
+            HIPCHK(h, hipMemcpyAsync(host.data(), p.dbg, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            unsigned long long t0 = ~0ull;
+            for (auto v : host) if (v && v < t0) t0 = v;
+            for (int w = 0; w < 12; ++w) {
+                fprintf(stderr, "wave %2d:", w);
+                for (int i = 0; i < 64; ++i) {
+                    const unsigned long long v = host[w * 64 + i];
+                    if (v) fprintf(stderr, " [%d]%.1f", i, (double)(v - t0) * 0.01);
+                }
+                fprintf(stderr, "\n");
+            }
+            p.dbg = nullptr;
+        }
+#endif
     }
     if (mse) {
         if (n_iter > 0) {
@@ -919,6 +961,7 @@ int tts_create(const tts_config_t* cfg, int device_id, tts_handle_t* out) {
 }
 
 int tts_destroy(tts_handle_t h) {
+    DeviceScope dev_scope(h);
     if (!h) return TTS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
@@ -960,6 +1003,7 @@ int tts_destroy(tts_handle_t h) {
 const char* tts_last_error(tts_handle_t h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int tts_set_stream(tts_handle_t h, void* s) {
+    DeviceScope dev_scope(h);
     if (!h) return TTS_ERR_INVALID;
     {
         int rc = sync_all(h);
@@ -982,6 +1026,7 @@ int tts_set_stream(tts_handle_t h, void* s) {
 }
 
 int tts_set_option(tts_handle_t h, const char* key, int value) {
+    DeviceScope dev_scope(h);
     if (!h || !key) return TTS_ERR_INVALID;
     if (!std::strcmp(key, "use_graph")) h->use_graph = value;
     else if (!std::strcmp(key, "profile")) h->profile = value;
@@ -1001,6 +1046,7 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
 }
 
 int tts_synchronize(tts_handle_t h) {
+    DeviceScope dev_scope(h);
     if (!h) return TTS_ERR_INVALID;
     return sync_all(h);
 }
@@ -1048,6 +1094,7 @@ int tts_load_weights_blob(tts_handle_t h, const float* blob, size_t n) {
 }
 
 int tts_finalize_weights(tts_handle_t h) {
+    DeviceScope dev_scope(h);
     if (!h) return TTS_ERR_INVALID;
     for (const auto& e : h->manifest)
         if (!h->host_w.count(e.name)) return fail(h, TTS_ERR_NOT_LOADED, "missing weight " + e.name);
@@ -1172,13 +1219,27 @@ int tts_malloc(void** dptr, size_t bytes) {
     return hipMalloc(dptr, bytes ? bytes : 4) == hipSuccess ? TTS_OK : TTS_ERR_HIP;
 }
 int tts_free(void* dptr) { return hipFree(dptr) == hipSuccess ? TTS_OK : TTS_ERR_HIP; }
+int tts_device_malloc(tts_handle_t h, void** dptr, size_t bytes) {
+    if (!h || !dptr) return TTS_ERR_INVALID;
+    DeviceScope dev_scope(h);
+    HIPCHK(h, hipMalloc(dptr, bytes ? bytes : 4));
+    return TTS_OK;
+}
+int tts_device_free(tts_handle_t h, void* dptr) {
+    if (!h) return TTS_ERR_INVALID;
+    DeviceScope dev_scope(h);
+    HIPCHK(h, hipFree(dptr));
+    return TTS_OK;
+}
 int tts_memcpy_h2d(tts_handle_t h, void* dst, const void* src, size_t bytes) {
+    DeviceScope dev_scope(h);
     if (!h) return TTS_ERR_INVALID;
     HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return TTS_OK;
 }
 int tts_memcpy_d2h(tts_handle_t h, void* dst, const void* src, size_t bytes) {
+    DeviceScope dev_scope(h);
     if (!h) return TTS_ERR_INVALID;
     if (h->front) HIPCHK(h, hipStreamSynchronize(h->front));   // optional outputs of a pipelined synthesize
     HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1186,6 +1247,7 @@ int tts_memcpy_d2h(tts_handle_t h, void* dst, const void* src, size_t bytes) {
     return TTS_OK;
 }
 int tts_memset(tts_handle_t h, void* dst, int value, size_t bytes) {
+    DeviceScope dev_scope(h);
     if (!h) return TTS_ERR_INVALID;
     HIPCHK(h, hipMemsetAsync(dst, value, bytes, h->stream));
     return TTS_OK;
@@ -1193,6 +1255,7 @@ int tts_memset(tts_handle_t h, void* dst, int value, size_t bytes) {
 
 // ---------------------------------------------------------------------------------------- stages
 int tts_encoder_forward(tts_handle_t h, const int32_t* ids, int B, int Ts, float* memory) {
+    DeviceScope dev_scope(h);
     int rc = check_ready(h);
     if (rc) return rc;
     if (!ids || !memory || B < 1 || Ts < 1) return fail(h, TTS_ERR_INVALID, "encoder_forward: bad arguments");
@@ -1206,6 +1269,7 @@ int tts_encoder_forward(tts_handle_t h, const int32_t* ids, int B, int Ts, float
         GemmGroup g = dense_group(h->embedding, c.embedding_size, h->enc_pre_wt[0], h->enc_pre_b[0], pre1,
                                   c.enc_prenet_units[0], M, c.enc_prenet_units[0], c.embedding_size, ACT_RELU);
         g.gather = ids;
+        g.gather_rows = c.vocabulary_size;
         if ((rc = run_single(h, g))) return rc;
     }
     if ((rc = run_single(h, dense_group(pre1, c.enc_prenet_units[0], h->enc_pre_wt[1], h->enc_pre_b[1], pre2,
@@ -1220,6 +1284,7 @@ int tts_encoder_forward(tts_handle_t h, const int32_t* ids, int B, int Ts, float
 
 int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int n_steps, float* mel,
                         float* alignments) {
+    DeviceScope dev_scope(h);
     int rc = check_ready(h);
     if (rc) return rc;
     if (!memory || !mel || B < 1 || Ts < 1 || n_steps < 1) return fail(h, TTS_ERR_INVALID, "decoder_forward: bad arguments");
@@ -1303,7 +1368,7 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
 // post-net CBHG + final Dense; with mag != null the Dense epilogue also emits the de-normalised,
 // power-raised magnitude in the internal frame-major layout [B*T][FP] (fused tts_denorm_power).
 static int postnet_impl(tts_handle_t h, const float* mel, int B, int T, float* linear, float* mag, float ref_db,
-                        float max_db, float power) {
+                        float max_db, float power, int* db_flag = nullptr) {
     int rc = check_ready(h);
     if (rc) return rc;
     // linear may be null when only the de-normalised magnitude is wanted (tts_synthesize without linear_out)
@@ -1322,6 +1387,7 @@ static int postnet_impl(tts_handle_t h, const float* mel, int B, int T, float* l
         g.d_ref = ref_db;
         g.d_range = std::fabs(ref_db) + std::fabs(max_db);
         g.d_pow = power;
+        g.d_flag = db_flag;
     }
     if ((rc = run_single(h, g))) return rc;
     ++launches;
@@ -1330,14 +1396,30 @@ static int postnet_impl(tts_handle_t h, const float* mel, int B, int T, float* l
 }
 
 int tts_postnet_forward(tts_handle_t h, const float* mel, int B, int T, float* linear) {
+    DeviceScope dev_scope(h);
     if (!linear) return fail(h, TTS_ERR_INVALID, "postnet_forward: bad arguments");
     return postnet_impl(h, mel, B, T, linear, nullptr, 0.f, 0.f, 1.f);
 }
 
-static int denorm_check(tts_handle_t h, float ref_db, float max_db) {
-    // reference audio/conversion.py:47-49: AssertionError when any dB value < -100.  The lowest
-    // value inv_normalize_decibel can produce is ref - (|ref| + |max|) (clip(x) == 0).
-    if (ref_db - (std::fabs(ref_db) + std::fabs(max_db)) < -100.0f)
+// reference audio/conversion.py:47-49: decibel_to_magnitude raises AssertionError when some dB value is below
+// -100.  The lowest value inv_normalize_decibel can produce is ref - (|ref| + |max|) (clip(x) == 0): with the
+// reference's constants (6.02, 99.89) that is -93.87 dB, so the assertion cannot fire and nothing is checked.
+// Constants that allow it get the data-dependent check the reference makes: the de-normalising kernels raise
+// a device flag, which the caller reads back (one stream synchronisation, only in that configuration).
+static bool denorm_can_assert(float ref_db, float max_db) {
+    return ref_db - (std::fabs(ref_db) + std::fabs(max_db)) < -100.0f;
+}
+static int denorm_flag_arm(tts_handle_t h, int** flag) {
+    if (!h->an.flag) HIPCHK(h, hipMalloc(&h->an.flag, sizeof(int)));
+    HIPCHK(h, hipMemsetAsync(h->an.flag, 0, sizeof(int), h->stream));
+    *flag = h->an.flag;
+    return TTS_OK;
+}
+static int denorm_flag_read(tts_handle_t h) {
+    int flag = 0;
+    HIPCHK(h, hipMemcpyAsync(&flag, h->an.flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (flag)
         return fail(h, TTS_ERR_DB_RANGE,
                     "\"conversion.decibel_to_magnitude\" was asked to convert a dB value smaller -100 dB.");
     return TTS_OK;
@@ -1345,19 +1427,24 @@ static int denorm_check(tts_handle_t h, float ref_db, float max_db) {
 
 int tts_denorm_power(tts_handle_t h, const float* linear, int B, int T, int F, float ref_db, float max_db, float power,
                      float* mag) {
+    DeviceScope dev_scope(h);
     if (!h || !linear || !mag || B < 1 || T < 1 || F < 1) return fail(h, TTS_ERR_INVALID, "denorm_power: bad arguments");
-    int rc = denorm_check(h, ref_db, max_db);
-    if (rc) return rc;
+    int rc;
+    int* flag = nullptr;
+    if (denorm_can_assert(ref_db, max_db) && (rc = denorm_flag_arm(h, &flag))) return rc;
     const int FP = (F + 3) & ~3;
     WS(h, "denorm.tmp", float, (size_t)B * T * FP, tmp);
-    ProfScope ps(h, ST_DENORM, 2);
-    HIPCHK(h, launch_denorm_power(h->stream, linear, tmp, (size_t)B * T, F, FP, ref_db, max_db, power));
-    HIPCHK(h, launch_tf_to_ft(h->stream, tmp, mag, B, F, T, FP));
-    return TTS_OK;
+    {
+        ProfScope ps(h, ST_DENORM, 2);
+        HIPCHK(h, launch_denorm_power(h->stream, linear, tmp, (size_t)B * T, F, FP, ref_db, max_db, power, flag));
+        HIPCHK(h, launch_tf_to_ft(h->stream, tmp, mag, B, F, T, FP));
+    }
+    return flag ? denorm_flag_read(h) : TTS_OK;
 }
 
 int tts_griffin_lim(tts_handle_t h, const float* mag, const float* init_phase, uint64_t seed, int B, int T, int n_iter,
                     int win_length, int hop_length, int n_fft, float* wav, float* mse) {
+    DeviceScope dev_scope(h);
     if (!h || !mag || !wav || B < 1 || n_iter < 0) return fail(h, TTS_ERR_INVALID, "griffin_lim: bad arguments");
     int rc = gl_prepare(h, T, win_length, hop_length, n_fft);
     if (rc) return rc;
@@ -1368,12 +1455,14 @@ int tts_griffin_lim(tts_handle_t h, const float* mag, const float* init_phase, u
 }
 
 int tts_peak_normalize(tts_handle_t h, float* wav, int B, int n) {
+    DeviceScope dev_scope(h);
     if (!h || !wav || B < 1 || n < 1) return fail(h, TTS_ERR_INVALID, "peak_normalize: bad arguments");
     HIPCHK(h, launch_peak_normalize(h->stream, wav, B, n));
     return TTS_OK;
 }
 
 int tts_stft(tts_handle_t h, const float* wav, int B, int n, int n_fft, int win_length, int hop_length, float* out) {
+    DeviceScope dev_scope(h);
     if (!h || !wav || !out || B < 1) return fail(h, TTS_ERR_INVALID, "stft: bad arguments");
     float2* buf;
     int Tf;
@@ -1385,6 +1474,7 @@ int tts_stft(tts_handle_t h, const float* wav, int B, int n, int n_fft, int win_
 
 int tts_stft_magnitude(tts_handle_t h, const float* wav, int B, int n, int n_fft, int win_length, int hop_length,
                        float power, float* lin) {
+    DeviceScope dev_scope(h);
     if (!h || !wav || !lin || B < 1) return fail(h, TTS_ERR_INVALID, "stft_magnitude: bad arguments");
     float2* buf;
     int Tf;
@@ -1396,6 +1486,7 @@ int tts_stft_magnitude(tts_handle_t h, const float* wav, int B, int n, int n_fft
 
 int tts_mel_spectrogram(tts_handle_t h, const float* lin, int B, int n_frames, int n_fft, int sr, int n_mels, float fmin,
                         float fmax, float* mel) {
+    DeviceScope dev_scope(h);
     if (!h || !lin || !mel || B < 1 || n_frames < 1 || n_mels < 1 || sr < 1)
         return fail(h, TTS_ERR_INVALID, "mel_spectrogram: bad arguments");
     if (n_fft != TTS_GL_NFFT) return fail(h, TTS_ERR_UNSUPPORTED, "mel_spectrogram: only n_fft == 2048 is implemented");
@@ -1437,6 +1528,7 @@ int tts_mel_spectrogram(tts_handle_t h, const float* lin, int B, int n_frames, i
 }
 
 int tts_db_convert(tts_handle_t h, const float* in, size_t n, int mode, float ref_db, float max_db, float* out) {
+    DeviceScope dev_scope(h);
     if (!h || !in || !out || mode < 0 || mode > 3) return fail(h, TTS_ERR_INVALID, "db_convert: bad arguments");
     if (n == 0) return TTS_OK;
     if (mode == 1) {
@@ -1457,13 +1549,13 @@ int tts_db_convert(tts_handle_t h, const float* in, size_t n, int mode, float re
 
 int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_synth_params_t* sp,
                    const float* init_phase, float* wav, float* mel_out, float* align_out, float* linear_out) {
+    DeviceScope dev_scope(h);
     int rc = check_ready(h);
     if (rc) return rc;
     if (!ids || !sp || !wav) return fail(h, TTS_ERR_INVALID, "synthesize: bad arguments");
     const tts_config_t& c = h->cfg;
     const int T = sp->n_steps * c.reduction;
     const int F = 1 + c.n_fft / 2, FP = TTS_GL_FP;
-    if ((rc = denorm_check(h, sp->ref_db, sp->max_db))) return rc;
     if ((rc = gl_prepare(h, T, sp->win_length, sp->hop_length, c.n_fft))) return rc;
     WS(h, "syn.memory", float, (size_t)B * Ts * 2 * c.n_gru_units, memory);
     // The decoder output is double-buffered by call parity: the encoder / decoder of call j+1 (second
@@ -1486,6 +1578,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
             HIPCHK(h, hipStreamCreateWithPriority(&h->front, hipStreamNonBlocking, prio_greatest));
             HIPCHK(h, hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, prio_greatest));
             HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->hold_flags), 2 * sizeof(int)));
+            HIPCHK(h, cu_hold_configure());
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_front_done, hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_post_done[0], hipEventDisableTiming));
@@ -1522,7 +1615,10 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         HIPCHK(h, hipEventRecord(h->ev_front_done, h->front));
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_front_done, 0));
     }
-    if ((rc = postnet_impl(h, mel, B, T, linear, magi, sp->ref_db, sp->max_db, sp->power))) return rc;
+    int* db_flag = nullptr;
+    if (denorm_can_assert(sp->ref_db, sp->max_db) && (rc = denorm_flag_arm(h, &db_flag))) return rc;
+    if ((rc = postnet_impl(h, mel, B, T, linear, magi, sp->ref_db, sp->max_db, sp->power, db_flag))) return rc;
+    if (db_flag && (rc = denorm_flag_read(h))) return rc;   // as the reference: no waveform for such a spectrogram
     if (pipelined) {
         HIPCHK(h, hipEventRecord(h->ev_post_done[parity], h->stream));
         h->post_pending[parity] = true;
@@ -1532,6 +1628,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
 }
 
 int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* bytes) {
+    DeviceScope dev_scope(h);
     if (!h || !name) return TTS_ERR_INVALID;
     auto it = h->ws.find(name);
     if (it == h->ws.end()) return fail(h, TTS_ERR_INVALID, std::string("no workspace buffer ") + name);
@@ -1565,6 +1662,7 @@ int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_worker
 // optionally with the max-pool loader; for tools/gemm_bench.py.
 int tts_debug_gemm(tts_handle_t h, const float* A, const float* Wt, float* C, int M, int N, int Cin, int ktaps, int T,
                    int pool) {
+    DeviceScope dev_scope(h);
     if (!h || !A || !Wt || !C || M < 1 || N < 1 || Cin < 4 || (Cin & 3) || ktaps < 1 || T < 1 || M % T) return TTS_ERR_INVALID;
     GemmGroup g = conv_group(A, Cin, ktaps, T, Wt, nullptr, nullptr, nullptr, C, N, 0, M, N, ACT_NONE, pool);
     const int slices = gemm_splitk_slices(g.K);   // same rule as the CBHG projections
@@ -1579,6 +1677,7 @@ int tts_debug_gemm(tts_handle_t h, const float* A, const float* Wt, float* C, in
 // Diagnostic: occupy `n_wgs` workgroup slots of `lds_kb` KB LDS each for `ms` milliseconds on a private
 // stream (to study how the other kernels behave on a partially occupied GPU).  Not part of the product path.
 int tts_debug_hold(tts_handle_t h, int n_wgs, int lds_kb, double ms) {
+    DeviceScope dev_scope(h);
     if (!h || n_wgs < 1 || lds_kb < 1 || lds_kb > 160) return TTS_ERR_INVALID;
     static hipStream_t dbg = nullptr;
     static int* never = nullptr;
@@ -1589,11 +1688,13 @@ int tts_debug_hold(tts_handle_t h, int n_wgs, int lds_kb, double ms) {
         HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&never), sizeof(int)));
         HIPCHK(h, hipMemset(never, 0, sizeof(int)));
     }
+    HIPCHK(h, cu_hold_configure());
     HIPCHK(h, launch_cu_hold(dbg, n_wgs, never, ms, lds_kb));
     return TTS_OK;
 }
 
 int tts_profile_reset(tts_handle_t h) {
+    DeviceScope dev_scope(h);
     if (!h) return TTS_ERR_INVALID;
     prof_collect(h);
     for (int i = 0; i < ST_COUNT; ++i) {
@@ -1604,6 +1705,7 @@ int tts_profile_reset(tts_handle_t h) {
 }
 
 int tts_profile_get(tts_handle_t h, const char* stage, float* ms_total, int64_t* launches) {
+    DeviceScope dev_scope(h);
     if (!h || !stage) return TTS_ERR_INVALID;
     prof_collect(h);
     for (int i = 0; i < ST_COUNT; ++i)

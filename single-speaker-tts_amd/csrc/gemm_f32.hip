@@ -70,7 +70,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
         const int mm = a_ok[i] ? m : 0;
         a_t[i] = mm % g.T;
         if (g.gather) {
-            a_row[i] = g.A + (size_t)g.gather[mm] * g.lda;
+            // ids outside the table read as a zero row (what TF's GPU embedding_lookup returns) instead of
+            // whatever follows the table in the weight arena; the Python mirror rejects them up front
+            const int id = g.gather[mm];
+            const bool in_table = (unsigned)id < (unsigned)g.gather_rows;
+            a_ok[i] = a_ok[i] && in_table;
+            a_row[i] = g.A + (size_t)(in_table ? id : 0) * g.lda;
         } else {
             a_row[i] = g.A + ((ptrdiff_t)mm - g.padl) * (ptrdiff_t)g.lda;
         }
@@ -205,7 +210,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
                     v = v * sc + sh;
                     if (g.R) v += g.R[(size_t)m * g.ldr + n];
                     if (!DENORM || g.C) g.C[(size_t)m * g.ldc + g.coff + n] = v;
-                    if (DENORM && g.C2) g.C2[(size_t)m * g.ldc2 + n] = denorm_pow(v, g.d_ref, g.d_range, g.d_pow);
+                    if (DENORM && g.C2) {
+                        const float db = denorm_db(v, g.d_ref, g.d_range);
+                        if (g.d_flag && db < -100.0f) *g.d_flag = 1;
+                        g.C2[(size_t)m * g.ldc2 + n] = db_pow(db, g.d_pow);
+                    }
                 }
             }
     }

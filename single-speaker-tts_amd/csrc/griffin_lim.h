@@ -35,6 +35,7 @@ struct GlParams {
     int cls_C[GL_MAX_CLASSES], cls_n[GL_MAX_CLASSES], cls_t0[GL_MAX_CLASSES], cls_slot0[GL_MAX_CLASSES],
         cls_first[GL_MAX_CLASSES], cls_chunks[GL_MAX_CLASSES];
     unsigned* work_counter;  // zeroed counter of THIS launch: the persistent workgroups draw item ids from it
+    unsigned long long* dbg; // tools only (-DGL_TIMELINE builds): [GL waves][64] s_memrealtime stamps of workgroup 0
 };
 
 size_t gl_lds_bytes(const GlParams& p);
@@ -50,7 +51,7 @@ hipError_t launch_tf_to_ft(hipStream_t s, const float* in, float* out, int B, in
 hipError_t launch_phase_init(hipStream_t s, const float* init_ft, uint64_t seed, const float* mag_tf, void* out, int B,
                              int F, int T, int FP);
 hipError_t launch_denorm_power(hipStream_t s, const float* lin, float* mag, size_t rows, int F, int FP,
-                               float ref_db, float max_db, float power);
+                               float ref_db, float max_db, float power, int* below_flag);
 hipError_t launch_peak_normalize(hipStream_t s, float* wav, int B, int n);
 hipError_t launch_peak_scale(hipStream_t s, float* wav, int B, int n, const float* partial, int nparts);
 hipError_t launch_stft(hipStream_t s, const float* wav, int B, int n, int Tf, const float* window, int win, int hop,

@@ -16,7 +16,6 @@
 // with fewer free engines the decoder's launches wait for Griffin-Lim workgroups to exit).  They poll one flag word with s_sleep between polls and ALWAYS terminate: either
 // the flag is set (the decoder finished) or the wall-clock bound expires.
 #include "tts_common.h"
-#include <mutex>
 
 namespace tts {
 
@@ -30,15 +29,14 @@ __global__ __launch_bounds__(64) void cu_hold_kernel(const int* flag, unsigned l
     }
 }
 
+// Function attributes are per device: every handle calls this once on its own device.
+hipError_t cu_hold_configure() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&cu_hold_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 hipError_t launch_cu_hold(hipStream_t s, int n_cus, const int* flag, double timeout_ms, int lds_kb) {
     const unsigned long long ticks = (unsigned long long)(timeout_ms * 1e5);
-    static std::once_flag once;
-    static hipError_t attr_status = hipSuccess;
-    std::call_once(once, [] {
-        attr_status = hipFuncSetAttribute(reinterpret_cast<const void*>(&cu_hold_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    if (attr_status != hipSuccess) return attr_status;
     hipLaunchKernelGGL(cu_hold_kernel, dim3(n_cus), dim3(64), (size_t)lds_kb * 1024, s, flag, ticks);
     return hipGetLastError();
 }

@@ -24,11 +24,16 @@ __device__ __forceinline__ float tanhf_(float x) {
     return 1.0f - 2.0f / (e + 1.0f);
 }
 // reference tacotron/inference.py:96-101,175 + audio/conversion.py:102,51: clip -> dB -> magnitude -> ** power
-__device__ __forceinline__ float denorm_pow(float x, float ref_db, float range_db, float power) {
+__device__ __forceinline__ float denorm_db(float x, float ref_db, float range_db) {
     const float c = fminf(fmaxf(x, 0.f), 1.f);
-    const float db = (c - 1.0f) * range_db + ref_db;
+    return (c - 1.0f) * range_db + ref_db;
+}
+__device__ __forceinline__ float db_pow(float db, float power) {
     // (10^(db/20)) ** power == 2^(db * power * log2(10) / 20): one exp2 instead of exp2 + powf
     return exp2f(db * (power * (0.05f * 3.3219280948873623f)));
+}
+__device__ __forceinline__ float denorm_pow(float x, float ref_db, float range_db, float power) {
+    return db_pow(denorm_db(x, ref_db, range_db), power);
 }
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.0f);
@@ -45,6 +50,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 struct GemmGroup {
     const float* A;
     const int32_t* gather;  // optional: row m reads A + gather[m] * lda (embedding lookup)
+    int gather_rows;        // rows of the gathered table: ids outside [0, gather_rows) read as a zero row
     const float* Wt;        // packed weights [N][K], k contiguous
     const float* bias;      // [N] or null
     const float* scale;     // [N] folded batch-norm scale or null
@@ -60,6 +66,8 @@ struct GemmGroup {
     float* C2;
     int ldc2, N2;
     float d_ref, d_range, d_pow;
+    int* d_flag;            // optional: set to 1 when a de-normalised value lies below -100 dB (reference
+                            // audio/conversion.py:47-49); only passed when the constants allow that at all
     // split-K: this group accumulates only the k tiles [kt0, kt1) (multiples of the tile depth 32; 0, 0 = all of
     // K) and is launched with a plain epilogue into a partial-sum buffer; see launch_gemm_splitk
     int kt0, kt1;
@@ -85,6 +93,7 @@ hipError_t launch_bigru(hipStream_t s, const float* xproj, int xld, const float*
 size_t bigru_wrec_floats(int H, int cudnn);
 
 // ----------------------------------------------------------------------------- CU reservation (reserve.hip)
+hipError_t cu_hold_configure();   // per device, before the first launch_cu_hold
 hipError_t launch_cu_hold(hipStream_t s, int n_cus, const int* flag, double timeout_ms, int lds_kb = 64);
 
 // ----------------------------------------------------------------------------- helpers

@@ -54,92 +54,143 @@
 namespace tts {
 
 // ------------------------------------------------------------------------------------ complex helpers
-typedef float2 cf;
-__device__ __forceinline__ cf cmk(float a, float b) { return make_float2(a, b); }
-__device__ __forceinline__ cf cadd(cf a, cf b) { return cmk(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return cmk(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return cmk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// A complex number is ONE packed value (an aligned 64-bit register pair): gfx950 issues a VALU instruction per
+// wave every ~4 cycles whether it is v_add_f32 or v_pk_add_f32 (tools/valu_microbench2.hip: 1.72 ns against
+// 1.84 ns per instruction and SIMD), so complex add / sub cost one instruction and a complex multiply two
+// (v_pk_mul_f32 + v_pk_fma_f32).  Multiplications by +-i, conjugations and the real / imaginary broadcasts of
+// the multiply are the op_sel / neg_lo / neg_hi source modifiers of the packed instructions; hipcc does not
+// form those from shuffles (it emits v_mov + v_xor), hence the one-line asm statements.  Plain asm, not
+// volatile: the compiler still schedules and removes them like any other pure operation.
+typedef float cf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf cmk(float a, float b) { return (cf){a, b}; }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+__device__ __forceinline__ cf cscale(cf a, float s) { return a * s; }
 __device__ __forceinline__ cf cconj(cf a) { return cmk(a.x, -a.y); }
-__device__ __forceinline__ cf cmul_mi(cf a) { return cmk(a.y, -a.x); }   // a * (-i)
-__device__ __forceinline__ cf cmul_pi(cf a) { return cmk(-a.y, a.x); }   // a * (+i)
-__device__ __forceinline__ cf cscale(cf a, float s) { return cmk(a.x * s, a.y * s); }
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ cf cadd_mi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + (+i) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ cf cadd_pi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// conj(a + i b) = (a.x - b.y, -a.y - b.x)
+__device__ __forceinline__ cf cconj_add_pi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + conj(b), a - conj(b)
+__device__ __forceinline__ cf cadd_conj(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf csub_conj(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * b
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// a * conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
+__device__ __forceinline__ cf cmul_conj(cf a, cf b) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// a * k for a compile-time constant k, which lives in a scalar register pair
+__device__ __forceinline__ cf cmul_k(cf a, cf k) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(k));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "s"(k), "v"(t));
+    return r;
+}
+
+// Workgroup barrier that orders LDS accesses only.  __syncthreads() also waits for every outstanding global
+// load and STORE of the wave (s_waitcnt vmcnt(0)); at the end of phase B that is the full HBM write latency of a
+// frame's spectrum row, three times per chunk, for nothing: no wave ever reads what another wave stored to
+// global memory inside this kernel.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS hand-off between lanes of ONE wave.  The LDS unit executes one wave's DS operations in
     // issue order, so a ds_read issued after a ds_write of the same wave observes it for every
     // lane: no s_waitcnt is needed, only a compiler-level ordering point (the compiler still waits
     // on lgkmcnt before it USES a loaded register).
-#ifdef GL_DRAIN_LDS
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
     asm volatile("" ::: "memory");
-#endif
     __builtin_amdgcn_wave_barrier();
 }
 
-// forward radix-4 butterfly (W4 = -i)
+// forward radix-4 butterfly (W4 = -i): 8 packed adds
 __device__ __forceinline__ void r4(cf& a, cf& b, cf& c, cf& d) {
     const cf s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = csub(b, d);
     a = cadd(s0, s2);
     c = csub(s0, s2);
-    b = cadd(s1, cmul_mi(s3));   // a - i b - c + i d
-    d = cadd(s1, cmul_pi(s3));   // a + i b - c - i d
+    b = cadd_mi(s1, s3);   // a - i b - c + i d
+    d = cadd_pi(s1, s3);   // a + i b - c - i d
+}
+// the same with c standing for (-i) c: the W16^4 twiddle of the 16-point transform folded into the butterfly
+__device__ __forceinline__ void r4_c_mi(cf& a, cf& b, cf& c, cf& d) {
+    const cf s0 = cadd_mi(a, c), s1 = cadd_pi(a, c), s2 = cadd(b, d), s3 = csub(b, d);
+    a = cadd(s0, s2);
+    c = csub(s0, s2);
+    b = cadd_mi(s1, s3);
+    d = cadd_pi(s1, s3);
 }
 
 // forward 16-point DFT in registers, natural order in and out: out[k] = sum_j v[j] W16^{jk}
+// (64 packed adds + 8 complex multiplies by constants = 80 VALU instructions)
 __device__ __forceinline__ void fft16(cf (&v)[16]) {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
     // step 1: for each j1, radix-4 over j2 (elements j1 + 4 j2) -> t[j1][k2] stored at v[j1 + 4 k2]
 #pragma unroll
     for (int j1 = 0; j1 < 4; ++j1) r4(v[j1], v[j1 + 4], v[j1 + 8], v[j1 + 12]);
-    // twiddle t[j1][k2] *= W16^{j1 k2}
-    v[1 + 4] = cmul(v[1 + 4], cmk(C1, -S1));    // W^1
-    v[1 + 8] = cmul(v[1 + 8], cmk(R2, -R2));    // W^2
-    v[1 + 12] = cmul(v[1 + 12], cmk(S1, -C1));  // W^3
-    v[2 + 4] = cmul(v[2 + 4], cmk(R2, -R2));    // W^2
-    v[2 + 8] = cmul_mi(v[2 + 8]);               // W^4 = -i
-    v[2 + 12] = cmul(v[2 + 12], cmk(-R2, -R2)); // W^6
-    v[3 + 4] = cmul(v[3 + 4], cmk(S1, -C1));    // W^3
-    v[3 + 8] = cmul(v[3 + 8], cmk(-R2, -R2));   // W^6
-    v[3 + 12] = cmul(v[3 + 12], cmk(-C1, S1));  // W^9
+    // twiddle t[j1][k2] *= W16^{j1 k2}; W^4 = -i (t[2][2]) is folded into the second butterfly of k2 = 2
+    v[1 + 4] = cmul_k(v[1 + 4], cmk(C1, -S1));    // W^1
+    v[1 + 8] = cmul_k(v[1 + 8], cmk(R2, -R2));    // W^2
+    v[1 + 12] = cmul_k(v[1 + 12], cmk(S1, -C1));  // W^3
+    v[2 + 4] = cmul_k(v[2 + 4], cmk(R2, -R2));    // W^2
+    v[2 + 12] = cmul_k(v[2 + 12], cmk(-R2, -R2)); // W^6
+    v[3 + 4] = cmul_k(v[3 + 4], cmk(S1, -C1));    // W^3
+    v[3 + 8] = cmul_k(v[3 + 8], cmk(-R2, -R2));   // W^6
+    v[3 + 12] = cmul_k(v[3 + 12], cmk(-C1, S1));  // W^9
     // step 2: for each k2, radix-4 over j1 -> out[k2 + 4 k1] ; data for k2 sits at v[4 k2 + j1]
     cf o[16];
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
         cf a = v[4 * k2 + 0], b = v[4 * k2 + 1], c = v[4 * k2 + 2], d = v[4 * k2 + 3];
-        r4(a, b, c, d);
+        if (k2 == 2) r4_c_mi(a, b, c, d);
+        else r4(a, b, c, d);
         o[k2 + 0] = a; o[k2 + 4] = b; o[k2 + 8] = c; o[k2 + 12] = d;
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = o[i];
 }
 
-#ifndef E1S
-#define E1S 80   // row stride (complex) of the first exchange image: 2*E1S = 32 (mod 64) banks
-#endif
-#ifndef E2S
-#define E2S 17
-#endif
-#ifndef EX_CPLX
-#ifdef GL_FFT_LDS_STAGE1
-#define EX_CPLX 1280   // 16 rows of E1S
-#else
-#define EX_CPLX 1088   // 64 rows of E2S (the only exchange image) >= the 1024 bins of the merge pass
-#endif
-#endif
+#define E2S 17     // row stride (complex) of the exchange image: 17 is odd, 8-byte reads and writes are conflict free
+#define EXC 544    // complex numbers per wave: 32 rows of E2S (half of the 64 x 16 exchange image) >= the 513
+                   // bins of half a mirror pass; 4.25 KB per wave -- twelve waves have to fit beside the signal
 
 struct FftTw {
     const cf* a;   // LDS table: a[(k2-1)*64] = W1024^{lane*k2}, k2 = 1..15 (already offset by lane)
     cf b[3];       // W64^{(lane&15)*d}, d = 1..3
     __device__ __forceinline__ cf a_at(int k2) const { return a[(k2 - 1) * 64]; }
 };
-struct FftTwReg {  // the same twiddles held in registers for the whole kernel (no LDS reads inside the FFT)
-    cf a[15];
-    cf b[3];
-    __device__ __forceinline__ cf a_at(int k2) const { return a[k2 - 1]; }
-};
 
-// forward 1024-point complex FFT across one wave.  in: v[j] = z[lane + 64 j]; out: v[c] = Z[lane + 64 c].
 // Exchange a register-index bit with a lane-index bit, for the pair of complex registers (a, b):
 // v_permlane32_swap / v_permlane16_swap transpose the 2 x 2 block {a, b} x {lane bit 5 (or 4) = 0, 1}:
 // afterwards a holds [a.lo | b.lo] and b holds [a.hi | b.hi] (halves of 32 lanes, or rows of 16).
@@ -157,29 +208,20 @@ __device__ __forceinline__ void swap_bit4(cf& a, cf& b) {
 }
 
 // forward 1024-point complex FFT across one wave.  in: v[j] = z[lane + 64 j]; out: v[c] = Z[lane + 64 c].
-// Index split n = lane + 64 j, k = k2 + 16 k1', ...: radix-16 over j in registers, twiddle, then the
-// element (row k2, column lane) has to reach lane (a = lane & 15, kq = k2 & 3) register (k2 >> 2, lane >> 4):
-// a 4 x 4 transpose between the two low register-index bits and the two high lane bits, done with
-// 32 permlane swaps (no LDS); radix-4; the second exchange (a 16 x 16 transpose inside each row of 16
-// lanes) goes through the wave's LDS buffer; radix-16.
-template <typename TW>
-__device__ __forceinline__ void fft1024(cf (&v)[16], cf* ex, const TW& tw, int lane) {
+// Index split n = lane + 64 j, k = k2 + 16 k1', ...: radix-16 over j in registers, twiddle (table in LDS, one
+// ds_read_b64 per point), then the element (row k2, column lane) has to reach lane (a = lane & 15, kq = k2 & 3)
+// register (k2 >> 2, lane >> 4): a 4 x 4 transpose between the two low register-index bits and the two high
+// lane bits, done with 32 permlane swaps (no LDS); radix-4; the second exchange (a 16 x 16 transpose inside each
+// row of 16 lanes: lane L collects row L = 16 d + 4 i + kq of a 64 x 16 image) goes through the wave's LDS
+// buffer in two halves -- rows 0..31 (written from the registers d = 0, 1, read by lanes 0..31), then rows
+// 32..63 -- so that the buffer is 4.25 KB per wave instead of 8.5 KB; radix-16.
+__device__ __forceinline__ void fft1024(cf (&v)[16], cf* ex, const FftTw& tw, int lane) {
+#ifdef GL_ABL_NOFFT
+    return;
+#endif
     fft16(v);
 #pragma unroll
     for (int k2 = 1; k2 < 16; ++k2) v[k2] = cmul(v[k2], tw.a_at(k2));
-#ifdef GL_FFT_LDS_STAGE1
-#pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) ex[k2 * E1S + lane] = v[k2];
-    wave_lds_sync();
-    {
-        const int a = lane & 15, kq = lane >> 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) v[4 * i + b] = ex[(kq + 4 * i) * E1S + a + 16 * b];
-    }
-    wave_lds_sync();
-#else
     // new v[4 i + b] at lane (a, kq) = old v[4 i + kq] at lane (a, b)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -188,26 +230,73 @@ __device__ __forceinline__ void fft1024(cf (&v)[16], cf* ex, const TW& tw, int l
         swap_bit5(v[4 * i + 0], v[4 * i + 2]);
         swap_bit5(v[4 * i + 1], v[4 * i + 3]);
     }
-#endif
     const int a = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         r4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
 #pragma unroll
         for (int d = 1; d < 4; ++d) v[4 * i + d] = cmul(v[4 * i + d], tw.b[d - 1]);
+    }
+    cf* wr = ex + kq * E2S + a;                // row (16 d + 4 i + kq) mod 32, column a
+    const cf* rd = ex + (lane & 31) * E2S;     // row lane mod 32
+    cf nv[16];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) ex[(16 * d + kq + 4 * i) * E2S + a] = v[4 * i + d];
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) wr[(16 * d + 4 * i) * E2S] = v[4 * i + d];
+    wave_lds_sync();
+    if (lane < 32) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) nv[x] = rd[x];
     }
     wave_lds_sync();
 #pragma unroll
-    for (int x = 0; x < 16; ++x) v[x] = ex[lane * E2S + x];
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int d = 2; d < 4; ++d) wr[(16 * (d - 2) + 4 * i) * E2S] = v[4 * i + d];
     wave_lds_sync();
+    if (lane >= 32) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) nv[x] = rd[x];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int x = 0; x < 16; ++x) v[x] = nv[x];
     fft16(v);
 }
 
+// Bins MH - k of a spectrum whose bins k = lane + 64 c this lane holds in z[c]: m[c] = Z[MH - lane - 64 c],
+// staged through the wave's exchange buffer in two halves: the bins below MH / 2 are written first and read by
+// the registers c >= 8, then the bins from MH / 2 on, read by c < 8.  Bin MH itself (wanted by lane 0, c = 0) is
+// in no register: the caller passes it as nyq -- phase A: the Nyquist bin of the row; phase B: Z[0], because
+// the FFT output is MH-periodic.
+__device__ __forceinline__ void mirror_bins(const cf (&z)[16], cf (&m)[16], cf* ex, int lane, cf nyq) {
+#ifdef GL_ABL_NOMIRROR
+#pragma unroll
+    for (int c = 0; c < 16; ++c) m[c] = z[15 - c];
+    return;
+#endif
+    cf* wr = ex + lane;
+    const cf* rd = ex + (512 - lane);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) wr[64 * c] = z[c];          // bins [0, 512)
+    if (lane == 0) ex[512] = z[8];                           // ... and bin 512, its own mirror image
+    wave_lds_sync();
+#pragma unroll
+    for (int c = 8; c < 16; ++c) m[c] = rd[-64 * (c - 8)];   // MH - lane - 64 c = 512 - lane - 64 (c - 8), in [1, 512]
+    wave_lds_sync();
+#pragma unroll
+    for (int c = 8; c < 16; ++c) wr[64 * (c - 8)] = z[c];   // bins [512, 1024) at index k - 512
+    if (lane == 0) ex[512] = nyq;                            // bin 1024 at index 512
+    wave_lds_sync();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) m[c] = rd[-64 * c];          // MH - lane - 64 c - 512 = 512 - lane - 64 c
+    wave_lds_sync();
+}
+
 // ------------------------------------------------------------------------------------ GL iteration
-#define GL_NW 8            // waves per workgroup
-#define GL_THREADS 512
+#define GL_NW 12           // waves per workgroup: three per SIMD (the kernel is held to 168 VGPRs)
+#define GL_THREADS (GL_NW * 64)
 #define NFFT 2048
 #define MH 1024            // NFFT / 2
 
@@ -226,51 +315,95 @@ __device__ __forceinline__ cf unit_phasor(cf z) {
 // The spectra are streamed once per iteration (1.3 GB per launch at the bench size): non-temporal accesses
 // keep them from evicting the decoder's weights and attention memory, which the second stream re-reads
 // every step while this kernel runs.
-#ifdef GL_NO_STREAMING_HINT
-#define GL_STREAM_LOAD(ptr) (*(ptr))
-#define GL_STREAM_STORE(ptr, val) (*(ptr) = (val))
-#else
-typedef float gl_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ cf gl_stream_load(const cf* p) {
-    const gl_f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const gl_f32x2*>(p));
-    return cmk(v.x, v.y);
-}
 __device__ __forceinline__ float gl_stream_load(const float* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void gl_stream_store(cf* p, cf v) {
-    gl_f32x2 t;
-    t.x = v.x; t.y = v.y;
-    __builtin_nontemporal_store(t, reinterpret_cast<gl_f32x2*>(p));
-}
+__device__ __forceinline__ void gl_stream_store(cf* p, cf v) { __builtin_nontemporal_store(v, p); }
 #define GL_STREAM_LOAD(ptr) gl_stream_load(ptr)
 #define GL_STREAM_STORE(ptr, val) gl_stream_store((ptr), (val))
+
+// LDS carve of gl_iter_kernel (bytes):
+//   [twiddles W2048^k, k < 1024: 8 KB][twiddles W1024^{lane k2} as [k2-1][lane]: 7.5 KB]
+//   [window images, 2 sets x 1024 float2: 16 KB][exchange GL_NW x EXC complex: 51 KB][control][signal]
+#define GL_LDS_TWR 0
+#define GL_LDS_TWA (GL_LDS_TWR + 1024 * 8)
+#define GL_LDS_WIN (GL_LDS_TWA + 15 * 64 * 8)
+#define GL_LDS_EX (GL_LDS_WIN + 2 * 1024 * 8)
+#define GL_LDS_CTRL (GL_LDS_EX + GL_NW * EXC * 8)
+// control words
+enum { CT_FLAGS = 0 /* GL_NW overlap-add progress flags */, CT_BNEXT = GL_NW, CT_NEXT_ITEM = GL_NW + 1, CT_WORDS = 16 };
+#define GL_LDS_SIG (GL_LDS_CTRL + CT_WORDS * 4)
+
+#ifdef GL_TIMELINE   // tools only: wall-clock stamps (100 MHz) of workgroup 0's first chunks, one row per wave
+#define GL_TL(IDX)                                                                                          \
+    if (p.dbg && blockIdx.x == 0 && lane == 0 && (IDX) < 64) {                                              \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                          \
+        p.dbg[wave * 64 + (IDX)] = __builtin_amdgcn_s_memrealtime();                                        \
+    }
+#ifdef GL_TIMELINE_FINE   // stamps inside ONE overlap-add round and ONE phase-B frame of the second chunk
+#undef GL_TL
+#define GL_TL(IDX)
+#define GL_TLF(COND, IDX)                                                                                   \
+    if (p.dbg && blockIdx.x == 0 && lane == 0 && (COND)) {                                                  \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                          \
+        p.dbg[wave * 64 + (IDX)] = __builtin_amdgcn_s_memrealtime();                                        \
+    }
+#else
+#define GL_TLF(COND, IDX)
+#endif
+#else
+#define GL_TL(IDX)
+#define GL_TLF(COND, IDX)
 #endif
 
-// LDS control words behind the exchange buffers
-enum { CT_FLAGS = 0 /* GL_NW overlap-add progress flags */, CT_BNEXT = 8, CT_NEXT_ITEM = 9, CT_WORDS = 16 };
+#ifdef GL_ABL_NOOLA   // tools only: time the kernel without the overlap-add traffic
+#define GL_OLA_ADD(dst, val) asm volatile("" :: "v"(val))
+#define GL_OLA_SET(dst, val) asm volatile("" :: "v"(val))
+#define GL_SIG_READ(expr) (1e-3f * (float)lane)
+#else
+#define GL_OLA_ADD(dst, val) ((dst) += (val))
+#define GL_OLA_SET(dst, val) ((dst) = (val))
+#define GL_SIG_READ(expr) (expr)
+#endif
+
+// The three waves of a SIMD (waves w, w + 4, w + 8 of the workgroup) are arbitrated oldest first, which lets the
+// first four waves run ahead and the last four finish alone at the end of a phase.  Rotating a static priority
+// through the three age classes, one step per frame, evens their progress out.
+#ifdef GL_NO_ALTPRIO
+#define GL_ROTATE_PRIO(R_)
+#else
+#define GL_ROTATE_PRIO(R_)                                                            \
+    {                                                                                 \
+        const int pr_ = ((wave >> 2) + (R_)) % 3;                                     \
+        if (pr_ == 0) __builtin_amdgcn_s_setprio(0);                                  \
+        else if (pr_ == 1) __builtin_amdgcn_s_setprio(1);                             \
+        else __builtin_amdgcn_s_setprio(2);                                           \
+    }
+#endif
 
 // One Griffin-Lim iteration (MODE 0: phase_in -> phase_out) or the final iSTFT (MODE 1: phase_in -> wav).
 // WIN_CT / HOP_CT: compile-time window / hop (0 = take them from the parameters); the reference
 // configuration 1102 / 275 gets its own instantiation so that all window-support tests fold away.
 //
-// PERSISTENT workgroups: the grid is one workgroup per compute unit; each keeps its twiddles and windows in
-// registers and pulls work items (utterance, first frame, frame count) from a global counter until the
-// launch's item list is exhausted.  Items are numbered class-major, classes in descending frame count, so
-// the big items go first and the small ones balance the tail (GlParams::cls_*).
+// PERSISTENT workgroups: the grid is one workgroup per compute unit; each keeps its tables in LDS and pulls
+// work items (utterance, first frame, frame count) from a global counter until the launch's item list is
+// exhausted.  Items are numbered class-major, classes in descending frame count, so the big items go first and
+// the small ones balance the tail (GlParams::cls_*).
 template <int MODE, int WIN_CT, int HOP_CT, bool MSE>
 __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int win = WIN_CT ? WIN_CT : p.win;
     const int hop = HOP_CT ? HOP_CT : p.hop;
     const int ncol = (WIN_CT && HOP_CT) ? (WIN_CT + HOP_CT - 1) / (HOP_CT ? HOP_CT : 1) : p.ncol;
-    // carve: [exchange: GL_NW * EX_CPLX cf][control: CT_WORDS int][signal]
-    cf* ex_all = reinterpret_cast<cf*>(smem_raw);
-    int* ctrl = reinterpret_cast<int*>(ex_all + GL_NW * EX_CPLX);
-    float* sig = reinterpret_cast<float*>(ctrl + CT_WORDS);
+    cf* twr_tab = reinterpret_cast<cf*>(smem_raw + GL_LDS_TWR);
+    cf* twa_tab = reinterpret_cast<cf*>(smem_raw + GL_LDS_TWA);
+    cf* win_tab = reinterpret_cast<cf*>(smem_raw + GL_LDS_WIN);
+    cf* ex_all = reinterpret_cast<cf*>(smem_raw + GL_LDS_EX);
+    int* ctrl = reinterpret_cast<int*>(smem_raw + GL_LDS_CTRL);
+    float* sig = reinterpret_cast<float*>(smem_raw + GL_LDS_SIG);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    cf* ex = ex_all + wave * EX_CPLX;
+    cf* ex = ex_all + wave * EXC;
     const int halo = ncol - 1;
     const int wpad = (NFFT - win) >> 1;
     const int L = hop * (p.T - 1);
@@ -278,19 +411,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     // ---------------- one-time setup
     if (tid == 0) ctrl[CT_NEXT_ITEM] = (int)atomicAdd(p.work_counter, 1u);
     if (tid < CT_NEXT_ITEM) ctrl[tid] = 0;
-    // All twiddles live in registers for the whole kernel (every lane uses the same 34 values for every
-    // frame): twr[j] = W2048^{lane + 64 j} for the real-FFT split / merge passes, tw.a[k2-1] =
-    // W1024^{lane k2} and tw.b for the FFT itself.  No table in LDS, no LDS read latency inside a round.
-    cf twr[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) twr[j] = p.tw2048[lane + 64 * j];
-    FftTwReg tw;
-#pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) tw.a[k2 - 1] = p.tables[1024 + (k2 - 1) * 64 + lane];
-#pragma unroll
-    for (int d = 1; d < 4; ++d) tw.b[d - 1] = p.tw1024[16 * (lane & 15) * d];
-    // This lane's window samples (n = 2*(lane + 64 c) + {0,1}) come from p.wlane, a per-lane image
-    // [set][lane][c][e] built by the host (gl_build_wlane; 128 contiguous bytes per lane and set):
+    // Tables every frame needs, shared by the twelve waves: twr[k] = W2048^k for the real-FFT split / merge
+    // passes (lane reads k = lane + 64 j), twa = W1024^{lane k2} for the FFT itself, and the two window images
+    // win[set][m] = (w[2m], w[2m+1]) built by the host (gl_build_wlane):
     //   set 0, analysis window of phase B: w[n] / (2 MH)  (the iFFT scale folded in; unit phasors do not
     //          depend on scale),
     //   set 1, synthesis window of phase A for INTERIOR frames: set 0 / window-sum-square.  librosa's istft
@@ -298,28 +421,25 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     //          neighbours either side all exist that sum depends on the window position only, so the
     //          division folds into the window and the signal in LDS is final as soon as the overlap-add is.
     //          (Frames near the utterance ends take 1 / wss per sample from p.rwss.)
-    // Only one set is live at a time: it is (re)loaded at the start of each phase, which keeps the kernel
-    // inside the 256-register budget of two waves per SIMD.
-    float wreg[16][2];
-#define GL_LOAD_WINDOW(SET)                                                                       \
-    {                                                                                             \
-        const float4* wl_ = reinterpret_cast<const float4*>(p.wlane + ((SET) * 64 + lane) * 32);  \
-        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                        \
-            const float4 w4_ = wl_[q_];   /* slots 2 q_, 2 q_ + 1 */                              \
-            wreg[2 * q_][0] = w4_.x; wreg[2 * q_][1] = w4_.y;                                     \
-            wreg[2 * q_ + 1][0] = w4_.z; wreg[2 * q_ + 1][1] = w4_.w;                             \
-        }                                                                                         \
-        _Pragma("unroll") for (int c_ = 0; c_ < 16; ++c_) {                                       \
-            /* slot statically outside the window support (lane 0's sample nw_, lane 63's nw_ + 126) */ \
-            const int nw_ = 128 * c_ - wpad;                                                      \
-            if (WIN_CT && (nw_ + 127 < 0 || nw_ >= win)) { wreg[c_][0] = 0.f; wreg[c_][1] = 0.f; } \
-        }                                                                                         \
+    for (int i = tid; i < 1024; i += GL_THREADS) twr_tab[i] = reinterpret_cast<const cf*>(p.tw2048)[i];
+    for (int i = tid; i < 15 * 64; i += GL_THREADS) twa_tab[i] = reinterpret_cast<const cf*>(p.tables)[1024 + i];
+    for (int i = tid; i < 1024; i += GL_THREADS) win_tab[i] = reinterpret_cast<const cf*>(p.wlane)[i];
+    for (int i = tid; i < 1024; i += GL_THREADS) {   // synthesis image as (w[2m], -w[2m+1]): the iFFT output is conj(v)
+        const cf w = reinterpret_cast<const cf*>(p.wlane)[1024 + i];
+        win_tab[1024 + i] = cmk(w.x, -w.y);
     }
-    __syncthreads();
+    FftTw tw;
+    tw.a = twa_tab + lane;
+#pragma unroll
+    for (int d = 1; d < 4; ++d) tw.b[d - 1] = reinterpret_cast<const cf*>(p.tw1024)[16 * (lane & 15) * d];
+    const cf* twr = twr_tab + lane;        // twr[64 j] = W2048^{lane + 64 j}
+    const cf* wana = win_tab + lane;       // wana[64 c] = analysis window samples 2 (lane + 64 c) + {0, 1}
+    const cf* wsyn = win_tab + 1024 + lane;
+    lds_barrier();
     int item = __builtin_amdgcn_readfirstlane(ctrl[CT_NEXT_ITEM]);   // wave-uniform: keep it (and all it decodes to) in SGPRs
 
     float warm = 0.f, warm_acc = 0.f;   // see the end of the loop body
-    GL_LOAD_WINDOW(1)                   // synthesis window for the first chunk; reloaded at the end of every phase B
+    int tl_chunk = 0;                   // (timeline builds) chunks this workgroup has finished
     const int carry_len = (2 * halo - 1) * hop + win;   // samples that consecutive chunks of a run share
     while (item < p.n_items) {
         // ---------------- decode the work item (wave-uniform scalar code): a RUN of consecutive frames of one
@@ -337,7 +457,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         const int run_t0 = p.cls_t0[k] + jc * run_len;
         const int slot0 = p.cls_slot0[k] + jc * p.cls_chunks[k];   // ordinal of the run's first chunk in its utterance
         const float* magb = p.mag + (size_t)b * p.T * p.FP;
-        const cf* phb = p.phase_in + (size_t)b * p.T * p.FP;
+        const cf* phb = reinterpret_cast<const cf*>(p.phase_in) + (size_t)b * p.T * p.FP;
         unsigned next_item_reg = 0;
         if (tid == 0) next_item_reg = atomicAdd(p.work_counter, 1u);   // consumed before the first barrier below
         int next_item = p.n_items;
@@ -353,22 +473,32 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         const int R = Rr > ncol ? Rr : ncol;             // overlap-add rounds; wave w owns frames [fa0 + R w, + R)
         const int span = (nA - 1) * hop + win;
         if (tid == 0) ctrl[CT_BNEXT] = 0;                // phase B of the previous chunk is over
+        const int tl0 = tl_chunk * 28;
+        GL_TL(tl0)
 
-        // Prefetch registers for one frame's spectrum row, already in the layout the split pass wants:
-        // gk[j] = X[lane + 64 j] and gm[j] = X[MH - (lane + 64 j)] (the mirrored bins; lane 0 / j 0 is the
-        // Nyquist bin).  Both are coalesced 512-byte wave loads of the same 8 KB row, so the second set
-        // hits in cache, and the row never has to be staged through LDS.  UNCONDITIONAL loads (the frame
-        // index is clamped instead of branching): registers filled under a branch stay in scratch memory,
-        // and hipcc then waits for the loads right after issuing them.
-        cf gk[16], gm[16];
+        // Prefetch registers for one frame's spectrum row: gk[j] = X[lane + 64 j] (sixteen coalesced 512-byte
+        // wave loads = the 8 KB row, read once) and the Nyquist bin X[MH].  The mirrored bins X[MH - k] the
+        // split pass pairs them with come through the wave's exchange buffer (mirror_bins), not from a second
+        // pass over the row: with twelve waves per compute unit the rows in flight no longer fit the caches.
+        // UNCONDITIONAL loads (the frame index is clamped instead of branching): registers filled under a
+        // branch stay in scratch memory, and hipcc then waits for the loads right after issuing them.
+        cf gk[16];
+        float nyq;
+#ifdef GL_ABL_NOLOAD
+#define GL_ABL_LOADS(prow_, tf_)                                                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gk[j_] = cmk(1e-3f * (lane + j_ + tf_), 2e-3f * (lane - j_)); \
+        nyq = 0.5f;
+#else
+#define GL_ABL_LOADS(prow_, tf_)                                                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gk[j_] = prow_[64 * j_];                         \
+        nyq = reinterpret_cast<const float*>(phb + (size_t)tf_ * p.FP + MH)[0];
+#endif
 #define GL_LOAD_FRAME(FA)                                                                  \
     {                                                                                      \
         int tf_ = t0 - halo + (FA);                                                        \
         tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                  \
         const cf* prow_ = phb + (size_t)tf_ * p.FP + lane;                                 \
-        const cf* mrow_ = phb + (size_t)tf_ * p.FP + (MH - lane);                          \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gk[j_] = prow_[64 * j_];                  \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gm[j_] = mrow_[-64 * j_];                 \
+        GL_ABL_LOADS(prow_, tf_)                                                           \
     }
         GL_LOAD_FRAME(fa0 + R * wave)
 
@@ -379,39 +509,43 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         // atomics, no workgroup barriers inside the phase, fixed summation order.  Round 0 STORES (each
         // wave also zeroes the rest of its own region), so the buffer needs no clearing pass.
         for (int r = 0; r < R; ++r) {
-#ifndef GL_NO_ALTPRIO
-            if ((r + (wave >= GL_NW / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
+            GL_ROTATE_PRIO(r)
             const int fa = fa0 + r + R * wave;
             const int tf = t0 - halo + fa;
             const bool ok = fa < nA && tf >= 0 && tf < p.T;
-            cf v[16];
+            cf v[16];   // only defined (and only used) when ok
+            GL_TLF(tl_chunk == 1 && r == 2, 0)
             if (ok) {
+                cf gm[16];
+                mirror_bins(gk, gm, ex, lane, cmk(nyq, 0.f));
+                GL_TLF(tl_chunk == 1 && r == 2, 1)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     cf xk = gk[j];
-                    cf xm = cconj(gm[j]);
-                    if (j == 0 && lane == 0) { xk.y = 0.f; xm.y = 0.f; }   // DC and Nyquist bins are real
+                    cf xr = gm[j];                                         // xm = conj(xr)
+                    if (j == 0 && lane == 0) { xk.y = 0.f; xr.y = 0.f; }   // DC and Nyquist bins are real
                     // Zin = E + i O, E = (xk + xm)/2, O = conj(twr) (xk - xm)/2 ; feed conj(Zin).
                     // The two 1/2 factors are folded into the output scale (the FFT is linear).
-                    const cf e = cadd(xk, xm);
-                    const cf o = cmul(cconj(twr[j]), csub(xk, xm));
-                    const cf zin = cadd(e, cmul_pi(o));
-                    v[j] = cconj(zin);
+                    const cf e = cadd_conj(xk, xr);
+                    const cf o = cmul_conj(csub_conj(xk, xr), twr[64 * j]);
+                    v[j] = cconj_add_pi(e, o);
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = cmk(0.f, 0.f);
             }
             // the row is consumed: fetch the next round's frame into the same registers now, it lands
             // while this frame's FFT runs
+            GL_TLF(tl_chunk == 1 && r == 2, 2)
             if (r + 1 < R) GL_LOAD_FRAME(fa + 1)
             if (ok) {
                 fft1024(v, ex, tw, lane);
+                GL_TLF(tl_chunk == 1 && r == 2, 3)
                 // z[m] = conj(v)/MH, m = lane + 64 c: x[2m] = Re, x[2m+1] = Im
                 if (tf >= halo && tf + halo < p.T) {
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) v[c] = cmk(v[c].x * wreg[c][0], -v[c].y * wreg[c][1]);
+                    for (int c = 0; c < 16; ++c) {
+                        const int nw_ = 128 * c - wpad;   // lane 0's sample; lane 63's is nw_ + 126
+                        if (WIN_CT && (nw_ + 127 < 0 || nw_ >= win)) continue;   // statically outside the window
+                        v[c] = v[c] * wsyn[64 * c];   // the table holds (w[2m], -w[2m+1]): x = conj(v) w
+                    }
                 } else {
                     // frame near an utterance end: fewer overlapping neighbours, take 1 / wss per sample
                     // (rare path; four slots at a time so that its loads do not inflate the register budget)
@@ -423,20 +557,21 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                             const int nw0 = 2 * (lane + 64 * c) - wpad;
                             const bool i0 = nw0 >= 0 && nw0 < win, i1 = nw0 + 1 >= 0 && nw0 + 1 < win;
                             const float r0 = rwp[i0 ? nw0 : 0], r1 = rwp[i1 ? nw0 + 1 : 0];
-                            const float w0 = p.wlane[lane * 32 + 2 * c];
-                            const float w1 = p.wlane[lane * 32 + 2 * c + 1];
-                            v[c] = cmk(v[c].x * w0 * r0, -v[c].y * w1 * r1);
+                            const cf w = wana[64 * c];
+                            v[c] = cmk(v[c].x * w.x * r0, -v[c].y * w.y * r1);
                         }
                         asm volatile("" ::: "memory");
                     }
                 }
             }
+            GL_TLF(tl_chunk == 1 && r == 2, 4)
             const int need = r - (R - ncol);
             if (need > 0 && wave + 1 < GL_NW) {
                 volatile int* flag = ctrl + CT_FLAGS + wave + 1;
                 while (*flag < need) __builtin_amdgcn_s_sleep(1);
             }
             asm volatile("" ::: "memory");
+            GL_TLF(tl_chunk == 1 && r == 2, 5)
             float* sf = sig + fa * hop;
             if (r == 0) {
                 const int lo = fa * hop;
@@ -450,18 +585,18 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
 #pragma unroll
                         for (int c = 0; c < 16; ++c) {
                             const int nw0 = 2 * (lane + 64 * c) - wpad, nw1 = nw0 + 1;
-                            if (nw0 >= 0 && nw0 < win) sf[nw0] += v[c].x;
-                            if (nw1 >= 0 && nw1 < win) sf[nw1] += v[c].y;
+                            if (nw0 >= 0 && nw0 < win) GL_OLA_ADD(sf[nw0], v[c].x);
+                            if (nw1 >= 0 && nw1 < win) GL_OLA_ADD(sf[nw1], v[c].y);
                         }
                     }
                 } else {
-                    int zlo = lo;
-                    if (fa < nA) {
+                    int zlo = lo < span ? lo : span;   // a frame outside the utterance contributes zeros
+                    if (ok) {
 #pragma unroll
                         for (int c = 0; c < 16; ++c) {
                             const int nw0 = 2 * (lane + 64 * c) - wpad, nw1 = nw0 + 1;
-                            if (nw0 >= 0 && nw0 < win) sf[nw0] = v[c].x;
-                            if (nw1 >= 0 && nw1 < win) sf[nw1] = v[c].y;
+                            if (nw0 >= 0 && nw0 < win) GL_OLA_SET(sf[nw0], v[c].x);
+                            if (nw1 >= 0 && nw1 < win) GL_OLA_SET(sf[nw1], v[c].y);
                         }
                         zlo = lo + win;
                     }
@@ -471,18 +606,18 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
                     const int nw0 = 2 * (lane + 64 * c) - wpad, nw1 = nw0 + 1;
-                    if (nw0 >= 0 && nw0 < win) sf[nw0] += v[c].x;
-                    if (nw1 >= 0 && nw1 < win) sf[nw1] += v[c].y;
+                    if (nw0 >= 0 && nw0 < win) GL_OLA_ADD(sf[nw0], v[c].x);
+                    if (nw1 >= 0 && nw1 < win) GL_OLA_ADD(sf[nw1], v[c].y);
                 }
             }
             asm volatile("" ::: "memory");
             if (lane == 0) *reinterpret_cast<volatile int*>(ctrl + CT_FLAGS + wave) = r + 1;
+            GL_TLF(tl_chunk == 1 && r == 2, 6)
+            GL_TL(tl0 + 1 + r)
         }
-        // this wave is done with the synthesis window: fetch the analysis window of phase B into the same
-        // registers now, so that the loads fly while the wave waits for the others at the barrier
-        if (MODE == 0) GL_LOAD_WINDOW(0)
         if (tid == 0 && cq == 0) ctrl[CT_NEXT_ITEM] = (int)next_item_reg;
-        __syncthreads();   // all overlap-adds done (the signal is final), next item published
+        lds_barrier();   // all overlap-adds done (the signal is final), next item published
+        GL_TL(tl0 + 8)
         if (cq == 0) next_item = __builtin_amdgcn_readfirstlane(ctrl[CT_NEXT_ITEM]);
         if (tid < GL_NW) ctrl[CT_FLAGS + tid] = 0;   // nobody looks at the phase-A flags before the next item
         const int ybase = (t0 - halo) * hop + wpad - MH;   // trimmed-signal index of sig[0]
@@ -503,7 +638,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 for (int o = 32; o > 0; o >>= 1) pk = fmaxf(pk, __shfl_xor(pk, o));
                 float* red = reinterpret_cast<float*>(ex_all);   // exchange buffers are idle now
                 if (lane == 0) red[wave] = pk;
-                __syncthreads();
+                lds_barrier();
                 if (tid == 0) {
                     float m = 0.f;
                     for (int w = 0; w < GL_NW; ++w) m = fmaxf(m, red[w]);
@@ -512,15 +647,13 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             }
         } else {
             // ---------------- phase B: forward FFT of the owned frames, new unit phasors
-            cf* pob = p.phase_out + (size_t)b * p.T * p.FP;
+            cf* pob = reinterpret_cast<cf*>(p.phase_out) + (size_t)b * p.T * p.FP;
             float mse_acc = 0.f;
-            // frames are handed out dynamically (LDS counter): the wave that wins issue arbitration on
-            // its SIMD takes more of them, so both waves of a SIMD finish together
+            // frames are handed out dynamically (LDS counter): the waves that win issue arbitration on
+            // their SIMD take more of them, so all waves of a SIMD finish together
             int* b_next = ctrl + CT_BNEXT;
             for (int r = 0;; ++r) {
-#ifndef GL_NO_ALTPRIO
-                if ((r + (wave >= GL_NW / 2 ? 0 : 1)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
+                GL_ROTATE_PRIO(r + 1)
                 int fb = wave + GL_NW * r;   // static map when the per-wave mse sums must have a fixed order
                 if (!MSE) {
                     if (lane == 0) fb = atomicAdd(b_next, 1);
@@ -528,12 +661,17 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 }
                 const int t = t0 + fb;
                 if (fb >= C || t >= p.T) break;   // wave-uniform
+                GL_TLF(tl_chunk == 1 && r == 2, 10)
                 cf v[16];
                 // target magnitudes of this frame (needed only after the FFT: the loads fly meanwhile)
                 const float* mrow = magb + (size_t)t * p.FP;
                 float mg[16];
 #pragma unroll
+#ifdef GL_ABL_NOMAG
+                for (int c = 0; c < 16; ++c) mg[c] = 1.0f + 0.01f * (c + t);
+#else
                 for (int c = 0; c < 16; ++c) mg[c] = fabsf(GL_STREAM_LOAD(mrow + lane + 64 * c));
+#endif
                 const int ylo = t * hop + wpad - MH;          // y index of window sample 0
                 const bool edge = ylo < 0 || ylo + win > L;   // wave-uniform: reflect padding needed
                 if (!edge) {
@@ -543,9 +681,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                         const int n = 2 * (lane + 64 * j);
                         const int nw0 = n - wpad, nw1 = n + 1 - wpad;
                         float x0 = 0.f, x1 = 0.f;
-                        if (nw0 >= 0 && nw0 < win) x0 = wreg[j][0] * sf[nw0];
-                        if (nw1 >= 0 && nw1 < win) x1 = wreg[j][1] * sf[nw1];
-                        v[j] = cmk(x0, x1);
+                        if (!(WIN_CT && (128 * j - wpad + 127 < 0 || 128 * j - wpad >= win))) {
+                            if (nw0 >= 0 && nw0 < win) x0 = GL_SIG_READ(sf[nw0]);
+                            if (nw1 >= 0 && nw1 < win) x1 = GL_SIG_READ(sf[nw1]);
+                        }
+                        v[j] = cmk(x0, x1) * wana[64 * j];
                     }
                 } else {
 #pragma unroll
@@ -553,46 +693,49 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                         const int n = 2 * (lane + 64 * j);
                         float x0 = 0.f, x1 = 0.f;
                         const int nw0 = n - wpad, nw1 = n + 1 - wpad;
+                        const cf w = wana[64 * j];
                         if (nw0 >= 0 && nw0 < win) {
                             int y = ylo + nw0;
                             y = y < 0 ? -y : y;
                             y = y >= L ? 2 * (L - 1) - y : y;
-                            x0 = wreg[j][0] * sig[y - ybase];
+                            x0 = w.x * sig[y - ybase];
                         }
                         if (nw1 >= 0 && nw1 < win) {
                             int y = ylo + nw1;
                             y = y < 0 ? -y : y;
                             y = y >= L ? 2 * (L - 1) - y : y;
-                            x1 = wreg[j][1] * sig[y - ybase];
+                            x1 = w.y * sig[y - ybase];
                         }
                         v[j] = cmk(x0, x1);
                     }
                 }
+                GL_TLF(tl_chunk == 1 && r == 2, 11)
                 fft1024(v, ex, tw, lane);
-#pragma unroll
-                for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
-                wave_lds_sync();
+                GL_TLF(tl_chunk == 1 && r == 2, 12)
+                cf zmr[16];   // Z[MH - k]; lane 0, c 0: Z[0] itself
+                mirror_bins(v, zmr, ex, lane, v[0]);
+                GL_TLF(tl_chunk == 1 && r == 2, 13)
                 cf* orow = pob + (size_t)t * p.FP;
                 // next estimate: target magnitude, new phase.  Fast path: x * (rsq(|x|^2) * |S|), valid
                 // while |x|^2 stays well inside the float range; the min / max of |x|^2 over the lane's
                 // bins are tracked and the (practically never taken) exact path below redoes the frame
                 // otherwise.
                 float s_min = 3.0e38f, s_max = 0.f;
-                cf zmr[16];   // all mirrored bins first: one LDS latency for the pass instead of one per bin
-#pragma unroll
-                for (int c = 0; c < 16; ++c) zmr[c] = ex[(MH - (lane + 64 * c)) & (MH - 1)];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
                     const int k = lane + 64 * c;
                     const cf zk = v[c];
-                    const cf zm = cconj(zmr[c]);
-                    // 2 X[k] = (zk + zm) - i twr (zk - zm); the phase does not care about the factor 2
-                    const cf e = cadd(zk, zm);
-                    const cf o = cmul(twr[c], csub(zk, zm));
-                    const cf x = cadd(e, cmul_mi(o));
+                    // zm = conj(zmr); 2 X[k] = (zk + zm) - i twr (zk - zm); the phase does not care about the factor 2
+                    const cf e = cadd_conj(zk, zmr[c]);
+                    const cf o = cmul(csub_conj(zk, zmr[c]), twr[64 * c]);
+                    const cf x = cadd_mi(e, o);
                     const float s = fmaf(x.x, x.x, x.y * x.y);
                     const float g = __builtin_amdgcn_rsqf(s) * mg[c];   // raw v_rsq_f32: s is range-checked below
-                    GL_STREAM_STORE(orow + k, cmk(x.x * g, x.y * g));
+#ifdef GL_ABL_NOSTORE
+                    asm volatile("" :: "v"(x * g));
+#else
+                    GL_STREAM_STORE(orow + k, x * g);
+#endif
                     s_min = fminf(s_min, s);
                     s_max = fmaxf(s_max, s);
                     if (MSE) {
@@ -602,15 +745,14 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 }
                 if (__builtin_expect(__any(!(s_min > 1.0e-30f && s_max < 1.0e30f)), 0)) {
                     // exact path: zero / tiny / huge bins (angle(0) = 0, range-safe normalisation)
-#pragma unroll 1
+#pragma unroll
                     for (int c = 0; c < 16; ++c) {
                         const int k = lane + 64 * c;
-                        const cf zk = ex[k];
-                        const cf zm = cconj(ex[(MH - k) & (MH - 1)]);
-                        const cf e = cadd(zk, zm);
-                        const cf o = cmul(p.tw2048[k], csub(zk, zm));
-                        const cf x = cadd(e, cmul_mi(o));
-                        orow[k] = cscale(unit_phasor(x), fabsf(mrow[k]));
+                        const cf zk = v[c];
+                        const cf e = cadd_conj(zk, zmr[c]);
+                        const cf o = cmul(csub_conj(zk, zmr[c]), twr[64 * c]);
+                        const cf x = cadd_mi(e, o);
+                        orow[k] = cscale(unit_phasor(x), mg[c]);
                     }
                 }
                 if (lane == 0) {
@@ -623,15 +765,17 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                         mse_acc += d * d;
                     }
                 }
-                wave_lds_sync();
+                GL_TLF(tl_chunk == 1 && r == 2, 14)
+                GL_TL(tl0 + 9 + r)
             }
+            GL_TL(tl0 + 25)
             if (MSE) {
-                __syncthreads();   // all waves done with their exchange buffers
+                lds_barrier();   // all waves done with their exchange buffers
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) mse_acc += __shfl_xor(mse_acc, o);
                 float* red = reinterpret_cast<float*>(ex_all);
                 if (lane == 0) red[wave] = mse_acc;
-                __syncthreads();
+                lds_barrier();
                 if (tid == 0) {
                     float s = 0.f;
                     for (int w = 0; w < GL_NW; ++w) s += red[w];
@@ -643,10 +787,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         // item): one load per lane, each from a different 128-byte line of the spectrum row this wave will
         // need first (its round-0 frame), so that the real loads at the top find the row in L2 instead of
         // waiting for HBM with nothing else to run.  The value is only summed into a dummy, much later.
-        if (MODE == 0) GL_LOAD_WINDOW(1)   // ... and the synthesis window back, under the wait at the end barrier
         warm_acc += warm;
         const bool more = t0 + C < run_t0 + run_len;
-#ifndef GL_NO_WARM
         {
             int bn = b, tfn = -1;
             if (more) {
@@ -672,8 +814,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 warm = row2[32 * lane];   // 64 lanes x 128 B = the first 8 KB of the 8224-byte row
             }
         }
-#endif
-        __syncthreads();   // everyone is done with the signal buffer
+        lds_barrier();   // everyone is done with the signal buffer
+        GL_TL(tl0 + 26)
+        ++tl_chunk;
         if (more) {
             // shift the signal of the frames shared with the next chunk to the front of the buffer
             // (source [C hop, C hop + carry_len) and destination [0, carry_len) do not overlap: the host
@@ -681,7 +824,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             const int src = C * hop;
 #pragma unroll 1
             for (int i = tid; i < carry_len; i += GL_THREADS) sig[i] = sig[src + i];
-            __syncthreads();
+            lds_barrier();
         }
         t0 += C;
       }   // chunks of the run
@@ -689,45 +832,48 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     }
     if (warm_acc == 1.2345e30f) ctrl[CT_WORDS - 1] = 1;   // keeps the warming loads alive; never true in practice
 #undef GL_LOAD_FRAME
-#undef GL_LOAD_WINDOW
+#undef GL_ABL_LOADS
 }
 
 size_t gl_lds_bytes(const GlParams& p) {
     const int halo = p.ncol - 1;
     const int nA = p.C + 2 * halo;
     const int span = (nA - 1) * p.hop + p.win;
-    return (size_t)(GL_NW * EX_CPLX) * sizeof(cf) + CT_WORDS * sizeof(int) + (size_t)((span + 3) & ~3) * sizeof(float);
+    return (size_t)GL_LDS_SIG + (size_t)((span + 3) & ~3) * sizeof(float);
 }
 
+// Window images of the kernel, out[2][1024][2]: out[set][m][e] is the window weight of sample n = 2 m + e of
+// the zero-padded 2048-sample frame.  Set 0: analysis window / n_fft.  Set 1: set 0 times 1 / window-sum-square
+// at an interior frame (all `halo` neighbours either side exist), if there is one.
 void gl_build_wlane(const float* window, const float* rwss, int win, int hop, int T, float* out) {
     const int wpad = (NFFT - win) / 2;
     const int halo = (win + hop - 1) / hop - 1;
-    const int t_ref = halo < T ? halo : T - 1;   // an interior frame (all `halo` neighbours either side exist) if there is one
-    for (int c = 0; c < 16; ++c)
-        for (int e = 0; e < 2; ++e)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int nw = 2 * (lane + 64 * c) + e - wpad;
-                const bool in = nw >= 0 && nw < win;
-                const float w = in ? window[nw] * (0.5f / (float)MH) : 0.f;
-                const float rw = in ? rwss[(size_t)t_ref * hop + wpad + nw] : 0.f;
-                out[(0 * 64 + lane) * 32 + 2 * c + e] = w;
-                out[(1 * 64 + lane) * 32 + 2 * c + e] = w * rw;
-            }
+    const int t_ref = halo < T ? halo : T - 1;
+    for (int n = 0; n < NFFT; ++n) {
+        const int nw = n - wpad;
+        const bool in = nw >= 0 && nw < win;
+        const float w = in ? window[nw] * (0.5f / (float)MH) : 0.f;
+        const float rw = in ? rwss[(size_t)t_ref * hop + wpad + nw] : 0.f;
+        out[n] = w;
+        out[NFFT + n] = w * rw;
+    }
 }
 
-// Largest item size (frames owned per work item) whose signal buffer fits in LDS, at most 64; sizes are
-// 8 R - 2 halo so that the overlap-add rounds of all eight waves are full.
+// Largest chunk (frames owned per pass over the LDS signal buffer) that fits beside the tables and the exchange
+// buffers, at most 64: a multiple of GL_NW, so that the overlap-add rounds of a continuing chunk and the
+// forward transforms of phase B are full.
 int gl_max_item_frames(int win, int hop) {
     GlParams q;
     q.win = win; q.hop = hop;
     q.ncol = (win + hop - 1) / hop;
-    int best = 0;
-    for (int R = q.ncol; R <= 16; ++R) {
-        q.C = GL_NW * R - 2 * (q.ncol - 1);
-        if (q.C > 64) break;
-        if (q.C >= 1 && gl_lds_bytes(q) <= 160 * 1024) best = q.C;
+    int best_any = 0, best_mult = 0;
+    for (int C = 1; C <= 64; ++C) {
+        q.C = C;
+        if (gl_lds_bytes(q) > 160 * 1024) break;
+        best_any = C;
+        if (C % GL_NW == 0) best_mult = C;
     }
-    return best;
+    return best_mult ? best_mult : best_any;
 }
 
 // Work-item schedule of one launch.  Every utterance's T frames are cut into RUNS of consecutive frames
@@ -742,10 +888,10 @@ struct GlCut { int chunk; int nc; int c[GL_MAX_CLASSES]; int n[GL_MAX_CLASSES]; 
 
 // measured cost of a run's first chunk (us, MI355X, reference window / hop) against its owned frames
 double gl_chunk_cost(int frames) {
-    static const int xs[] = {0, 8, 16, 32, 40, 48, 56, 64};
-    static const double ys[] = {18.0, 24.0, 29.5, 45.0, 52.8, 61.0, 71.0, 81.0};
+    static const int xs[] = {0, 12, 24, 36, 48, 60};
+    static const double ys[] = {14.0, 22.0, 33.0, 44.0, 55.0, 66.0};
     const int n = sizeof(xs) / sizeof(xs[0]);
-    if (frames >= xs[n - 1]) return ys[n - 1] + (frames - xs[n - 1]) * 1.25;
+    if (frames >= xs[n - 1]) return ys[n - 1] + (frames - xs[n - 1]) * 0.95;
     int i = 0;
     while (i + 1 < n && frames > xs[i + 1]) ++i;
     return ys[i] + (ys[i + 1] - ys[i]) * (frames - xs[i]) / (double)(xs[i + 1] - xs[i]);
@@ -913,27 +1059,28 @@ hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int n_cus, int final
 // librosa.stft(center=True, reflect, hann) of real signals: one wave per frame, signal read straight
 // from global memory (this is the feature-extraction side, reference audio/features.py:62,145 --
 // not part of the synthesis loop).  out [B][Tf][FP] complex.
-__global__ __launch_bounds__(GL_THREADS) void stft_kernel(const float* __restrict__ wav, int n, int Tf,
-                                                          const float* __restrict__ window, int win, int hop,
-                                                          const cf* __restrict__ tw1024, const cf* __restrict__ tw2048,
-                                                          cf* __restrict__ out, int FP) {
+#define STFT_NW 8
+__global__ __launch_bounds__(STFT_NW * 64) void stft_kernel(const float* __restrict__ wav, int n, int Tf,
+                                                           const float* __restrict__ window, int win, int hop,
+                                                           const cf* __restrict__ tw1024, const cf* __restrict__ tw2048,
+                                                           cf* __restrict__ out, int FP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf* ex_all = reinterpret_cast<cf*>(smem_raw);
-    cf* twR = ex_all + GL_NW * EX_CPLX;
+    cf* twR = reinterpret_cast<cf*>(smem_raw);
     cf* twA = twR + 1024;
-    float* wtab = reinterpret_cast<float*>(twA + 15 * 64);
+    cf* ex_all = twA + 15 * 64;
+    float* wtab = reinterpret_cast<float*>(ex_all + STFT_NW * EXC);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    cf* ex = ex_all + wave * EX_CPLX;
-    for (int i = tid; i < win; i += GL_THREADS) wtab[i] = window[i];
-    for (int i = tid; i < 1024; i += GL_THREADS) twR[i] = tw2048[i];
-    for (int i = tid; i < 15 * 64; i += GL_THREADS) twA[i] = tw1024[(i & 63) * ((i >> 6) + 1)];
+    cf* ex = ex_all + wave * EXC;
+    for (int i = tid; i < win; i += STFT_NW * 64) wtab[i] = window[i];
+    for (int i = tid; i < 1024; i += STFT_NW * 64) twR[i] = tw2048[i];
+    for (int i = tid; i < 15 * 64; i += STFT_NW * 64) twA[i] = tw1024[(i & 63) * ((i >> 6) + 1)];
     FftTw tw;
 #pragma unroll
     for (int d = 1; d < 4; ++d) tw.b[d - 1] = tw1024[16 * (lane & 15) * d];
     tw.a = twA + lane;
     __syncthreads();
     const int b = blockIdx.y;
-    const int t = blockIdx.x * GL_NW + wave;
+    const int t = blockIdx.x * STFT_NW + wave;
     if (t >= Tf) return;
     const float* y = wav + (size_t)b * n;
     const int wpad = (NFFT - win) >> 1;
@@ -956,18 +1103,16 @@ __global__ __launch_bounds__(GL_THREADS) void stft_kernel(const float* __restric
         v[j] = cmk(x[0], x[1]);
     }
     fft1024(v, ex, tw, lane);
-#pragma unroll
-    for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
-    wave_lds_sync();
+    cf zmr[16];
+    mirror_bins(v, zmr, ex, lane, v[0]);
     cf* orow = out + ((size_t)b * Tf + t) * FP;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         const int k = lane + 64 * c;
         const cf zk = v[c];
-        const cf zm = cconj(ex[(MH - k) & (MH - 1)]);
-        const cf e = cscale(cadd(zk, zm), 0.5f);
-        const cf o = cmul(twR[k], cscale(csub(zk, zm), 0.5f));
-        orow[k] = cadd(e, cmul_mi(o));
+        const cf e = cscale(cadd_conj(zk, zmr[c]), 0.5f);
+        const cf o = cmul(cscale(csub_conj(zk, zmr[c]), 0.5f), twR[k]);
+        orow[k] = cadd_mi(e, o);
     }
     if (lane == 0) orow[MH] = cmk(v[0].x - v[0].y, 0.f);
     if (lane < FP - MH - 1) orow[MH + 1 + lane] = cmk(0.f, 0.f);
@@ -980,9 +1125,10 @@ static hipError_t stft_configure() {
 
 hipError_t launch_stft(hipStream_t s, const float* wav, int B, int n, int Tf, const float* window, int win, int hop,
                        const float2* tw1024, const float2* tw2048, float2* out, int FP) {
-    const size_t lds = (size_t)(GL_NW * EX_CPLX + 1024 + 15 * 64) * sizeof(cf) + (size_t)((win + 3) & ~3) * sizeof(float);
-    dim3 grid((Tf + GL_NW - 1) / GL_NW, B);
-    hipLaunchKernelGGL(stft_kernel, grid, dim3(GL_THREADS), lds, s, wav, n, Tf, window, win, hop, tw1024, tw2048, out, FP);
+    const size_t lds = (size_t)(1024 + 15 * 64 + STFT_NW * EXC) * sizeof(cf) + (size_t)((win + 3) & ~3) * sizeof(float);
+    dim3 grid((Tf + STFT_NW - 1) / STFT_NW, B);
+    hipLaunchKernelGGL(stft_kernel, grid, dim3(STFT_NW * 64), lds, s, wav, n, Tf, window, win, hop,
+                       reinterpret_cast<const cf*>(tw1024), reinterpret_cast<const cf*>(tw2048), reinterpret_cast<cf*>(out), FP);
     return hipGetLastError();
 }
 
@@ -1014,7 +1160,7 @@ __global__ void cplx_tf_to_ft_kernel(const cf* in, float* out, int F, int T, int
 hipError_t launch_cplx_tf_to_ft(hipStream_t s, const float2* in, float* out, int B, int F, int T, int FP, int mode,
                                 float power) {
     dim3 grid((T + 31) / 32, (F + 31) / 32, B);
-    hipLaunchKernelGGL(cplx_tf_to_ft_kernel, grid, dim3(32, 8), 0, s, in, out, F, T, FP, mode, power);
+    hipLaunchKernelGGL(cplx_tf_to_ft_kernel, grid, dim3(32, 8), 0, s, reinterpret_cast<const cf*>(in), out, F, T, FP, mode, power);
     return hipGetLastError();
 }
 

@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--T', type=int, default=1000)
     ap.add_argument('--iters', type=int, default=60)
     ap.add_argument('--reps', type=int, default=3)
+    ap.add_argument('--nocheck', action='store_true', help='ablation builds produce garbage')
     a = ap.parse_args()
     sstts = importlib.import_module('single-speaker-tts_amd')
     eng = sstts.Engine()
@@ -37,7 +38,8 @@ def main():
     alg = 20.0 * 1025 * a.T * a.B
     print('gl_iter: {:.1f} us/launch over {} launches -> {:.0f} GB/s algorithmic; gl_final {:.1f} us'.format(
         per * 1e3, n, alg / (per * 1e-3) / 1e9, 1e3 * msf / max(1, nf)))
-    assert np.isfinite(wav.to_host()).all()
+    if not a.nocheck:
+        assert np.isfinite(wav.to_host()).all()
 
 
 if __name__ == '__main__':
