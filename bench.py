@@ -83,6 +83,57 @@ def _cpu_gl_job(args):
     return A.peak_normalize(A.spectrogram_to_wav(mag, WIN, HOP, N_FFT, N_ITER, init_phase=init))
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes, one rank per GPU, wired up
+    the way `python -m torch.distributed.run --nproc-per-node N` would (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT).  The parent never touches the GPU (no HIP call, no torch.cuda): the children are
+    plain subprocesses, nothing is exec'ed over a process that holds a device."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r else None))
+    rc = 0
+    for r, pr in enumerate(procs):
+        pr.wait()
+        rc = rc or pr.returncode
+    return rc
+
+
+def dist_selftest(rank, local_rank, world, dist):
+    """--dist-selftest: everything of the N > 1 path except the GPU work (process group, the one weight broadcast,
+    shard ranges, the max-over-ranks reduction), so that the launcher can be rehearsed on a box without GPUs."""
+    shard = importlib.import_module('single-speaker-tts_amd.sharding')
+    Wm = importlib.import_module('single-speaker-tts_amd.tacotron.weights')
+    n = Wm.n_parameters()
+    blob = Wm.pack_blob(Wm.synthetic_weights(0)) if rank == 0 else np.zeros(n, np.float32)
+    got = shard.broadcast_blob(blob, src=0, device='cpu')
+    import torch
+    t = torch.tensor([float(np.abs(got).sum()), float(rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    lo, hi = shard.shard_range(world * B_PER_GPU, world, rank)
+    ok = abs(float(np.abs(got).sum()) - float(t[0])) < 1e-6 and hi - lo == B_PER_GPU
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(ok))
+    if rank == 0:
+        print(json.dumps({'selftest': 'dist', 'n_gpus': world, 'world_size_seen': dist.get_world_size(),
+                          'backend': dist.get_backend(), 'ok': all(flags)}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -92,7 +143,11 @@ def main():
     ap.add_argument('--pipeline', type=int, default=None, help='override the library default (stream pipelining)')
     ap.add_argument('--reserve-cus', type=int, default=None)
     ap.add_argument('--hold-lds-kb', type=int, default=None)
+    ap.add_argument('--dist-selftest', action='store_true', help='rehearse the N > 1 launch path without GPU work')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -109,8 +164,16 @@ def main():
         n_dev = max(1, torch.cuda.device_count())
         if backend != 'nccl':
             local_rank = local_rank % n_dev
-        torch.cuda.set_device(local_rank)
+        if not args.dist_selftest:
+            torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world)
+        if rank == 0:
+            print('bench: process group up, backend {} world size {}'.format(dist.get_backend(), dist.get_world_size()),
+                  file=sys.stderr, flush=True)
+    if args.dist_selftest:
+        if dist is None:
+            raise SystemExit('--dist-selftest needs --gpus N > 1')
+        return dist_selftest(rank, local_rank, world, dist)
 
     sstts = importlib.import_module('single-speaker-tts_amd')
     P = importlib.import_module('single-speaker-tts_amd.tacotron.params')
@@ -213,6 +276,7 @@ def main():
             'value': frames_total * args.steps / elapsed,
             'unit': 'mel-frames/s',
             'n_gpus': world,
+            'world_size_seen': dist.get_world_size() if dist is not None else 1,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': ms_per_step,

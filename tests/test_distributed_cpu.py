@@ -55,3 +55,19 @@ def test_broadcast_and_shards_world2(tmp_path):
     d0 = np.load(tmp_path / 'digest0.npy')[0]
     d1 = np.load(tmp_path / 'digest1.npy')[0]
     assert d0 == d1 and d0 > 0
+
+
+def test_bench_self_launches_n_ranks(tmp_path):
+    """`python bench.py --gpus 2` without torchrun: the parent spawns two children, which form a gloo group,
+    broadcast the weight blob and report the world size they saw (--dist-selftest skips the GPU work)."""
+    import json
+    import subprocess
+    env = dict(os.environ, SSTTS_DIST_BACKEND='gloo')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dist-selftest'], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1]
+    rec = json.loads(line)
+    assert rec['n_gpus'] == 2 and rec['world_size_seen'] == 2 and rec['ok'] is True
