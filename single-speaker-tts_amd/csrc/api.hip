@@ -860,16 +860,16 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
             std::vector<unsigned long long> host(64 * 16);
             HIPCHK(h, hipMemcpyAsync(host.data(), p.dbg, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
-            unsigned long long t0 = ~0ull;
-            for (auto v : host) if (v && v < t0) t0 = v;
-            for (int w = 0; w < 12; ++w) {
-                fprintf(stderr, "wave %2d:", w);
-                for (int i = 0; i < 64; ++i) {
-                    const unsigned long long v = host[w * 64 + i];
-                    if (v) fprintf(stderr, " [%d]%.1f", i, (double)(v - t0) * 0.01);
-                }
-                fprintf(stderr, "\n");
-            }
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int w = 0; w < 512; ++w) if (host[2 * w]) { t0 = std::min(t0, host[2 * w]); t1 = std::max(t1, host[2 * w + 1]); }
+            std::vector<double> ends, starts;
+            for (int w = 0; w < 512; ++w) if (host[2 * w]) { starts.push_back((host[2 * w] - t0) * 0.01); ends.push_back((host[2 * w + 1] - t0) * 0.01); }
+            std::sort(ends.begin(), ends.end());
+            std::sort(starts.begin(), starts.end());
+            const size_t n = ends.size();
+            double mean = 0; for (double e : ends) mean += e; mean /= n ? n : 1;
+            fprintf(stderr, "workgroups %zu: start last %.1f us; end min %.1f p10 %.1f median %.1f mean %.1f p90 %.1f max %.1f us\n", n,
+                    starts.back(), ends.front(), ends[n / 10], ends[n / 2], mean, ends[n * 9 / 10], ends.back());
             p.dbg = nullptr;
         }
 #endif

@@ -275,6 +275,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     const int wpad = (NFFT - win) >> 1;
     const int L = hop * (p.T - 1);
 
+#ifdef GL_TIMELINE   // tools only: wall-clock (100 MHz) start / end of every workgroup
+    if (p.dbg && tid == 0) p.dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---------------- one-time setup
     if (tid == 0) ctrl[CT_NEXT_ITEM] = (int)atomicAdd(p.work_counter, 1u);
     if (tid < CT_NEXT_ITEM) ctrl[tid] = 0;
@@ -688,6 +691,12 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         item = next_item;
     }
     if (warm_acc == 1.2345e30f) ctrl[CT_WORDS - 1] = 1;   // keeps the warming loads alive; never true in practice
+#ifdef GL_TIMELINE
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 #undef GL_LOAD_FRAME
 #undef GL_LOAD_WINDOW
 }

@@ -24,6 +24,24 @@ namespace tts {
 #define GRU_THREADS 1024
 #define GRU_QPAD 36   // floats per K-quarter of the state in LDS (32 + 4: quarters hit different banks)
 
+// Lane sums with DPP operands (v_add_f32_dpp, no LDS round trip: hipcc lowers __shfl_xor to ds_bpermute_b32, a
+// dependent LDS access per reduction level).  After gru_sum4 every lane of a quad holds the quad's sum; gru_sum8
+// is valid in the first lane of each group of eight.
+template <int CTRL>
+__device__ __forceinline__ float gru_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float gru_sum4(float v) {
+    v += gru_dpp<0xB1>(v);    // quad_perm [1,0,3,2]: lane ^ 1
+    v += gru_dpp<0x4E>(v);    // quad_perm [2,3,0,1]: lane ^ 2
+    return v;
+}
+__device__ __forceinline__ float gru_sum8(float v) {
+    v = gru_sum4(v);
+    v += gru_dpp<0x104>(v);   // row_shl:4: lane i takes lane i + 4
+    return v;
+}
+
 template <int H, bool CUDNN>
 __global__ __launch_bounds__(GRU_THREADS) void bigru_kernel(const float* __restrict__ xproj, int xld,
                                                             const float* __restrict__ wrec,
@@ -88,9 +106,7 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_kernel(const float* __restr
             a2 = fmaf(hv.z, wg[i + 2], a2);
             a3 = fmaf(hv.w, wg[i + 3], a3);
         }
-        float g = (a0 + a1) + (a2 + a3);
-        g += __shfl_xor(g, 1);
-        g += __shfl_xor(g, 2);
+        const float g = gru_sum4((a0 + a1) + (a2 + a3));
         float pc = 0.f;
         if (CUDNN) {
             // candidate's recurrent part does not depend on r here: compute it in the same phase
@@ -104,10 +120,7 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_kernel(const float* __restr
                 p2 = fmaf(hv.z, wc[i + 2], p2);
                 p3 = fmaf(hv.w, wc[i + 3], p3);
             }
-            pc = (p0 + p1) + (p2 + p3);
-            pc += __shfl_xor(pc, 1);
-            pc += __shfl_xor(pc, 2);
-            pc += __shfl_xor(pc, 4);
+            pc = gru_sum8((p0 + p1) + (p2 + p3));
         }
         if (kq == 0) {
             const float gate = sigmoidf_(xg + g);
@@ -133,10 +146,7 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_kernel(const float* __restr
                 p2 = fmaf(hv.z, wc[i + 2], p2);
                 p3 = fmaf(hv.w, wc[i + 3], p3);
             }
-            pc = (p0 + p1) + (p2 + p3);
-            pc += __shfl_xor(pc, 1);
-            pc += __shfl_xor(pc, 2);
-            pc += __shfl_xor(pc, 4);
+            pc = gru_sum8((p0 + p1) + (p2 + p3));
         }
         if (ke == 0) {
             const float c = CUDNN ? tanhf_(xc + rs[cc] * (pc + bch)) : tanhf_(xc + pc);
