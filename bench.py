@@ -35,6 +35,7 @@ WIN, HOP, N_FFT = 1102, 275, 2048
 REF_DB, MAX_DB, POWER = 6.02, 99.89, 1.3
 SR = 22050
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA (v_mfma_f32_32x32x2_f32), same guide
 
 
 def synthetic_ids(B, Ts, seed):
@@ -256,6 +257,23 @@ def main():
     ms_alone, n_alone = eng.profile_get('gl_iter')
     gl_alone_ms = ms_alone / max(1, n_alone)
     mag_alone.free()
+    # second roofline: the MFMA GEMM kernel on the largest post-net layer (first projection: conv1d k=3,
+    # 1024 -> 256 channels, max-pool fused into the loader, M = B*T rows), HIP events around tts_debug_gemm
+    M, N, CIN, KT = B * T, hp.post.projections[0][0], hp.post.n_banks * hp.post.n_filters, 3
+    rng = np.random.default_rng(3)
+    ga = eng.to_device(rng.standard_normal((M + 8, CIN), dtype=np.float32))
+    gw = eng.to_device(rng.standard_normal((N, KT * CIN), dtype=np.float32) * 0.05)
+    gc = eng.empty((M, N))
+    eng._check(eng.lib.tts_debug_gemm(eng.handle, ga.data_ptr(), gw.data_ptr(), gc.data_ptr(), M, N, CIN, KT, T, 1))
+    eng.synchronize()
+    eng.profile_reset()
+    for _ in range(10):
+        eng._check(eng.lib.tts_debug_gemm(eng.handle, ga.data_ptr(), gw.data_ptr(), gc.data_ptr(), M, N, CIN, KT, T, 1))
+    gemm_ms, gemm_n = eng.profile_get('debug_gemm')
+    gemm_ms /= max(1, gemm_n)
+    gemm_flop = 2.0 * M * N * KT * CIN
+    for d in (ga, gw, gc):
+        d.free()
 
     if rank == 0:
         frames_total = world * B_PER_GPU * T
@@ -266,10 +284,13 @@ def main():
         gl_launch_ms = stage_ms['gl_iter'] / max(1, launches['gl_iter'])
         alg_bytes = 20.0 * F * T * B_PER_GPU
         achieved = alg_bytes / (gl_launch_ms * 1e-3) / 1e9 if gl_launch_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC passes of the same build (FETCH_SIZE / WRITE_SIZE cannot be read
+        # inside this process): newest profiles/*gl_iter_hbm_bytes_per_launch.json
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'gl_iter_hbm_bytes_per_launch.json')
-        if os.path.exists(pmc):
-            with open(pmc) as f:
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*gl_iter_hbm_bytes_per_launch.json')))
+        if pmcs:
+            with open(pmcs[-1]) as f:
                 traffic = json.load(f).get('hbm_bytes_per_launch')
         out = {
             'metric': 'mel-frames/sec (end-to-end text->waveform incl. 60-iter Griffin-Lim, 64-utt LJ-Speech-shaped batch per GPU)',
@@ -296,6 +317,11 @@ def main():
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'launch_ms': gl_launch_ms, 'launch_ms_alone': gl_alone_ms,
                          'algorithmic_bytes_per_launch': alg_bytes},
+            'roofline_mfma': {'kernel': 'gemm_f32_kernel (post-net projection 1: conv1d k=3, 1024 -> 256, max-pool in the loader, M = {})'.format(M),
+                              'bound': 'mfma', 'achieved': gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
+                              'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': (gemm_flop / (gemm_ms * 1e-3) / 1e12) / MFMA_F32_PEAK_TFLOPS if gemm_ms > 0 else 0.0,
+                              'traffic': None, 'launch_ms': gemm_ms, 'flop_per_launch': gemm_flop},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(weights, hp)

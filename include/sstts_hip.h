@@ -69,14 +69,21 @@ typedef struct tts_config {
     int32_t force_cudnn;         /* 0: tf GRUCell (TF-CPU parity target); 1: CudnnCompatibleGRUCell */
     /* model_params.attention (tacotron/params/model.py:112-128).  The local mechanism is the reference's
      * experimental LocalLuongAttention (tacotron/attention.py:109-342) in its default sub-mode:
-     * AttentionMode.MONOTONIC + AttentionScore.DOT; PREDICTIVE needs extra variables and its window
-     * padding is inconsistent in the reference, GENERAL/CONCAT raise NotImplementedError there. */
+     * AttentionMode.MONOTONIC or PREDICTIVE with AttentionScore.DOT; GENERAL / CONCAT raise NotImplementedError
+     * in the reference. */
     int32_t attention_mechanism; /* TTS_ATTENTION_LUONG (default) | TTS_ATTENTION_LOCAL_LUONG */
     int32_t luong_local_window_d;/* 10: window = 2D+1 memory positions around the decoder step index */
     int32_t luong_force_gaussian;/* 1: reported alignments are gaussian-weighted (attention.py:73-80) */
+    int32_t luong_local_mode;    /* TTS_LOCAL_MONOTONIC (default): window centre = decoder step index, clamped into
+                                  * the memory; TTS_LOCAL_PREDICTIVE: centre p = T_s sigmoid(v_p^T tanh(W_p h)) per
+                                  * utterance (attention.py:246-258), two more weights in the manifest.  A predicted
+                                  * window that leaves the memory makes tts_decoder_forward / tts_synthesize return
+                                  * TTS_ERR_UNSUPPORTED (the reference fails at run time there, attention.py:288-304);
+                                  * in this mode those calls synchronise the stream to read that condition. */
 } tts_config_t;
 
 enum tts_attention { TTS_ATTENTION_LUONG = 0, TTS_ATTENTION_LOCAL_LUONG = 1 };
+enum tts_local_mode { TTS_LOCAL_MONOTONIC = 0, TTS_LOCAL_PREDICTIVE = 1 };
 
 /* ---- lifecycle ------------------------------------------------------------------------ */
 const char* tts_version(void);
@@ -198,7 +205,8 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
 
 /* ---- profiling -------------------------------------------------------------------------- */
 /* With option "profile"=1 the library brackets its stages with HIP events on the handle's
- * stream.  Stages: "encoder", "decoder", "postnet", "denorm", "gl_iter", "gl_final".
+ * stream.  Stages: "encoder", "decoder", "postnet", "denorm", "gl_iter", "gl_final", "debug_gemm"
+ * (launches of tts_debug_gemm).
  * Returns accumulated milliseconds and the number of kernel launches covered since the last
  * tts_profile_reset.  Synchronises the stream. */
 int tts_profile_reset(tts_handle_t h);

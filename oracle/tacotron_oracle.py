@@ -215,6 +215,38 @@ def local_luong_monotonic(query, keys, values, time, d, force_gaussian):
     return ctx, full
 
 
+def local_luong_predictive(query, keys, values, w_p, v_p, d, force_gaussian):
+    """LocalLuongAttention (PREDICTIVE + DOT) for one decoder step: the window centre is predicted per utterance,
+    p = T_s * sigmoid(v_p^T tanh(W_p h))  (reference tacotron/attention.py:246-258; tensordot(wp, query, [0, 1])
+    transposed is query @ W_p, the second tensordot is tanh(.) @ v_p), the window is [floor(p) - D, floor(p) + D]
+    (:273-286) and everything else is the monotonic path (:288-342, 52-92) with the real-valued p in the gaussian.
+
+    Where a window leaves the memory the reference is not well defined: it pads the (2D+1)-wide alignments with
+    abs(start) zeros in front and abs(stop - T_s) behind (:294-299), which only adds up to T_s for windows inside
+    the memory -- otherwise the rows of the batch get different lengths and tf.stack / the gaussian product
+    (range(window_start, window_stop) has fewer than 2D+1 entries) fail at run time.  That case raises here too.
+    Returns (context (B, units), padded alignments (B, T_s), p (B,))."""
+    B, Ts, _ = keys.shape
+    dt = keys.dtype
+    p = dt.type(Ts) * sigmoid(np.tanh(query @ w_p) @ v_p)[:, 0]          # (B,)
+    centre = np.floor(p).astype(np.int64)
+    start, stop = centre - d, centre + d + 1
+    if (start < 0).any() or (stop > Ts).any():
+        raise ValueError('LocalLuongAttention (predictive): a window leaves the memory; the reference pads such '
+                         'windows inconsistently (tacotron/attention.py:288-304) and fails at run time')
+    ctx = np.zeros((B, values.shape[-1]), dtype=dt)
+    full = np.zeros((B, Ts), dtype=dt)
+    for b in range(B):
+        kwin, vwin = keys[b, start[b]:stop[b]], values[b, start[b]:stop[b]]
+        a = softmax_lastaxis(kwin @ query[b])
+        ctx[b] = a @ vwin
+        if force_gaussian:
+            dist = np.arange(start[b], stop[b], dtype=dt) - p[b]
+            a = a * np.exp(-(dist ** 2) / 2 * dt.type((d / 2) ** 2))
+        full[b, start[b]:stop[b]] = a
+    return ctx, full, p
+
+
 def decoder(memory, w, hp, n_steps=None, trace=None):
     """reference tacotron/model.py:175-334 in Mode.PREDICT (S7, S8).
 
@@ -237,8 +269,10 @@ def decoder(memory, w, hp, n_steps=None, trace=None):
     U = dec.n_decoder_gru_units
     att_hp = getattr(hp, 'attention', None)
     local = att_hp is not None and att_hp.mechanism == 'LocalLuongAttention'
-    if local and (att_hp.luong_local_mode != 'monotonic' or att_hp.luong_local_score != 'dot'):
-        raise NotImplementedError('LocalLuongAttention: monotonic + dot only')
+    if local and (att_hp.luong_local_mode not in ('monotonic', 'predictive') or att_hp.luong_local_score != 'dot'):
+        raise NotImplementedError('LocalLuongAttention: the general / concat scores raise NotImplementedError in '
+                                  'the reference too (tacotron/attention.py:436,464)')
+    predictive = local and att_hp.luong_local_mode == 'predictive'
     keys = memory @ w['decoder2/memory_layer/kernel']
     x = np.zeros((B, dec.target_size), dtype=dt)
     att = np.zeros((B, A), dtype=dt)
@@ -250,7 +284,12 @@ def decoder(memory, w, hp, n_steps=None, trace=None):
         cell_in = np.concatenate([x, att], -1)
         p = pre_net(cell_in, w, _ATT + '/pre_net', dec.pre_net_layers)
         h_att = gru_cell(p, h_att, w, _ATT + '/gru_cell', cudnn)
-        if local:
+        if predictive:
+            score = None
+            ctx, a, _ = local_luong_predictive(h_att, keys, memory, w[_ATT + '/local_luong_attention/local_w_p'],
+                                               w[_ATT + '/local_luong_attention/local_v_p'],
+                                               att_hp.luong_local_window_D, att_hp.luong_force_gaussian)
+        elif local:
             score = None
             ctx, a = local_luong_monotonic(h_att, keys, memory, t, att_hp.luong_local_window_D,
                                            att_hp.luong_force_gaussian)

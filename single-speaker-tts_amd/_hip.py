@@ -42,6 +42,7 @@ class TtsConfig(ctypes.Structure):
         ('n_decoder_gru_units', c_int32), ('n_decoder_gru_layers', c_int32), ('n_mels', c_int32),
         ('reduction', c_int32), ('n_fft', c_int32), ('force_cudnn', c_int32),
         ('attention_mechanism', c_int32), ('luong_local_window_d', c_int32), ('luong_force_gaussian', c_int32),
+        ('luong_local_mode', c_int32),
     ]
 
 
@@ -200,9 +201,11 @@ class Engine(object):
             att = hparams.attention
             if att.mechanism not in ('LuongAttention', 'LocalLuongAttention'):
                 raise NotImplementedError('attention mechanism {!r}'.format(att.mechanism))
-            if att.mechanism == 'LocalLuongAttention' and (att.luong_local_mode != 'monotonic' or
+            if att.mechanism == 'LocalLuongAttention' and (att.luong_local_mode not in ('monotonic', 'predictive') or
                                                            att.luong_local_score != 'dot'):
-                raise NotImplementedError('LocalLuongAttention: only monotonic + dot is implemented')
+                raise NotImplementedError('LocalLuongAttention: the general / concat scores raise '
+                                          'NotImplementedError in the reference too')
+            cfg.luong_local_mode = 1 if att.luong_local_mode == 'predictive' else 0
             cfg.attention_mechanism = 1 if att.mechanism == 'LocalLuongAttention' else 0
             cfg.luong_local_window_d = att.luong_local_window_D
             cfg.luong_force_gaussian = 1 if att.luong_force_gaussian else 0

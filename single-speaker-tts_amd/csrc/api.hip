@@ -44,8 +44,8 @@ struct CbhgWeights {
     const float* gru_rec;     // packed recurrent weights, both directions
 };
 
-enum Stage { ST_ENCODER = 0, ST_DECODER, ST_POSTNET, ST_DENORM, ST_GL_ITER, ST_GL_FINAL, ST_COUNT };
-const char* kStageNames[ST_COUNT] = {"encoder", "decoder", "postnet", "denorm", "gl_iter", "gl_final"};
+enum Stage { ST_ENCODER = 0, ST_DECODER, ST_POSTNET, ST_DENORM, ST_GL_ITER, ST_GL_FINAL, ST_DEBUG_GEMM, ST_COUNT };
+const char* kStageNames[ST_COUNT] = {"encoder", "decoder", "postnet", "denorm", "gl_iter", "gl_final", "debug_gemm"};
 
 struct ProfSpan {
     hipEvent_t a, b;
@@ -256,6 +256,11 @@ void build_manifest(tts_handle_t h) {
     }
     gru_entries(m, std::string(kAtt) + "/gru_cell", n_in, att, cudnn);
     add(m, std::string(kAtt) + "/attention_layer/kernel", {att + mem, att});
+    if (c.attention_mechanism == TTS_ATTENTION_LOCAL_LUONG && c.luong_local_mode == TTS_LOCAL_PREDICTIVE) {
+        // tf.get_variable inside LocalLuongAttention.__call__ (reference tacotron/attention.py:247-250)
+        add(m, std::string(kAtt) + "/local_luong_attention/local_v_p", {att, 1});
+        add(m, std::string(kAtt) + "/local_luong_attention/local_w_p", {att, att});
+    }
     for (int i = 0; i < c.n_decoder_gru_layers; ++i)
         gru_entries(m, std::string(kMrc) + "/cell_" + std::to_string(i + 1) + "/gru_cell",
                     i == 0 ? att : c.n_decoder_gru_units, c.n_decoder_gru_units, cudnn);
@@ -919,6 +924,7 @@ int tts_default_config(tts_config_t* c) {
     c->attention_mechanism = TTS_ATTENTION_LUONG;
     c->luong_local_window_d = 10;
     c->luong_force_gaussian = 1;
+    c->luong_local_mode = TTS_LOCAL_MONOTONIC;
     return TTS_OK;
 }
 
@@ -944,6 +950,8 @@ int tts_create(const tts_config_t* cfg, int device_id, tts_handle_t* out) {
         return fail(nullptr, TTS_ERR_UNSUPPORTED, "attention_mechanism must be TTS_ATTENTION_LUONG or TTS_ATTENTION_LOCAL_LUONG");
     if (c.attention_mechanism == TTS_ATTENTION_LOCAL_LUONG && c.luong_local_window_d < 1)
         return fail(nullptr, TTS_ERR_INVALID, "luong_local_window_d must be >= 1");
+    if (c.luong_local_mode != TTS_LOCAL_MONOTONIC && c.luong_local_mode != TTS_LOCAL_PREDICTIVE)
+        return fail(nullptr, TTS_ERR_INVALID, "luong_local_mode must be TTS_LOCAL_MONOTONIC or TTS_LOCAL_PREDICTIVE");
     if (c.enc_n_banks < 1 || c.post_n_banks < 1 || c.reduction < 1 || c.vocabulary_size < 1 || c.n_highway_layers < 0)
         return fail(nullptr, TTS_ERR_INVALID, "bad counts");
     if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, TTS_ERR_HIP, "hipSetDevice failed");
@@ -1152,6 +1160,12 @@ int tts_finalize_weights(tts_handle_t h) {
     }
     const GruOffsets o_ag = pack_dec_gru(h, p, std::string(kAtt) + "/gru_cell", n_in, att, cudnn);
     const size_t o_al = pack_transposed(p, W(h, std::string(kAtt) + "/attention_layer/kernel").data(), att + mem, att);
+    const bool predictive = c.attention_mechanism == TTS_ATTENTION_LOCAL_LUONG && c.luong_local_mode == TTS_LOCAL_PREDICTIVE;
+    size_t o_wp = 0, o_vp = 0;
+    if (predictive) {
+        o_wp = pack_copy(p, W(h, std::string(kAtt) + "/local_luong_attention/local_w_p").data(), (size_t)att * att);
+        o_vp = pack_copy(p, W(h, std::string(kAtt) + "/local_luong_attention/local_v_p").data(), (size_t)att);
+    }
     GruOffsets o_dg[4];
     for (int i = 0; i < c.n_decoder_gru_layers; ++i)
         o_dg[i] = pack_dec_gru(h, p, std::string(kMrc) + "/cell_" + std::to_string(i + 1) + "/gru_cell",
@@ -1203,6 +1217,9 @@ int tts_finalize_weights(tts_handle_t h) {
     d.n_layers = c.n_decoder_gru_layers; d.att_units = att; d.dec_units = U; d.mem_units = mem;
     d.local_d = c.attention_mechanism == TTS_ATTENTION_LOCAL_LUONG ? c.luong_local_window_d : 0;
     d.local_gaussian = c.luong_force_gaussian != 0;
+    d.local_predictive = predictive ? 1 : 0;
+    d.local_wp = predictive ? base + o_wp : nullptr;
+    d.local_vp = predictive ? base + o_vp : nullptr;
     d.n_mels = c.n_mels; d.reduction = c.reduction;
     d.prenet1_units = c.dec_prenet_units[0]; d.prenet2_units = c.dec_prenet_units[1];
     h->dense_wt = base + o_dw;
@@ -1324,6 +1341,13 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
     sc.yhist = yhist;
     sc.align_raw = align_raw;
     sc.zeros = h->zeros;
+    const bool predictive = h->dec.local_d > 0 && h->dec.local_predictive;
+    if (predictive) {
+        WS(h, "dec.p_hist", float, (size_t)n_steps * B, p_hist);
+        WS(h, "dec.err_flag", int, 4, err_flag);
+        sc.p_hist = p_hist;
+        sc.err_flag = err_flag;
+    }
 
     const int OUT = c.n_mels * c.reduction;
     const int64_t per_step = 2 + 2 + 1 + 1 + 2 * NL;
@@ -1362,7 +1386,19 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
         HIPCHK(h, hipGraphLaunch(h->dec_graph, h->stream));
     }
     // OutputProjectionWrapper for all steps at once: mel[b][t][:] = y[b][t] W_o + b_o
-    return run_single(h, dense_group(yhist, U, h->dec.out_wt, h->dec.out_b, mel, OUT, B * n_steps, OUT, U, ACT_NONE));
+    if ((rc = run_single(h, dense_group(yhist, U, h->dec.out_wt, h->dec.out_b, mel, OUT, B * n_steps, OUT, U, ACT_NONE))))
+        return rc;
+    if (predictive) {
+        // a predicted window that leaves the memory: the reference fails at run time (attention.py:288-304)
+        int flag = 0;
+        HIPCHK(h, hipMemcpyAsync(&flag, sc.err_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (flag)
+            return fail(h, TTS_ERR_UNSUPPORTED,
+                        "LocalLuongAttention (predictive): a predicted attention window leaves the memory; the "
+                        "reference pads such windows inconsistently and fails there too");
+    }
+    return TTS_OK;
 }
 
 // post-net CBHG + final Dense; with mag != null the Dense epilogue also emits the de-normalised,
@@ -1665,6 +1701,7 @@ int tts_debug_gemm(tts_handle_t h, const float* A, const float* Wt, float* C, in
     DeviceScope dev_scope(h);
     if (!h || !A || !Wt || !C || M < 1 || N < 1 || Cin < 4 || (Cin & 3) || ktaps < 1 || T < 1 || M % T) return TTS_ERR_INVALID;
     GemmGroup g = conv_group(A, Cin, ktaps, T, Wt, nullptr, nullptr, nullptr, C, N, 0, M, N, ACT_NONE, pool);
+    ProfScope ps(h, ST_DEBUG_GEMM, 1);
     const int slices = gemm_splitk_slices(g.K);   // same rule as the CBHG projections
     if (slices > 1) {
         WS(h, "debug.splitk", float, (size_t)slices * M * N, part);

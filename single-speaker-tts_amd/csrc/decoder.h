@@ -46,8 +46,11 @@ struct DecoderWeights {
     Gru gru[4];
     const float* out_wt; const float* out_b;             // [r*n_mels][U]
     int n_layers, att_units, dec_units, mem_units, n_mels, reduction, prenet1_units, prenet2_units;
-    int local_d;         // > 0: LocalLuongAttention (monotonic, dot) with window 2*local_d + 1
+    int local_d;         // > 0: LocalLuongAttention (dot score) with window 2*local_d + 1
     int local_gaussian;  // luong_force_gaussian (affects the reported alignments only)
+    int local_predictive;            // window centre predicted per utterance instead of the step index
+    const float* local_wp;           // [A][A]  (row-major as TF stores it: q @ W_p)
+    const float* local_vp;           // [A]
 };
 
 struct DecoderScratch {
@@ -60,6 +63,8 @@ struct DecoderScratch {
     float* yhist;        // [B][n_steps][U]: top-layer outputs of every step (feeds the deferred output projection)
     float* align_raw;    // [n_steps][B][Ts] unnormalised exp(score - part max), used when the caller wants no alignments
     const float* zeros;  // >= n_mels zero floats
+    float* p_hist;       // [n_steps][B] predicted window centres (predictive local attention) or null
+    int* err_flag;       // set to 1 when a predicted window leaves the memory (predictive local attention)
 };
 
 // Enqueues the whole n_steps loop on stream s (capturable: no syncs, no allocations), including

@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const float* __restr
                                                             float* __restrict__ e_out,         // [B][Ts] of this step
                                                             float* __restrict__ parts,         // [PARTS][B][D]
                                                             float* __restrict__ stats,         // [B][PARTS][2] of this step
-                                                            int B, int Ts, int Tp, int w_lo, int w_n) {
+                                                            int B, int Ts, int Tp, int w_lo, int w_n,
+                                                            const float* __restrict__ p_row, int local_d) {
     constexpr int D = 256;
     __shared__ __attribute__((aligned(16))) float qs[D];
     extern __shared__ float sc[];   // Tp scores
@@ -209,7 +210,13 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const float* __restr
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    // the scored positions are [w_lo, w_lo + w_n): the whole memory, or the local window
+    // the scored positions are [w_lo, w_lo + w_n): the whole memory, or the local window -- whose start the
+    // predictive mode derives per utterance from this step's predicted centre (clamped into the memory: a window
+    // that leaves it has already raised the error flag, see dec_predict_centre_kernel)
+    if (p_row) {
+        const int c = (int)floorf(p_row[b]);
+        w_lo = min(max(c - local_d, 0), Ts - w_n);
+    }
     const int j_lo = w_lo + part * Tp;
     const int nj = min(Tp, w_lo + w_n - j_lo);   // may be <= 0 for an empty slice
     qs[tid] = query[(size_t)b * D + tid];
@@ -280,6 +287,40 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const float* __restr
     parts[((size_t)part * B + b) * D + tid] = (c0 + c1) + (c2 + c3);
 }
 
+// LocalLuongAttention in PREDICTIVE mode (reference attention.py:246-258): per utterance
+//   p = T_s * sigmoid( v_p^T tanh(W_p h) ),  window [floor(p) - D, floor(p) + D].
+// One workgroup per utterance: thread n forms (h W_p)[n], the workgroup reduces v_p . tanh(.).  A window that
+// leaves the memory is where the reference stops being well defined (its padding arithmetic, attention.py:288-304,
+// fails at run time): the error flag is raised and the caller reports TTS_ERR_UNSUPPORTED.
+__global__ __launch_bounds__(256) void dec_predict_centre_kernel(const float* __restrict__ query, const float* __restrict__ wp,
+                                                                 const float* __restrict__ vp, float* __restrict__ p_out,
+                                                                 int Ts, int local_d, int* __restrict__ err_flag) {
+    constexpr int A = 256;
+    __shared__ float qs[A];
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    qs[tid] = query[(size_t)b * A + tid];
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int k = 0; k < A; k += 4) {
+        a0 = fmaf(qs[k + 0], wp[(size_t)(k + 0) * A + tid], a0);
+        a1 = fmaf(qs[k + 1], wp[(size_t)(k + 1) * A + tid], a1);
+        a2 = fmaf(qs[k + 2], wp[(size_t)(k + 2) * A + tid], a2);
+        a3 = fmaf(qs[k + 3], wp[(size_t)(k + 3) * A + tid], a3);
+    }
+    float v = tanhf_((a0 + a1) + (a2 + a3)) * vp[tid];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+        const float p = (float)Ts * sigmoidf_((red[0] + red[1]) + (red[2] + red[3]));
+        p_out[b] = p;
+        const int c = (int)floorf(p);
+        if (c - local_d < 0 || c + local_d + 1 > Ts) *err_flag = 1;
+    }
+}
+
 // Window of LocalLuongAttention in MONOTONIC mode at decoder step t (reference attention.py:263-286):
 // p = min(max(t, D), Ts - (D + 1)), window [p - D, p + D + 1).  Needs Ts >= 2D + 1 (checked by the caller).
 __host__ __device__ static inline int local_center(int t, int Ts, int D) {
@@ -295,12 +336,19 @@ __host__ __device__ static inline int local_center(int t, int Ts, int D) {
 // context vector uses the UNweighted window softmax (attention.py:69-71).
 __global__ void dec_align_finalize_kernel(const float* __restrict__ e, const float* __restrict__ stats,
                                           float* __restrict__ align, int B, int Ts, int Tp, int local_d,
-                                          int gaussian) {
+                                          int gaussian, const float* __restrict__ p_hist) {
     const size_t tb = blockIdx.x;   // t * B + b
-    int w_lo = 0, pc = 0;
+    int w_lo = 0;
+    float pc = 0.f;   // window centre as the gaussian sees it: the step index, or the real-valued prediction
     if (local_d > 0) {
-        pc = local_center((int)(tb / B), Ts, local_d);
-        w_lo = pc - local_d;
+        if (p_hist) {
+            pc = p_hist[tb];
+            w_lo = min(max((int)floorf(pc) - local_d, 0), Ts - (2 * local_d + 1));
+        } else {
+            const int c = local_center((int)(tb / B), Ts, local_d);
+            pc = (float)c;
+            w_lo = c - local_d;
+        }
     }
     const float gk = 0.5f * (0.5f * local_d) * (0.5f * local_d);
     const float* st = stats + tb * TTS_ATT_PARTS * 2;
@@ -325,7 +373,7 @@ __global__ void dec_align_finalize_kernel(const float* __restrict__ e, const flo
             for (int i = 1; i < TTS_ATT_PARTS; ++i) wp = part == i ? w[i] : wp;
             a = e[tb * Ts + j] * wp * inv;
             if (local_d > 0 && gaussian) {
-                const float dist = (float)(j - pc);
+                const float dist = (float)j - pc;
                 a *= __expf(-(dist * dist) * gk);
             }
         }
@@ -387,6 +435,7 @@ hipError_t decoder_enqueue(hipStream_t s, const DecoderWeights& w, const Decoder
     hipError_t e;
     // zero states (attention, cell states): TF zero_state
     if ((e = hipMemsetAsync(sc.state, 0, sc.state_bytes, s)) != hipSuccess) return e;
+    if (LD > 0 && w.local_predictive && (e = hipMemsetAsync(sc.err_flag, 0, sizeof(int), s)) != hipSuccess) return e;
     float* e_buf = sc.align_raw;
     for (int t = 0; t < n_steps; ++t) {
         // PrenetWrapper on concat([x_t, attention_{t-1}])   (wrappers.py:122-124)
@@ -409,9 +458,17 @@ hipError_t decoder_enqueue(hipStream_t s, const DecoderWeights& w, const Decoder
         //  reference attention.py:563, which then scores only the window around it)
         float* stats_t = sc.att_stats + (size_t)t * B * TTS_ATT_PARTS * 2;
         const int w_lo = LD > 0 ? local_center(t, Ts, LD) - LD : 0;
+        const float* p_row = nullptr;
+        if (LD > 0 && w.local_predictive) {
+            float* p_t = sc.p_hist + (size_t)t * B;
+            hipLaunchKernelGGL(dec_predict_centre_kernel, dim3(B), dim3(256), 0, s, sc.h_att, w.local_wp, w.local_vp, p_t,
+                               Ts, LD, sc.err_flag);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            p_row = p_t;
+        }
         hipLaunchKernelGGL(dec_attention_kernel, dim3(TTS_ATT_PARTS, B), dim3(256), (size_t)Tp * sizeof(float), s,
                            sc.h_att, keys, memory, e_buf + (size_t)t * B * Ts, sc.ctx_parts, stats_t, B, Ts, Tp, w_lo,
-                           Wn);
+                           Wn, p_row, LD);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         // attention_layer(concat([cell_output, context])), no bias; context merged from the parts
         DecGemm al = mk(sc.h_att, A, A, sc.ctx_parts, w.mem_units, w.attn_layer_wt, nullptr, B, A, A + w.mem_units);
@@ -434,7 +491,7 @@ hipError_t decoder_enqueue(hipStream_t s, const DecoderWeights& w, const Decoder
     }
     if (align) {
         hipLaunchKernelGGL(dec_align_finalize_kernel, dim3(n_steps * B), dim3(64), 0, s, e_buf, sc.att_stats, align, B,
-                           Ts, Tp, LD, w.local_gaussian);
+                           Ts, Tp, LD, w.local_gaussian, (LD > 0 && w.local_predictive) ? sc.p_hist : nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return hipSuccess;

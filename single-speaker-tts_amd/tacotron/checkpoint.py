@@ -189,6 +189,77 @@ def latest_checkpoint(checkpoint_dir):
 
 _SLOT = re.compile(r'/(Adam(_\d+)?|Momentum|RMSProp(_\d+)?|ExponentialMovingAverage)$')
 
+# ------------------------------------------------------------------------------------------ CudnnGRU parameters
+# With force_cudnn=True (the shipped default, params/model.py:51) the CBHG bi-GRUs are tf.contrib.cudnn_rnn.CudnnGRU
+# layers (reference tacotron/layers.py:560-577) whose trainable variable is ONE opaque buffer.  TF 1.8 saves it
+# through CudnnGRUSaveable in the "canonical" form of CudnnCompatibleGRUCell [TF-1.8 contrib/cudnn_rnn/python/ops/
+# cudnn_rnn_ops.py]: per direction ``<scope>/stack_bidirectional_rnn/cell_0/bidirectional_rnn/{fw,bw}/
+# cudnn_compatible_gru_cell/{gates/{kernel,bias}, candidate/{input,hidden}_projection/{kernel,bias}}``.  Both forms
+# are accepted: canonical names are renamed onto the manifest, a raw opaque buffer is unpacked first.
+_CUDNN_CANON = re.compile(r'^(?P<scope>.*?)/(?:gru/)?(?:cudnn_gru/)?stack_bidirectional_rnn/cell_0/bidirectional_rnn/'
+                          r'(?P<d>fw|bw)/cudnn_compatible_gru_cell/(?P<rest>.+)$')
+_CUDNN_OPAQUE = re.compile(r'^(?P<scope>.*?)/(?:gru/)?(?:cudnn_gru/)?opaque_kernel$')
+
+
+def cudnn_gru_opaque_to_canonical(opaque, input_size, num_units, bidirectional=True):
+    """Unpack a one-layer cuDNN GRU parameter buffer into CudnnCompatibleGRUCell tensors.
+
+    cuDNN's layout (what cudnnGetRNNLinLayerMatrixParams walks, and what TF's CudnnGRUSaveable assumes): the
+    weight matrices of every pseudo-layer first (forward, then backward), then the biases of every pseudo-layer;
+    inside a pseudo-layer the input matrices W_r, W_u, W_c (each (num_units, input_size)) come before the
+    recurrent matrices R_r, R_u, R_c (each (num_units, num_units)), the biases likewise bW_r, bW_u, bW_c, bR_r,
+    bR_u, bR_c.  Gate order r (reset), u (update, cuDNN's z), c (candidate, cuDNN's h).
+
+    TF canonical form: gates/kernel = [[W_r; R_r]^T | [W_u; R_u]^T] with rows ordered [input ; state], gates/bias
+    = bW + bR; candidate/input_projection = (W_c^T, bW_c); candidate/hidden_projection = (R_c^T, bR_c) -- the
+    CudnnCompatibleGRUCell formulation c = tanh(x W_c + b_Wc + r * (h R_c + b_Rc)).
+
+    Returns {'fw' | 'bw': {suffix: array}}."""
+    opaque = np.asarray(opaque, dtype=np.float32).reshape(-1)
+    dirs = ('fw', 'bw') if bidirectional else ('fw',)
+    n_w = 3 * num_units * input_size + 3 * num_units * num_units
+    n_b = 6 * num_units
+    need = len(dirs) * (n_w + n_b)
+    if opaque.size < need:
+        raise ValueError('opaque CudnnGRU buffer has {} floats, a {}-directional {}->{} layer needs {}'.format(
+            opaque.size, len(dirs), input_size, num_units, need))
+    out = {}
+    for di, d in enumerate(dirs):
+        w = opaque[di * n_w:(di + 1) * n_w]
+        b = opaque[len(dirs) * n_w + di * n_b:len(dirs) * n_w + (di + 1) * n_b]
+        wi = w[:3 * num_units * input_size].reshape(3, num_units, input_size)
+        wr = w[3 * num_units * input_size:].reshape(3, num_units, num_units)
+        bw, br = b[:3 * num_units].reshape(3, num_units), b[3 * num_units:].reshape(3, num_units)
+        out[d] = {
+            'gates/kernel': np.concatenate([np.concatenate([wi[0].T, wr[0].T], 0), np.concatenate([wi[1].T, wr[1].T], 0)], 1),
+            'gates/bias': np.concatenate([bw[0] + br[0], bw[1] + br[1]]),
+            'candidate/input_projection/kernel': np.ascontiguousarray(wi[2].T),
+            'candidate/input_projection/bias': bw[2].copy(),
+            'candidate/hidden_projection/kernel': np.ascontiguousarray(wr[2].T),
+            'candidate/hidden_projection/bias': br[2].copy(),
+        }
+    return out
+
+
+def expand_cudnn_gru(tensors, hparams=None):
+    """CudnnGRU variables of a checkpoint -> manifest names (``<scope>/gru/{fw,bw}/gru_cell_{fw,bw}/...``)."""
+    hp = hparams or ModelParams()
+    out = dict(tensors)
+    for name, arr in tensors.items():
+        m = _CUDNN_CANON.match(name)
+        if m:
+            out['{}/gru/{}/gru_cell_{}/{}'.format(m.group('scope'), m.group('d'), m.group('d'), m.group('rest'))] = arr
+            continue
+        m = _CUDNN_OPAQUE.match(name)
+        if m:
+            # input of the bi-GRU = the highway width, units = n_gru_units (reference layers.py:555-566)
+            canon = cudnn_gru_opaque_to_canonical(arr, hp.encoder.n_highway_units, hp.encoder.n_gru_units, True)
+            for d, parts in canon.items():
+                for suffix, v in parts.items():
+                    out['{}/gru/{}/gru_cell_{}/{}'.format(m.group('scope'), d, d, suffix)] = v
+    return out
+
+
 
 def select_model_variables(tensors, hparams=None, aliases=None):
     """Pick the manifest's variables out of a checkpoint's tensors.
@@ -200,6 +271,8 @@ def select_model_variables(tensors, hparams=None, aliases=None):
     m = manifest(hp)
     aliases = aliases or {}
     out = {}
+    if hp.force_cudnn:
+        tensors = expand_cudnn_gru(tensors, hp)
     for name, arr in tensors.items():
         if _SLOT.search(name) or name in ('global_step', 'beta1_power', 'beta2_power'):
             continue
@@ -211,9 +284,8 @@ def select_model_variables(tensors, hparams=None, aliases=None):
     missing = [k for k in m if k not in out]
     if missing:
         hint = ''
-        if any('cudnn' in n.lower() for n in tensors):
-            hint = (' (the checkpoint holds CudnnGRU opaque parameters: re-save it with '
-                    'CudnnCompatibleGRUCell variables, force_cudnn=True)')
+        if any('cudnn' in n.lower() or 'opaque_kernel' in n for n in tensors) and not hp.force_cudnn:
+            hint = ' (the checkpoint holds CudnnGRU parameters: load it with hparams.force_cudnn = True)'
         raise KeyError('checkpoint lacks {} model variables, e.g. {}{}'.format(len(missing), missing[:3], hint))
     return out
 

@@ -50,7 +50,7 @@ class AttentionParams:
     tacotron/attention.py:14-29) are spelled as lower-case strings."""
     mechanism: str = 'LuongAttention'          # | 'LocalLuongAttention'
     luong_local_score: str = 'dot'             # 'general' / 'concat' raise NotImplementedError in the reference
-    luong_local_mode: str = 'monotonic'        # 'predictive' is not implemented here
+    luong_local_mode: str = 'monotonic'        # or 'predictive' (p = S sigmoid(v_p^T tanh(W_p h)), attention.py:246-258)
     luong_force_gaussian: bool = True
     luong_local_window_D: int = 10
 

@@ -92,6 +92,11 @@ def manifest(hp=None):
         n_in = units
     _gru_entries(m, _ATT + '/gru_cell', n_in, att, cudnn)
     m[_ATT + '/attention_layer/kernel'] = (att + mem, att)
+    a_hp = getattr(hp, 'attention', None)
+    if a_hp is not None and a_hp.mechanism == 'LocalLuongAttention' and a_hp.luong_local_mode == 'predictive':
+        # tf.get_variable calls inside LocalLuongAttention.__call__ (reference tacotron/attention.py:247-250)
+        m[_ATT + '/local_luong_attention/local_v_p'] = (att, 1)
+        m[_ATT + '/local_luong_attention/local_w_p'] = (att, att)
     for i in range(dec.n_gru_layers):
         _gru_entries(m, '{}/cell_{}/gru_cell'.format(_MRC, i + 1),
                      att if i == 0 else dec.n_decoder_gru_units, dec.n_decoder_gru_units, cudnn)
@@ -124,7 +129,7 @@ def synthetic_weights(seed=0, hp=None, dtype=np.float32):
         if name == 'encoder/embedding':
             lim = np.sqrt(6.0 / (shape[0] + shape[1]))
             w = rng.uniform(-lim, lim, shape)
-        elif leaf == 'kernel':
+        elif leaf in ('kernel', 'local_w_p', 'local_v_p'):
             fan_out = shape[-1]
             fan_in = int(np.prod(shape[:-1]))
             w = rng.normal(0.0, np.sqrt(2.0 / (fan_in + fan_out)), shape)

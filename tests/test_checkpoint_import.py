@@ -63,3 +63,84 @@ def test_latest_checkpoint_and_model_variable_selection(tmp_path, weights, hpara
     write_tensor_bundle(str(tmp_path / 'bad'), bad, block_entries=16)
     with pytest.raises(ValueError):
         C.load_checkpoint(str(tmp_path / 'bad'), hparams)
+
+
+def _torch_gru_as_cudnn_opaque(gru):
+    """The parameters of a one-layer torch.nn.GRU laid out as cuDNN's opaque buffer: weights of every direction
+    first ([W_r W_u W_c | R_r R_u R_c], torch's gate order r, z, n is cuDNN's), then the biases."""
+    ws, bs = [], []
+    for suf in ('', '_reverse') if gru.bidirectional else ('',):
+        ws += [getattr(gru, 'weight_ih_l0' + suf).detach().numpy().reshape(-1),
+               getattr(gru, 'weight_hh_l0' + suf).detach().numpy().reshape(-1)]
+        bs += [getattr(gru, 'bias_ih_l0' + suf).detach().numpy(), getattr(gru, 'bias_hh_l0' + suf).detach().numpy()]
+    return np.concatenate(ws + bs).astype(np.float32)
+
+
+def test_cudnn_opaque_buffer_unpacks_to_the_cell_torch_computes():
+    """CudnnGRU's opaque parameters -> CudnnCompatibleGRUCell tensors (reference tacotron/layers.py:560-577,
+    force_cudnn=True): checked against torch.nn.GRU, which runs the same cuDNN formulation from the same layout."""
+    import torch
+    from oracle import tacotron_oracle as O
+    C = pkg('tacotron.checkpoint')
+    torch.manual_seed(0)
+    n_in, U, B, T = 6, 5, 3, 7
+    gru = torch.nn.GRU(n_in, U, batch_first=True, bidirectional=True)
+    canon = C.cudnn_gru_opaque_to_canonical(_torch_gru_as_cudnn_opaque(gru), n_in, U, True)
+    w = {'gru/{}/gru_cell_{}/{}'.format(d, d, k): v.astype(np.float64) for d, parts in canon.items() for k, v in parts.items()}
+    assert w['gru/fw/gru_cell_fw/gates/kernel'].shape == (n_in + U, 2 * U)
+    x = np.random.default_rng(1).standard_normal((B, T, n_in))
+    ref, _ = gru.double()(torch.tensor(x))
+    assert np.allclose(O.bi_gru(x, w, 'gru', U, cudnn=True), ref.detach().numpy(), atol=1e-6)
+    with pytest.raises(ValueError):
+        C.cudnn_gru_opaque_to_canonical(np.zeros(10, np.float32), n_in, U, True)
+
+
+def test_cudnn_checkpoints_load_in_both_saved_forms(tmp_path):
+    """A force_cudnn=True checkpoint holds the CBHG bi-GRUs either as TF's canonical CudnnCompatibleGRUCell tensors
+    (what CudnnGRUSaveable writes) or as the raw opaque buffer; both must give the manifest's variables."""
+    import copy
+    C = pkg('tacotron.checkpoint')
+    W = pkg('tacotron.weights')
+    hp = copy.deepcopy(pkg('tacotron.params').ModelParams())
+    hp.force_cudnn = True
+    weights = W.synthetic_weights(3, hp)
+    U, H = hp.encoder.n_highway_units, hp.encoder.n_gru_units
+
+    def gru_keys(scope, d):
+        return [k for k in weights if k.startswith('{}/gru/{}/gru_cell_{}/'.format(scope, d, d))]
+
+    # (1) canonical names
+    canon = {}
+    for k, v in weights.items():
+        for scope in ('encoder', 'post_process'):
+            for d in ('fw', 'bw'):
+                pre = '{}/gru/{}/gru_cell_{}/'.format(scope, d, d)
+                if k.startswith(pre):
+                    k = '{}/gru/cudnn_gru/stack_bidirectional_rnn/cell_0/bidirectional_rnn/{}/cudnn_compatible_gru_cell/{}'.format(
+                        scope, d, k[len(pre):])
+        canon[k] = v
+    assert not any('/gru_cell_fw/' in k and k.startswith('encoder/gru') for k in canon)
+    write_tensor_bundle(str(tmp_path / 'canon'), canon, block_entries=16)
+    got = C.load_checkpoint(str(tmp_path / 'canon'), hp)
+    assert set(got) == set(weights) and all(np.array_equal(got[k], weights[k]) for k in weights)
+    # (2) opaque buffers, built by inverting the documented layout
+    opaque = {k: v for k, v in weights.items() if '/gru/fw/gru_cell_fw/' not in k and '/gru/bw/gru_cell_bw/' not in k
+              or k.startswith('decoder2')}
+    for scope in ('encoder', 'post_process'):
+        ws, bs = [], []
+        for d in ('fw', 'bw'):
+            pre = '{}/gru/{}/gru_cell_{}/'.format(scope, d, d)
+            gk, gb = weights[pre + 'gates/kernel'], weights[pre + 'gates/bias']
+            wi = [gk[:U, :H].T, gk[:U, H:].T, weights[pre + 'candidate/input_projection/kernel'].T]
+            wr = [gk[U:, :H].T, gk[U:, H:].T, weights[pre + 'candidate/hidden_projection/kernel'].T]
+            ws += [np.concatenate([m.reshape(-1) for m in wi]), np.concatenate([m.reshape(-1) for m in wr])]
+            # gates bias: cuDNN keeps two biases that TF adds up; put everything into the input-side one
+            bs += [np.concatenate([gb[:H], gb[H:], weights[pre + 'candidate/input_projection/bias']]),
+                   np.concatenate([np.zeros(2 * H, np.float32), weights[pre + 'candidate/hidden_projection/bias']])]
+        opaque['{}/gru/cudnn_gru/opaque_kernel'.format(scope)] = np.concatenate(ws + bs).astype(np.float32)
+    write_tensor_bundle(str(tmp_path / 'opaque'), opaque, block_entries=16)
+    got = C.load_checkpoint(str(tmp_path / 'opaque'), hp)
+    assert set(got) == set(weights) and all(np.array_equal(got[k], weights[k]) for k in weights)
+    # the GRUCell configuration cannot take such a checkpoint: the error says why
+    with pytest.raises(KeyError, match='force_cudnn'):
+        C.load_checkpoint(str(tmp_path / 'opaque'), pkg('tacotron.params').ModelParams())

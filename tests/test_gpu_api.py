@@ -195,3 +195,48 @@ def test_serve_helpers(weights, tmp_path):
         P.model_params.decoder.maximum_iterations = 1000
         P.model_params.reconstruction_iterations = 50
     assert len(first) == 2 and len(second) == 1 and first[0].shape == (275 * 19,) and np.isfinite(first[1]).all()
+
+
+@pytest.mark.parametrize('cudnn', [False, True])
+def test_weights_through_the_checkpoint_importer_equal_the_dict_path(tmp_path, cudnn):
+    """load_checkpoint -> tts_set_weight gives bit-identical results to handing the same tensors over directly,
+    for the GRUCell layout and for a force_cudnn checkpoint that stores the CBHG bi-GRUs the way CudnnGRUSaveable
+    does (reference tacotron/inference.py:44-55,71; layers.py:560-577)."""
+    import copy
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tf_bundle_writer import write_tensor_bundle
+    C = pkg('tacotron.checkpoint')
+    W = pkg('tacotron.weights')
+    hp = copy.deepcopy(pkg('tacotron.params').ModelParams())
+    hp.force_cudnn = cudnn
+    weights = W.synthetic_weights(5, hp)
+    ck = {}
+    for k, v in weights.items():
+        if cudnn:
+            for scope in ('encoder', 'post_process'):
+                for d in ('fw', 'bw'):
+                    pre = '{}/gru/{}/gru_cell_{}/'.format(scope, d, d)
+                    if k.startswith(pre):
+                        k = '{}/gru/cudnn_gru/stack_bidirectional_rnn/cell_0/bidirectional_rnn/{}/cudnn_compatible_gru_cell/{}'.format(
+                            scope, d, k[len(pre):])
+        ck[k] = v
+    ck['global_step'] = np.array(215000, dtype=np.int64)
+    run = tmp_path / 'run'
+    run.mkdir()
+    write_tensor_bundle(str(run / 'model.ckpt-215000'), ck, block_entries=16)
+    (run / 'checkpoint').write_text('model_checkpoint_path: "model.ckpt-215000"\n')
+    loaded = C.load_checkpoint(str(run), hp)
+    ids = np.random.default_rng(0).integers(2, 39, (2, 11)).astype(np.int32)
+    ids[:, -1] = 1
+    outs = []
+    for w in (weights, loaded):
+        eng = pkg().Engine(hp)
+        eng.load_weights(w)
+        mem = eng.encoder_forward(ids)
+        mel, al = eng.decoder_forward(mem, 6)
+        lin = eng.postnet_forward(mel.to_host().reshape(2, 30, 80))
+        outs.append((mem.to_host(), mel.to_host(), al.to_host(), lin.to_host()))
+        eng.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)

@@ -110,3 +110,60 @@ def test_local_end_to_end_synthesize(hparams, weights, weights64):
         assert float(np.abs(out['alignments'].to_host() - ref['alignments']).max()) < 1e-4
     finally:
         eng.close()
+
+
+def _setup_predictive(hparams, D, gaussian, seed=11, vp_scale=1.0, vp_shift=0.0):
+    hp = copy.deepcopy(hparams)
+    hp.attention.mechanism = 'LocalLuongAttention'
+    hp.attention.luong_local_mode = 'predictive'
+    hp.attention.luong_local_window_D = D
+    hp.attention.luong_force_gaussian = gaussian
+    w = pkg('tacotron.weights').synthetic_weights(seed, hp)
+    vp = 'decoder2/decoder/output_projection_wrapper/multi_rnn_cell/cell_0/attention_wrapper/local_luong_attention/local_v_p'
+    w[vp] = (w[vp] * vp_scale + vp_shift).astype(np.float32)
+    eng = pkg().Engine(hp)
+    eng.load_weights(w)
+    return hp, eng, w
+
+
+@pytest.mark.parametrize('B,Ts,S,D,gaussian,vp_scale', [(3, 60, 12, 10, True, 1.0), (4, 90, 20, 5, False, 4.0),
+                                                        (2, 150, 9, 10, True, 8.0)])
+def test_predictive_local_attention_decoder(hparams, B, Ts, S, D, gaussian, vp_scale):
+    """LocalLuongAttention in PREDICTIVE mode (reference tacotron/attention.py:246-258): the window centre
+    p = T_s sigmoid(v_p^T tanh(W_p h)) is predicted per utterance and step; larger v_p spreads the centres."""
+    hp, eng, w = _setup_predictive(hparams, D, gaussian, vp_scale=vp_scale)
+    try:
+        assert len(eng.manifest()) == len(pkg('tacotron.weights').manifest(hp))
+        rng = np.random.default_rng(7 * B + D)
+        memory = rng.standard_normal((B, Ts, 256)).astype(np.float32) * 0.5
+        w64 = {k: v.astype(np.float64) for k, v in w.items()}
+        ref_mel, ref_al = O.decoder(memory.astype(np.float64), w64, hp, n_steps=S)
+        mel, al = eng.decoder_forward(memory, S)
+        al = al.to_host()
+        e_mel, e_al = rel_l2(mel.to_host(), ref_mel), float(np.abs(al - ref_al).max())
+        centres = np.array([[np.flatnonzero(al[t, b]).mean() for b in range(B)] for t in range(S)])
+        print('predictive local attention B={} Ts={} S={} D={}: mel {:.2e} align {:.2e}; window centres {:.1f}..{:.1f}'.format(
+            B, Ts, S, D, e_mel, e_al, centres.min(), centres.max()))
+        assert e_mel < 1e-3 and e_al < 1e-4
+        assert np.all((al != 0).sum(-1) <= 2 * D + 1)
+        if not gaussian:
+            np.testing.assert_allclose(al.sum(-1), 1.0, atol=1e-5)
+    finally:
+        eng.close()
+
+
+def test_predictive_window_leaving_the_memory_is_an_error(hparams):
+    """Where the predicted window leaves the memory the reference's padding arithmetic (attention.py:288-304)
+    breaks and TensorFlow fails at run time; the library reports TTS_ERR_UNSUPPORTED, the oracle raises."""
+    # T_s = 2D+1: only floor(p) == D keeps the window inside, and a large v_p spreads p = 21 sigmoid(.) well beyond
+    hp, eng, w = _setup_predictive(hparams, 10, True, vp_scale=8.0)
+    try:
+        memory = np.random.default_rng(1).standard_normal((2, 21, 256)).astype(np.float32)
+        w64 = {k: v.astype(np.float64) for k, v in w.items()}
+        with pytest.raises(ValueError):
+            O.decoder(memory.astype(np.float64), w64, hp, n_steps=3)
+        with pytest.raises(pkg('_hip').TtsError) as ei:
+            eng.decoder_forward(memory, 3)
+        assert ei.value.code == -5
+    finally:
+        eng.close()

@@ -183,6 +183,35 @@ def test_local_luong_decoder_reduces_to_global_when_window_is_the_memory(weights
     a, al_a = O.decoder(mem, weights64, hp, n_steps=5)
     b, al_b = O.decoder(mem, weights64, hparams, n_steps=5)
     assert rel_l2(a, b) < 1e-12 and np.abs(al_a - al_b).max() < 1e-14
-    hp.attention.luong_local_mode = 'predictive'
+    hp.attention.luong_local_score = 'general'
     with pytest.raises(NotImplementedError):
         O.decoder(mem, weights64, hp, n_steps=1)
+
+
+@pytest.mark.parametrize('Ts,D,gaussian', [(40, 10, True), (25, 3, False), (64, 5, True)])
+def test_predictive_local_luong_equals_masked_softmax_around_the_predicted_centre(Ts, D, gaussian):
+    """Independent formulation of LocalLuongAttention's PREDICTIVE mode (reference tacotron/attention.py:246-258,
+    273-342, 52-92): p = T_s sigmoid(v_p^T tanh(W_p h)) per row, then a softmax over the whole memory with -inf
+    outside [floor(p) - D, floor(p) + D]; the gaussian uses the real-valued p."""
+    rng = np.random.default_rng(Ts + D)
+    B, U = 4, 16
+    q = rng.standard_normal((B, U))
+    keys, values = rng.standard_normal((B, Ts, U)), rng.standard_normal((B, Ts, U))
+    wp, vp = rng.standard_normal((U, U)) * 0.3, rng.standard_normal((U, 1)) * 0.05   # centres stay near T_s / 2
+    ctx, al, p = O.local_luong_predictive(q, keys, values, wp, vp, D, gaussian)
+    tq = torch.from_numpy(q)
+    p_t = Ts * torch.sigmoid(torch.tanh(tq @ torch.from_numpy(wp)) @ torch.from_numpy(vp))[:, 0]
+    assert np.allclose(p, p_t.numpy(), atol=1e-12)
+    score = torch.einsum('bd,btd->bt', tq, torch.from_numpy(keys))
+    pos = torch.arange(Ts, dtype=torch.float64)[None, :]
+    c = torch.floor(p_t)[:, None]
+    mask = torch.where((pos >= c - D) & (pos <= c + D), 0.0, float('-inf'))
+    a = torch.softmax(score + mask, -1)
+    assert rel_l2(ctx, torch.einsum('bt,btd->bd', a, torch.from_numpy(values)).numpy()) < 1e-12
+    exp = a.numpy()
+    if gaussian:
+        exp = exp * np.exp(-((np.arange(Ts)[None, :] - p[:, None]) ** 2) / 2 * (D / 2) ** 2)
+    np.testing.assert_allclose(al, exp, atol=1e-14)
+    # a window that leaves the memory is where the reference stops being defined
+    with pytest.raises(ValueError):
+        O.local_luong_predictive(q, keys, values, wp, vp, Ts, gaussian)   # 2D+1 > T_s
