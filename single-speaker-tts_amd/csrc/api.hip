@@ -851,9 +851,9 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
             p.mse_partial = (mse && it == n_iter - 1) ? msep : nullptr;
             p.work_counter = counters + it;
 #ifdef GL_TIMELINE   // tools only: stamps of workgroup 0 during the last iteration
-            WS(h, "gl.timeline", unsigned long long, 64 * 16, tl);
+            WS(h, "gl.timeline", unsigned long long, 1024 + 64 * 16, tl);
             if (it == n_iter - 1) {
-                HIPCHK(h, hipMemsetAsync(tl, 0, 64 * 16 * sizeof(unsigned long long), h->stream));
+                HIPCHK(h, hipMemsetAsync(tl, 0, (1024 + 64 * 16) * sizeof(unsigned long long), h->stream));
                 p.dbg = tl;
             }
 #endif
@@ -862,9 +862,24 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
         }
 #ifdef GL_TIMELINE
         if (n_iter > 0) {
-            std::vector<unsigned long long> host(64 * 16);
+            std::vector<unsigned long long> host(1024 + 64 * 16);
             HIPCHK(h, hipMemcpyAsync(host.data(), p.dbg, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
+            {   // per-wave stamps of workgroup 0
+                unsigned long long w0 = ~0ull;
+                for (int i = 1024; i < 1024 + 64 * 16; ++i) if (host[i] && host[i] < w0) w0 = host[i];
+                for (int w = 0; w < 16; ++w) {
+                    bool any = false;
+                    for (int i = 0; i < 64; ++i) any = any || host[1024 + w * 64 + i];
+                    if (!any) continue;
+                    fprintf(stderr, "wave %2d:", w);
+                    for (int i = 0; i < 64; ++i) {
+                        const unsigned long long v = host[1024 + w * 64 + i];
+                        if (v) fprintf(stderr, " [%d]%.1f", i, (double)(v - w0) * 0.01);
+                    }
+                    fprintf(stderr, "\n");
+                }
+            }
             unsigned long long t0 = ~0ull, t1 = 0;
             for (int w = 0; w < 512; ++w) if (host[2 * w]) { t0 = std::min(t0, host[2 * w]); t1 = std::max(t1, host[2 * w + 1]); }
             std::vector<double> ends, starts;

@@ -25,8 +25,9 @@
 //   hazard (wave w round r vs wave w+1 rounds < r - (R - ncol)) is ordered by per-wave progress flags in
 //   LDS, so there are no atomics, no workgroup barriers inside the phase, and the summation order of every
 //   sample is fixed (bit-reproducible).  Round 0 stores instead of accumulating, so the buffer is never
-//   cleared.  The next round's spectrum row is prefetched into registers -- directly in the (k, 1024 - k)
-//   layout of the real-FFT split pass -- while the current frame's FFT runs.  The window-sum-square
+//   cleared.  The next round's spectrum row is prefetched into registers (bins k = lane + 64 j, read once)
+//   while the current frame's FFT runs; the mirrored bins 1024 - k of the real-FFT split pass come through
+//   the wave's exchange buffer (mirror_bins), not from a second pass over the row.  The window-sum-square
 //   normalisation of librosa's istft is folded into the synthesis window (a per-sample table only for the
 //   frames at the utterance ends), so the signal is final when the overlap-add is.
 //   Phase B forward-FFTs the C owned frames straight from LDS (reflect padding at the utterance edges is an
@@ -40,8 +41,11 @@
 // per FFT, 16 points per lane: radix-16 in registers -> 4x4 register/lane transpose (v_permlane16_swap /
 // v_permlane32_swap) -> radix-4 -> LDS transpose -> radix-16; all twiddles and this lane's window samples
 // (with the iFFT scale folded in) in registers.  Index math validated against numpy in
-// tests/test_host_logic.py (test_fft_decomposition_emulation).  This file is compiled with
-// -fno-slp-vectorize: packed f32 VALU ops are slower than the scalar pairs they replace on gfx950.
+// tests/test_host_logic.py (test_fft_decomposition_emulation).  Complex numbers are packed values (v_pk_add /
+// v_pk_mul / v_pk_fma_f32 with op_sel / neg modifiers, see "complex helpers"): the kernel is bound by VALU issue
+// (one instruction per ~4 cycles and SIMD whatever it is), and a packed instruction costs about as much as a
+// scalar one.  This file is still compiled with -fno-slp-vectorize: what the SLP vectoriser packs on its own
+// (unrelated scalars, with v_mov shuffles to align the pairs) is slower than leaving it scalar.
 //
 // Compile-time switches used by the tools/ micro-benchmarks only: GL_NO_ALTPRIO, GL_FFT_LDS_STAGE1 (first
 // exchange through LDS), GL_NO_STREAMING_HINT, E1S / E2S (exchange strides).
@@ -54,60 +58,127 @@
 namespace tts {
 
 // ------------------------------------------------------------------------------------ complex helpers
-typedef float2 cf;
-__device__ __forceinline__ cf cmk(float a, float b) { return make_float2(a, b); }
-__device__ __forceinline__ cf cadd(cf a, cf b) { return cmk(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return cmk(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return cmk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// A complex number is ONE packed value (an aligned 64-bit register pair): gfx950 issues a VALU instruction per
+// wave every ~4 cycles whether it is v_add_f32 or v_pk_add_f32 (tools/valu_microbench2.hip: 1.72 ns against
+// 1.84 ns per instruction and SIMD), so complex add / sub cost one instruction and a complex multiply two
+// (v_pk_mul_f32 + v_pk_fma_f32).  Multiplications by +-i, conjugations and the real / imaginary broadcasts of
+// the multiply are the op_sel / neg_lo / neg_hi source modifiers of the packed instructions; hipcc does not
+// form those from shuffles (it emits v_mov + v_xor), hence the one-line asm statements.  Plain asm, not
+// volatile: the compiler still schedules and removes them like any other pure operation.
+typedef float cf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf cmk(float a, float b) { return (cf){a, b}; }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+__device__ __forceinline__ cf cscale(cf a, float s) { return a * s; }
 __device__ __forceinline__ cf cconj(cf a) { return cmk(a.x, -a.y); }
-__device__ __forceinline__ cf cmul_mi(cf a) { return cmk(a.y, -a.x); }   // a * (-i)
-__device__ __forceinline__ cf cmul_pi(cf a) { return cmk(-a.y, a.x); }   // a * (+i)
-__device__ __forceinline__ cf cscale(cf a, float s) { return cmk(a.x * s, a.y * s); }
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ cf cadd_mi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + (+i) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ cf cadd_pi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// conj(a + i b) = (a.x - b.y, -a.y - b.x)
+__device__ __forceinline__ cf cconj_add_pi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + conj(b), a - conj(b)
+__device__ __forceinline__ cf cadd_conj(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf csub_conj(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * b
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// a * conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
+__device__ __forceinline__ cf cmul_conj(cf a, cf b) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// a * k for a compile-time constant k, which lives in a scalar register pair
+__device__ __forceinline__ cf cmul_k(cf a, cf k) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(k));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "s"(k), "v"(t));
+    return r;
+}
+
+// Workgroup barrier that orders LDS accesses only.  __syncthreads() also waits for every outstanding global
+// load and STORE of the wave (s_waitcnt vmcnt(0)); at the end of phase B that is the full HBM write latency of a
+// frame's spectrum row, three times per chunk, for nothing: no wave ever reads what another wave stored to
+// global memory inside this kernel.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS hand-off between lanes of ONE wave.  The LDS unit executes one wave's DS operations in
     // issue order, so a ds_read issued after a ds_write of the same wave observes it for every
     // lane: no s_waitcnt is needed, only a compiler-level ordering point (the compiler still waits
     // on lgkmcnt before it USES a loaded register).
-#ifdef GL_DRAIN_LDS
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
     asm volatile("" ::: "memory");
-#endif
     __builtin_amdgcn_wave_barrier();
 }
 
-// forward radix-4 butterfly (W4 = -i)
+// forward radix-4 butterfly (W4 = -i): 8 packed adds
 __device__ __forceinline__ void r4(cf& a, cf& b, cf& c, cf& d) {
     const cf s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = csub(b, d);
     a = cadd(s0, s2);
     c = csub(s0, s2);
-    b = cadd(s1, cmul_mi(s3));   // a - i b - c + i d
-    d = cadd(s1, cmul_pi(s3));   // a + i b - c - i d
+    b = cadd_mi(s1, s3);   // a - i b - c + i d
+    d = cadd_pi(s1, s3);   // a + i b - c - i d
+}
+// the same with c standing for (-i) c: the W16^4 twiddle of the 16-point transform folded into the butterfly
+__device__ __forceinline__ void r4_c_mi(cf& a, cf& b, cf& c, cf& d) {
+    const cf s0 = cadd_mi(a, c), s1 = cadd_pi(a, c), s2 = cadd(b, d), s3 = csub(b, d);
+    a = cadd(s0, s2);
+    c = csub(s0, s2);
+    b = cadd_mi(s1, s3);
+    d = cadd_pi(s1, s3);
 }
 
 // forward 16-point DFT in registers, natural order in and out: out[k] = sum_j v[j] W16^{jk}
+// (64 packed adds + 8 complex multiplies by constants = 80 VALU instructions)
 __device__ __forceinline__ void fft16(cf (&v)[16]) {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
     // step 1: for each j1, radix-4 over j2 (elements j1 + 4 j2) -> t[j1][k2] stored at v[j1 + 4 k2]
 #pragma unroll
     for (int j1 = 0; j1 < 4; ++j1) r4(v[j1], v[j1 + 4], v[j1 + 8], v[j1 + 12]);
-    // twiddle t[j1][k2] *= W16^{j1 k2}
-    v[1 + 4] = cmul(v[1 + 4], cmk(C1, -S1));    // W^1
-    v[1 + 8] = cmul(v[1 + 8], cmk(R2, -R2));    // W^2
-    v[1 + 12] = cmul(v[1 + 12], cmk(S1, -C1));  // W^3
-    v[2 + 4] = cmul(v[2 + 4], cmk(R2, -R2));    // W^2
-    v[2 + 8] = cmul_mi(v[2 + 8]);               // W^4 = -i
-    v[2 + 12] = cmul(v[2 + 12], cmk(-R2, -R2)); // W^6
-    v[3 + 4] = cmul(v[3 + 4], cmk(S1, -C1));    // W^3
-    v[3 + 8] = cmul(v[3 + 8], cmk(-R2, -R2));   // W^6
-    v[3 + 12] = cmul(v[3 + 12], cmk(-C1, S1));  // W^9
+    // twiddle t[j1][k2] *= W16^{j1 k2}; W^4 = -i (t[2][2]) is folded into the second butterfly of k2 = 2
+    v[1 + 4] = cmul_k(v[1 + 4], cmk(C1, -S1));    // W^1
+    v[1 + 8] = cmul_k(v[1 + 8], cmk(R2, -R2));    // W^2
+    v[1 + 12] = cmul_k(v[1 + 12], cmk(S1, -C1));  // W^3
+    v[2 + 4] = cmul_k(v[2 + 4], cmk(R2, -R2));    // W^2
+    v[2 + 12] = cmul_k(v[2 + 12], cmk(-R2, -R2)); // W^6
+    v[3 + 4] = cmul_k(v[3 + 4], cmk(S1, -C1));    // W^3
+    v[3 + 8] = cmul_k(v[3 + 8], cmk(-R2, -R2));   // W^6
+    v[3 + 12] = cmul_k(v[3 + 12], cmk(-C1, S1));  // W^9
     // step 2: for each k2, radix-4 over j1 -> out[k2 + 4 k1] ; data for k2 sits at v[4 k2 + j1]
     cf o[16];
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
         cf a = v[4 * k2 + 0], b = v[4 * k2 + 1], c = v[4 * k2 + 2], d = v[4 * k2 + 3];
-        r4(a, b, c, d);
+        if (k2 == 2) r4_c_mi(a, b, c, d);
+        else r4(a, b, c, d);
         o[k2 + 0] = a; o[k2 + 4] = b; o[k2 + 8] = c; o[k2 + 12] = d;
     }
 #pragma unroll
@@ -205,6 +276,21 @@ __device__ __forceinline__ void fft1024(cf (&v)[16], cf* ex, const TW& tw, int l
     fft16(v);
 }
 
+// Bins MH - k of a spectrum row whose bins k = lane + 64 c this lane holds in z[c]: m[c] = Z[MH - lane - 64 c],
+// through the wave's exchange buffer (one pass of 8-byte writes and reads).  Bin MH itself (wanted by lane 0,
+// c = 0) is in no register: the caller passes it.
+__device__ __forceinline__ void mirror_bins(const cf (&z)[16], cf (&m)[16], cf* ex, int lane, cf nyq) {
+    cf* wr = ex + lane;
+    const cf* rd = ex + (1024 - lane);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) wr[64 * c] = z[c];
+    if (lane == 0) ex[1024] = nyq;
+    wave_lds_sync();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) m[c] = rd[-64 * c];
+    wave_lds_sync();
+}
+
 // ------------------------------------------------------------------------------------ GL iteration
 #define GL_NW 8            // waves per workgroup
 #define GL_THREADS 512
@@ -226,24 +312,10 @@ __device__ __forceinline__ cf unit_phasor(cf z) {
 // The spectra are streamed once per iteration (1.3 GB per launch at the bench size): non-temporal accesses
 // keep them from evicting the decoder's weights and attention memory, which the second stream re-reads
 // every step while this kernel runs.
-#ifdef GL_NO_STREAMING_HINT
-#define GL_STREAM_LOAD(ptr) (*(ptr))
-#define GL_STREAM_STORE(ptr, val) (*(ptr) = (val))
-#else
-typedef float gl_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ cf gl_stream_load(const cf* p) {
-    const gl_f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const gl_f32x2*>(p));
-    return cmk(v.x, v.y);
-}
 __device__ __forceinline__ float gl_stream_load(const float* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void gl_stream_store(cf* p, cf v) {
-    gl_f32x2 t;
-    t.x = v.x; t.y = v.y;
-    __builtin_nontemporal_store(t, reinterpret_cast<gl_f32x2*>(p));
-}
+__device__ __forceinline__ void gl_stream_store(cf* p, cf v) { __builtin_nontemporal_store(v, p); }
 #define GL_STREAM_LOAD(ptr) gl_stream_load(ptr)
 #define GL_STREAM_STORE(ptr, val) gl_stream_store((ptr), (val))
-#endif
 
 // LDS control words behind the exchange buffers
 enum { CT_FLAGS = 0 /* GL_NW overlap-add progress flags */, CT_BNEXT = 8, CT_NEXT_ITEM = 9, CT_WORDS = 16 };
@@ -286,12 +358,12 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     // W1024^{lane k2} and tw.b for the FFT itself.  No table in LDS, no LDS read latency inside a round.
     cf twr[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) twr[j] = p.tw2048[lane + 64 * j];
+    for (int j = 0; j < 16; ++j) twr[j] = reinterpret_cast<const cf*>(p.tw2048)[lane + 64 * j];
     FftTwReg tw;
 #pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) tw.a[k2 - 1] = p.tables[1024 + (k2 - 1) * 64 + lane];
+    for (int k2 = 1; k2 < 16; ++k2) tw.a[k2 - 1] = reinterpret_cast<const cf*>(p.tables)[1024 + (k2 - 1) * 64 + lane];
 #pragma unroll
-    for (int d = 1; d < 4; ++d) tw.b[d - 1] = p.tw1024[16 * (lane & 15) * d];
+    for (int d = 1; d < 4; ++d) tw.b[d - 1] = reinterpret_cast<const cf*>(p.tw1024)[16 * (lane & 15) * d];
     // This lane's window samples (n = 2*(lane + 64 c) + {0,1}) come from p.wlane, a per-lane image
     // [set][lane][c][e] built by the host (gl_build_wlane; 128 contiguous bytes per lane and set):
     //   set 0, analysis window of phase B: w[n] / (2 MH)  (the iFFT scale folded in; unit phasors do not
@@ -340,7 +412,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         const int run_t0 = p.cls_t0[k] + jc * run_len;
         const int slot0 = p.cls_slot0[k] + jc * p.cls_chunks[k];   // ordinal of the run's first chunk in its utterance
         const float* magb = p.mag + (size_t)b * p.T * p.FP;
-        const cf* phb = p.phase_in + (size_t)b * p.T * p.FP;
+        const cf* phb = reinterpret_cast<const cf*>(p.phase_in) + (size_t)b * p.T * p.FP;
         unsigned next_item_reg = 0;
         if (tid == 0) next_item_reg = atomicAdd(p.work_counter, 1u);   // consumed before the first barrier below
         int next_item = p.n_items;
@@ -363,15 +435,15 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         // hits in cache, and the row never has to be staged through LDS.  UNCONDITIONAL loads (the frame
         // index is clamped instead of branching): registers filled under a branch stay in scratch memory,
         // and hipcc then waits for the loads right after issuing them.
-        cf gk[16], gm[16];
+        cf gk[16];
+        float nyq;
 #define GL_LOAD_FRAME(FA)                                                                  \
     {                                                                                      \
         int tf_ = t0 - halo + (FA);                                                        \
         tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                  \
         const cf* prow_ = phb + (size_t)tf_ * p.FP + lane;                                 \
-        const cf* mrow_ = phb + (size_t)tf_ * p.FP + (MH - lane);                          \
         _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gk[j_] = prow_[64 * j_];                  \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gm[j_] = mrow_[-64 * j_];                 \
+        nyq = reinterpret_cast<const float*>(phb + (size_t)tf_ * p.FP + MH)[0];            \
     }
         GL_LOAD_FRAME(fa0 + R * wave)
 
@@ -390,17 +462,18 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             const bool ok = fa < nA && tf >= 0 && tf < p.T;
             cf v[16];
             if (ok) {
+                cf gm[16];
+                mirror_bins(gk, gm, ex, lane, cmk(nyq, 0.f));
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     cf xk = gk[j];
-                    cf xm = cconj(gm[j]);
-                    if (j == 0 && lane == 0) { xk.y = 0.f; xm.y = 0.f; }   // DC and Nyquist bins are real
+                    cf xr = gm[j];                                         // xm = conj(xr)
+                    if (j == 0 && lane == 0) { xk.y = 0.f; xr.y = 0.f; }   // DC and Nyquist bins are real
                     // Zin = E + i O, E = (xk + xm)/2, O = conj(twr) (xk - xm)/2 ; feed conj(Zin).
                     // The two 1/2 factors are folded into the output scale (the FFT is linear).
-                    const cf e = cadd(xk, xm);
-                    const cf o = cmul(cconj(twr[j]), csub(xk, xm));
-                    const cf zin = cadd(e, cmul_pi(o));
-                    v[j] = cconj(zin);
+                    const cf e = cadd_conj(xk, xr);
+                    const cf o = cmul_conj(csub_conj(xk, xr), twr[j]);
+                    v[j] = cconj_add_pi(e, o);
                 }
             } else {
 #pragma unroll
@@ -414,7 +487,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 // z[m] = conj(v)/MH, m = lane + 64 c: x[2m] = Re, x[2m+1] = Im
                 if (tf >= halo && tf + halo < p.T) {
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) v[c] = cmk(v[c].x * wreg[c][0], -v[c].y * wreg[c][1]);
+                    for (int c = 0; c < 16; ++c) v[c] = v[c] * cmk(wreg[c][0], -wreg[c][1]);
                 } else {
                     // frame near an utterance end: fewer overlapping neighbours, take 1 / wss per sample
                     // (rare path; four slots at a time so that its loads do not inflate the register budget)
@@ -515,7 +588,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             }
         } else {
             // ---------------- phase B: forward FFT of the owned frames, new unit phasors
-            cf* pob = p.phase_out + (size_t)b * p.T * p.FP;
+            cf* pob = reinterpret_cast<cf*>(p.phase_out) + (size_t)b * p.T * p.FP;
             float mse_acc = 0.f;
             // frames are handed out dynamically (LDS counter): the wave that wins issue arbitration on
             // its SIMD takes more of them, so both waves of a SIMD finish together
@@ -588,14 +661,13 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 for (int c = 0; c < 16; ++c) {
                     const int k = lane + 64 * c;
                     const cf zk = v[c];
-                    const cf zm = cconj(zmr[c]);
-                    // 2 X[k] = (zk + zm) - i twr (zk - zm); the phase does not care about the factor 2
-                    const cf e = cadd(zk, zm);
-                    const cf o = cmul(twr[c], csub(zk, zm));
-                    const cf x = cadd(e, cmul_mi(o));
+                    // zm = conj(zmr); 2 X[k] = (zk + zm) - i twr (zk - zm); the phase does not care about the factor 2
+                    const cf e = cadd_conj(zk, zmr[c]);
+                    const cf o = cmul(csub_conj(zk, zmr[c]), twr[c]);
+                    const cf x = cadd_mi(e, o);
                     const float s = fmaf(x.x, x.x, x.y * x.y);
                     const float g = __builtin_amdgcn_rsqf(s) * mg[c];   // raw v_rsq_f32: s is range-checked below
-                    GL_STREAM_STORE(orow + k, cmk(x.x * g, x.y * g));
+                    GL_STREAM_STORE(orow + k, x * g);
                     s_min = fminf(s_min, s);
                     s_max = fmaxf(s_max, s);
                     if (MSE) {
@@ -609,10 +681,10 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                     for (int c = 0; c < 16; ++c) {
                         const int k = lane + 64 * c;
                         const cf zk = ex[k];
-                        const cf zm = cconj(ex[(MH - k) & (MH - 1)]);
-                        const cf e = cadd(zk, zm);
-                        const cf o = cmul(p.tw2048[k], csub(zk, zm));
-                        const cf x = cadd(e, cmul_mi(o));
+                        const cf zr = ex[(MH - k) & (MH - 1)];
+                        const cf e = cadd_conj(zk, zr);
+                        const cf o = cmul(csub_conj(zk, zr), reinterpret_cast<const cf*>(p.tw2048)[k]);
+                        const cf x = cadd_mi(e, o);
                         orow[k] = cscale(unit_phasor(x), fabsf(mrow[k]));
                     }
                 }
@@ -973,10 +1045,10 @@ __global__ __launch_bounds__(GL_THREADS) void stft_kernel(const float* __restric
     for (int c = 0; c < 16; ++c) {
         const int k = lane + 64 * c;
         const cf zk = v[c];
-        const cf zm = cconj(ex[(MH - k) & (MH - 1)]);
-        const cf e = cscale(cadd(zk, zm), 0.5f);
-        const cf o = cmul(twR[k], cscale(csub(zk, zm), 0.5f));
-        orow[k] = cadd(e, cmul_mi(o));
+        const cf zr = ex[(MH - k) & (MH - 1)];
+        const cf e = cscale(cadd_conj(zk, zr), 0.5f);
+        const cf o = cmul(cscale(csub_conj(zk, zr), 0.5f), twR[k]);
+        orow[k] = cadd_mi(e, o);
     }
     if (lane == 0) orow[MH] = cmk(v[0].x - v[0].y, 0.f);
     if (lane < FP - MH - 1) orow[MH + 1 + lane] = cmk(0.f, 0.f);
@@ -991,7 +1063,8 @@ hipError_t launch_stft(hipStream_t s, const float* wav, int B, int n, int Tf, co
                        const float2* tw1024, const float2* tw2048, float2* out, int FP) {
     const size_t lds = (size_t)(GL_NW * EX_CPLX + 1024 + 15 * 64) * sizeof(cf) + (size_t)((win + 3) & ~3) * sizeof(float);
     dim3 grid((Tf + GL_NW - 1) / GL_NW, B);
-    hipLaunchKernelGGL(stft_kernel, grid, dim3(GL_THREADS), lds, s, wav, n, Tf, window, win, hop, tw1024, tw2048, out, FP);
+    hipLaunchKernelGGL(stft_kernel, grid, dim3(GL_THREADS), lds, s, wav, n, Tf, window, win, hop,
+                       reinterpret_cast<const cf*>(tw1024), reinterpret_cast<const cf*>(tw2048), reinterpret_cast<cf*>(out), FP);
     return hipGetLastError();
 }
 
@@ -1023,7 +1096,7 @@ __global__ void cplx_tf_to_ft_kernel(const cf* in, float* out, int F, int T, int
 hipError_t launch_cplx_tf_to_ft(hipStream_t s, const float2* in, float* out, int B, int F, int T, int FP, int mode,
                                 float power) {
     dim3 grid((T + 31) / 32, (F + 31) / 32, B);
-    hipLaunchKernelGGL(cplx_tf_to_ft_kernel, grid, dim3(32, 8), 0, s, in, out, F, T, FP, mode, power);
+    hipLaunchKernelGGL(cplx_tf_to_ft_kernel, grid, dim3(32, 8), 0, s, reinterpret_cast<const cf*>(in), out, F, T, FP, mode, power);
     return hipGetLastError();
 }
 
