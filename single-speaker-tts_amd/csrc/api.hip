@@ -77,6 +77,7 @@ struct tts_handle_s {
     hipEvent_t ev_post_done[2] = {nullptr, nullptr};   // post-net of the calls of even / odd parity
     bool post_pending[2] = {false, false};
     unsigned syn_calls = 0;
+    int syn_shape[3] = {0, 0, 0};   // (B, Ts, n_steps) of the previous tts_synthesize call
 
     std::vector<ManifestEntry> manifest;
     std::map<std::string, std::vector<float>> host_w;
@@ -1621,7 +1622,12 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     float* linear = linear_out;   // null: the final Dense emits only the de-normalised magnitude (rows of 1028 floats;
                                   // the 1025-float rows of the linear spectrogram cannot be written in whole cache lines)
     WS(h, "gl.mag", float, (size_t)B * T * FP, magi);
-    const bool pipelined = h->pipeline && h->own_stream;   // inputs on a borrowed stream may still be in flight
+    // Pipelined only while the library owns its stream (inputs on a borrowed stream may still be in flight) and
+    // from the second call of a shape on: the first call of a new (B, Ts, n_steps) grows the workspaces, which
+    // synchronises every stream -- under the CU reservation that would park the host on the sleepers' 100 ms bound.
+    const bool same_shape = h->syn_shape[0] == B && h->syn_shape[1] == Ts && h->syn_shape[2] == sp->n_steps;
+    h->syn_shape[0] = B; h->syn_shape[1] = Ts; h->syn_shape[2] = sp->n_steps;
+    const bool pipelined = h->pipeline && h->own_stream && same_shape;
     if (pipelined) {
         if (!h->front) {
             int prio_least = 0, prio_greatest = 0;
