@@ -8,6 +8,40 @@
 
 typedef __attribute__((address_space(1))) unsigned gu32;
 
+// 16-byte write-through store / L1-bypassing load (sc1) through a buffer resource: aux bit 4 = sc1
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+template <int SLAB_FLOATS>   // wide variant: one 16-byte sc1 store per thread and hop, 16-byte sc1 loads
+__global__ __launch_bounds__(256) void hop_kernel_wide(float* slabs, unsigned* counters, unsigned* timeout, int W, int iters, float* sink) {
+    const int wg = blockIdx.x, c = wg / W, tid = threadIdx.x;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    unsigned* cnt = counters + 64 * c;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, (int)((size_t)2 * gridDim.x * SLAB_FLOATS * 4), 0x00020000);
+    for (int it = 0; it < iters; ++it) {
+        const int mine = ((it & 1) * gridDim.x + wg) * SLAB_FLOATS * 4;
+        for (int i = tid * 4; i < SLAB_FLOATS; i += 1024)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, acc), rs, mine + i * 4, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (unsigned)W * (unsigned)(it + 1);
+            unsigned spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > 4000000u) { *timeout = 1; break; }
+            }
+        }
+        __syncthreads();
+        const int base = ((it & 1) * gridDim.x + c * W) * SLAB_FLOATS * 4;
+        for (int i = tid * 4; i < W * SLAB_FLOATS; i += 1024) {
+            auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, base + i * 4, 0, 16);
+            acc += __builtin_bit_cast(f32x4_t, v) * 1e-9f;
+        }
+    }
+    sink[wg * 256 + tid] = acc.x + acc.y + acc.z + acc.w;
+}
+
 template <int SLAB_FLOATS>   // floats published per workgroup and hop (256 threads)
 __global__ __launch_bounds__(256) void hop_kernel(float* slabs, unsigned* counters, unsigned* timeout, int W, int iters, float* sink) {
     const int wg = blockIdx.x, c = wg / W, tid = threadIdx.x;
@@ -36,7 +70,7 @@ __global__ __launch_bounds__(256) void hop_kernel(float* slabs, unsigned* counte
     sink[wg * 256 + tid] = acc;
 }
 
-template <int SLAB>
+template <int SLAB, bool WIDE = false>
 void run(int G, int W, int iters) {
     float *slabs, *sink;
     unsigned *counters, *timeout;
@@ -52,7 +86,8 @@ void run(int G, int W, int iters) {
         (void)hipMemset(counters, 0, 64 * 64 * sizeof(unsigned));
         (void)hipMemset(timeout, 0, sizeof(unsigned));
         (void)hipEventRecord(a);
-        hipLaunchKernelGGL(hop_kernel<SLAB>, dim3(G), dim3(256), 0, 0, slabs, counters, timeout, W, iters, sink);
+        if (WIDE) hipLaunchKernelGGL(hop_kernel_wide<SLAB>, dim3(G), dim3(256), 0, 0, slabs, counters, timeout, W, iters, sink);
+        else hipLaunchKernelGGL(hop_kernel<SLAB>, dim3(G), dim3(256), 0, 0, slabs, counters, timeout, W, iters, sink);
         (void)hipEventRecord(b);
         (void)hipEventSynchronize(b);
         float ms = 0;
@@ -60,7 +95,7 @@ void run(int G, int W, int iters) {
         best = ms < best ? ms : best;
         (void)hipMemcpy(&tmo, timeout, sizeof(unsigned), hipMemcpyDeviceToHost);
     }
-    printf("G=%3d workgroups, clusters of %2d, slab %5d B: %.2f us per hop (%s%s)\n", G, W, SLAB * 4, best * 1e3 / iters,
+    printf("G=%3d workgroups, clusters of %2d, slab %5d B, %s accesses: %.2f us per hop (%s%s)\n", G, W, SLAB * 4, WIDE ? "16-byte" : " 4-byte", best * 1e3 / iters,
            hipGetErrorString(hipGetLastError()), tmo ? ", TIMEOUT" : "");
     (void)hipFree(slabs); (void)hipFree(sink); (void)hipFree(counters); (void)hipFree(timeout);
 }
@@ -76,5 +111,11 @@ int main() {
     run<1024>(64, 64, iters);
     run<256>(128, 32, iters);
     run<64>(64, 16, iters);
+    run<256, true>(64, 16, iters);
+    run<1024, true>(64, 16, iters);
+    run<1024, true>(64, 8, iters);
+    run<1024, true>(32, 8, iters);
+    run<256, true>(32, 32, iters);
+    run<1024, true>(64, 64, iters);
     return 0;
 }
