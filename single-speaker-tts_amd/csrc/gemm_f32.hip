@@ -56,10 +56,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
 
     // ---- staging assignment: 4 float4 of A and 4 of B per thread per tile
     // idx = tid + 256*i -> row = idx >> 3 (0..127), kq = idx & 7 (float4 column)
-    const float* a_row[4];
+    // Both operands are fetched with raw buffer loads: an element that must read as zero (rows past M / N, k past
+    // K, conv taps that leave the sequence, ids outside the embedding table) gets the byte offset 0xFFFFFFFF,
+    // which the buffer range check turns into a zero result -- the loader has no branches and no selects on data.
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, (int)0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wt), 0, (int)0xFFFFFFF0u, 0x00020000);
+    auto buf4 = [](const __amdgpu_buffer_rsrc_t& rs, unsigned byte_off) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 0));
+    };
+    int a_off[4];       // element offset of the row's k = 0 from g.A (may be "negative" for rows the tap mask removes)
     int a_t[4];         // time index of the row inside its sequence (conv masking)
     bool a_ok[4];
-    const float* b_row[4];
+    int b_off[4];
     bool b_ok[4];
     const int kq = tid & 7;
 #pragma unroll
@@ -75,13 +84,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
             const int id = g.gather[mm];
             const bool in_table = (unsigned)id < (unsigned)g.gather_rows;
             a_ok[i] = a_ok[i] && in_table;
-            a_row[i] = g.A + (size_t)(in_table ? id : 0) * g.lda;
+            a_off[i] = (in_table ? id : 0) * g.lda;
         } else {
-            a_row[i] = g.A + ((ptrdiff_t)mm - g.padl) * (ptrdiff_t)g.lda;
+            a_off[i] = (mm - g.padl) * g.lda;
         }
         const int n = n0 + row;
         b_ok[i] = n < N;
-        b_row[i] = g.Wt + (size_t)(b_ok[i] ? n : 0) * K;
+        b_off[i] = (b_ok[i] ? n : 0) * K;
     }
 
     float4 ra[4], rb[4];
@@ -101,16 +110,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
         const int tap = kk / g.Cin;  // all four floats share the tap (Cin % 4 == 0)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int ts = a_t[i] - g.padl + tap;
-            if (a_ok[i] && kin && ts >= 0 && ts < g.T) {
-                v = ld4(a_row[i] + kk);
-                if (g.pool && ts + 1 < g.T) v = max4(v, ld4(a_row[i] + kk + g.lda));
-            }
+            const bool ok = a_ok[i] && kin && ts >= 0 && ts < g.T;
+            const unsigned off = ok ? (unsigned)(a_off[i] + kk) * 4u : 0xFFFFFFFFu;
+            float4 v = buf4(a_rs, off);
+            if (g.pool) v = max4(v, buf4(a_rs, (ok && ts + 1 < g.T) ? off + (unsigned)g.lda * 4u : off));
             ra[i] = v;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b_ok[i] && kin) w = ld4(b_row[i] + kk);
-            rb[i] = w;
+            rb[i] = buf4(b_rs, (b_ok[i] && kin) ? (unsigned)(b_off[i] + kk) * 4u : 0xFFFFFFFFu);
         }
     };
     auto store_tile = [&]() {
@@ -222,7 +228,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
 
 hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups) {
     int max_n = 0;
-    for (int i = 0; i < n_groups; ++i) max_n = b.g[i].N > max_n ? b.g[i].N : max_n;
+    for (int i = 0; i < n_groups; ++i) {
+        const GemmGroup& g = b.g[i];
+        max_n = g.N > max_n ? g.N : max_n;
+        // the operands are addressed with 32-bit byte offsets (buffer loads): refuse what does not fit
+        const size_t a_rows = g.gather ? (size_t)g.gather_rows : (size_t)g.M + (size_t)(g.pool ? 1 : 0);
+        if (a_rows * (size_t)g.lda * 4 >= 0xFFFFFFF0ull || (size_t)g.N * (size_t)g.K * 4 >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    }
     const int m_blocks = (b.g[0].M + BM - 1) / BM;
     dim3 grid((m_blocks + 7) / 8 * 8, (max_n + BN - 1) / BN, n_groups);   // M-blocks padded to the XCD count (see the tile map)
     bool denorm = false;
