@@ -76,8 +76,25 @@ struct tts_handle_s {
     hipEvent_t ev_front_done = nullptr;
     hipEvent_t ev_post_done[2] = {nullptr, nullptr};   // post-net of the calls of even / odd parity
     bool post_pending[2] = {false, false};
+    bool front_pending = false;     // ev_front_done has been recorded at least once
     unsigned syn_calls = 0;
     int syn_shape[3] = {0, 0, 0};   // (B, Ts, n_steps) of the previous tts_synthesize call
+    // persistent decoder (decoder_persistent.hip).  1 (default): under the call pipeline, where it takes the decoder
+    // from ~21 to ~17 ms and no longer disturbs Griffin-Lim with launch boundaries; a stand-alone decoder call keeps
+    // the launch-per-layer graph, which is faster on an idle chip (9.4 against 14.6 ms at B = 64).  2: always
+    // (where the configuration allows it).  0: never.
+    int persistent_decoder = 1;
+    int gl_fused = 0;                // all Griffin-Lim iterations of a call in one launch (gl_iter_kernel, FUSED): same
+                                     // waveforms, measured no faster, so off unless asked for
+    bool gl_fused_used = false;      // a fused launch has been enqueued since the last status check
+    int* gl_status = nullptr;
+    int n_cus_dev = 0;
+    bool pd_configured = false;
+    bool pd_used = false;            // a persistent launch has been enqueued since the last status check
+    unsigned* pd_sync = nullptr;     // counters + status word of the last persistent launch
+    int pd_clusters = 0;
+    int* cur_hold_flag = nullptr;    // set by tts_synthesize around its decoder call: the sleepers' flag
+    int cur_cu_budget = 0;           // ... and the compute units the front stream may count on (0 = the whole chip)
 
     std::vector<ManifestEntry> manifest;
     std::map<std::string, std::vector<float>> host_w;
@@ -493,6 +510,26 @@ int sync_all(tts_handle_t h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->front && h->front != h->stream) HIPCHK(h, hipStreamSynchronize(h->front));
     if (h->aux) HIPCHK(h, hipStreamSynchronize(h->aux));
+    if (h->gl_fused_used) {
+        h->gl_fused_used = false;
+        int status = 0;
+        HIPCHK(h, hipMemcpy(&status, h->gl_status, sizeof(int), hipMemcpyDeviceToHost));
+        if (status)
+            return fail(h, TTS_ERR_HIP,
+                        "fused Griffin-Lim: a workgroup waited for a neighbour run longer than the bound (not all "
+                        "workgroups were co-resident); the waveforms of that call are invalid -- "
+                        "tts_set_option(h, \"gl_fused\", 0) selects one launch per iteration");
+    }
+    if (h->pd_used) {   // did every wait of the persistent decoder's last launch end by arrival?
+        h->pd_used = false;
+        int status = 0;
+        HIPCHK(h, hipMemcpy(&status, h->pd_sync + 64 * h->pd_clusters + 1, sizeof(int), hipMemcpyDeviceToHost));
+        if (status)
+            return fail(h, TTS_ERR_HIP,
+                        "persistent decoder: a workgroup waited for its cluster longer than the bound (not all "
+                        "workgroups were co-resident); the outputs of that call are invalid -- "
+                        "tts_set_option(h, \"persistent_decoder\", 0) selects the launch-per-layer path");
+    }
     return TTS_OK;
 }
 
@@ -844,7 +881,24 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     HIPCHK(h, launch_phase_init(h->stream, init_ft, seed, mag_int, ph0, B, F, T, FP));
     float2* cur = ph0;
     float2* nxt = ph1;
-    {
+    // One launch for all iterations when nothing per-iteration is asked for (gl_iter_kernel, FUSED); `free_cus`
+    // workgroups must all be resident, so under the call pipeline it is only used on the compute units the plan counts
+    const int free_cus = n_cus - held > 16 ? n_cus - held : n_cus;
+    const bool fused = h->gl_fused != 0 && !mse && n_iter > 1 && gl_fused_supported(p);
+    if (fused) {
+        ProfScope ps(h, ST_GL_ITER, n_iter);   // counted in iterations, like the separate launches
+        WS(h, "gl.done", unsigned, (size_t)p.n_items + 1, done);
+        HIPCHK(h, hipMemsetAsync(done, 0, ((size_t)p.n_items + 1) * sizeof(unsigned), h->stream));
+        p.n_fused = n_iter;
+        p.buf[0] = ph0; p.buf[1] = ph1;
+        p.done = done;
+        p.status = reinterpret_cast<int*>(done + p.n_items);
+        p.work_counter = counters;
+        HIPCHK(h, launch_gl_fused(h->stream, p, free_cus));
+        if (n_iter & 1) std::swap(cur, nxt);
+        h->gl_status = p.status;
+        h->gl_fused_used = true;
+    } else {
         ProfScope ps(h, ST_GL_ITER, n_iter);
         for (int it = 0; it < n_iter; ++it) {
             p.phase_in = cur;
@@ -979,6 +1033,11 @@ int tts_create(const tts_config_t* cfg, int device_id, tts_handle_t* out) {
         return fail(nullptr, TTS_ERR_HIP, "hipStreamCreate failed");
     }
     h->own_stream = true;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus < 1) cus = 256;
+        h->n_cus_dev = cus;
+    }
     build_manifest(h);
     *out = h;
     return TTS_OK;
@@ -1054,6 +1113,8 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     if (!h || !key) return TTS_ERR_INVALID;
     if (!std::strcmp(key, "use_graph")) h->use_graph = value;
     else if (!std::strcmp(key, "profile")) h->profile = value;
+    else if (!std::strcmp(key, "persistent_decoder")) h->persistent_decoder = value;
+    else if (!std::strcmp(key, "gl_fused")) h->gl_fused = value;
     else if (!std::strcmp(key, "reserve_cus")) {
         h->reserve_cus = value;
     } else if (!std::strcmp(key, "hold_lds_kb")) {
@@ -1371,7 +1432,23 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
     // keys = memory_layer(memory), no bias (LuongAttention; values stay the raw memory)
     if ((rc = run_single(h, dense_group(memory, mem, h->mem_wt, nullptr, keys, A, B * Ts, A, mem, ACT_NONE)))) return rc;
 
-    if (!h->use_graph) {
+    const int pd_budget = h->cur_cu_budget > 0 ? h->cur_cu_budget : h->n_cus_dev;
+    const bool pd_wanted = h->persistent_decoder >= 2 || (h->persistent_decoder == 1 && h->cur_cu_budget > 0);
+    const bool use_pd = pd_wanted && decoder_persistent_supports(h->dec, c.force_cudnn, B, Ts) &&
+                        decoder_persistent_workgroups(B) <= pd_budget;
+    if (use_pd) {
+        if (!h->pd_configured) {
+            HIPCHK(h, decoder_persistent_configure());
+            h->pd_configured = true;
+        }
+        const int clusters = (B + 15) / 16;
+        WS(h, "dec.pd_sync", unsigned, (size_t)64 * clusters + 2, pd_sync);
+        HIPCHK(h, decoder_persistent_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, alignments, pd_sync,
+                                             h->cur_hold_flag));
+        h->pd_sync = pd_sync;
+        h->pd_clusters = clusters;
+        h->pd_used = true;
+    } else if (!h->use_graph) {
         HIPCHK(h, decoder_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, alignments, c.force_cudnn));
     } else {
         auto& k = h->dec_key;
@@ -1653,6 +1730,9 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         if (h->reserve_cus > 0) {
             // reserve CUs for the front stream while the previous call's Griffin-Lim fills the rest
             hold_flag = h->hold_flags + (h->call_count++ & 1);
+            // the persistent decoder releases its call's sleepers as soon as it is resident: the next set must not
+            // start (and take another `reserve_cus` away from Griffin-Lim) before that decoder has finished
+            if (h->front_pending) HIPCHK(h, hipStreamWaitEvent(h->aux, h->ev_front_done, 0));
             HIPCHK(h, hipMemsetAsync(hold_flag, 0, sizeof(int), h->aux));
             HIPCHK(h, hipEventRecord(h->ev_aux, h->aux));
             HIPCHK(h, launch_cu_hold(h->aux, h->reserve_cus, hold_flag, 100.0, h->hold_lds_kb));
@@ -1661,7 +1741,11 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         h->stream = h->front;
     }
     rc = tts_encoder_forward(h, ids, B, Ts, memory);
+    h->cur_hold_flag = hold_flag;
+    h->cur_cu_budget = hold_flag ? h->reserve_cus : 0;
     if (!rc) rc = tts_decoder_forward(h, memory, B, Ts, sp->n_steps, mel, align_out);
+    h->cur_hold_flag = nullptr;
+    h->cur_cu_budget = 0;
     h->stream = main_stream;
     if (rc) {
         if (hold_flag) hipMemsetAsync(hold_flag, 1, sizeof(int), h->front);
@@ -1670,6 +1754,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     if (pipelined) {
         if (hold_flag) HIPCHK(h, hipMemsetAsync(hold_flag, 1, sizeof(int), h->front));   // release the held CUs
         HIPCHK(h, hipEventRecord(h->ev_front_done, h->front));
+        h->front_pending = true;
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_front_done, 0));
     }
     int* db_flag = nullptr;

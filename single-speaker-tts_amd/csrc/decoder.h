@@ -74,4 +74,27 @@ hipError_t decoder_enqueue(hipStream_t s, const DecoderWeights& w, const Decoder
                            const float* memory, const float* keys, int B, int Ts, int n_steps,
                            float* align, int cudnn);
 
+// ---- persistent form (decoder_persistent.hip): one launch for the whole loop, GRUCell form + global attention only
+struct PdParams {
+    const float *w1, *b1, *w1f, *b1f, *w2, *b2;   // pre-net (step 0 / folded / layer 2)
+    const float *ag_w, *ag_b, *ac_w, *ac_b;       // attention GRU gates / candidate
+    const float* al_w;                            // attention layer
+    const float *g_gw[2], *g_gb[2], *g_cw[2], *g_cb[2];
+    const float *memory, *keys;                   // [B][Ts][256]
+    float *att, *h_att, *h_dec[2], *p1, *p2, *rh, *ctx, *y0, *yhist;   // hand-off buffers [B][.] (state zeroed per call)
+    float* align;                                 // [n_steps][B][Ts] or null
+    unsigned* counters;                           // [clusters][64]: one arrival counter per cluster, zeroed per call
+    unsigned* resident;                           // workgroups that have started
+    int* status;                                  // set to 1 when a wait timed out (results are then invalid)
+    int* hold_flag;                               // optional: raised once every workgroup is resident (reserve.hip sleepers)
+    int B, Ts, n_steps, n_mels;
+};
+bool decoder_persistent_supports(const DecoderWeights& w, int cudnn, int B, int Ts);
+int decoder_persistent_workgroups(int B);         // compute units the launch needs all to itself
+hipError_t decoder_persistent_configure();        // per device
+// `sync`: 64 * ceil(B / 16) + 2 unsigned words
+hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, const DecoderScratch& sc, const float* memory,
+                                      const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync,
+                                      int* hold_flag);
+
 }  // namespace tts

@@ -1,0 +1,475 @@
+// Persistent form of the Luong-attention GRU decoder loop (gfx950): ONE launch for all n_steps steps.
+//
+// Same arithmetic as decoder.hip (reference tacotron/model.py:191-331, wrappers.py:94-124, helpers.py:83-110,
+// 161-205; GRUCell form, global LuongAttention) -- what changes is who waits for whom.  decoder.hip issues ten
+// dependent launches per step; under the call pipeline every one of them queues behind whatever else the chip is
+// running.  Here a CLUSTER of PD_W workgroups (one per CU, 1024 threads) owns 16 utterances for the whole loop:
+//   * every layer of a step is a phase; workgroup j of the cluster computes the same slice of output units in
+//     every step (32 of 256 units, 16 of the 128 of pre-net 2; for a GRU its r AND u columns, so the update gate
+//     and the cell state of its units never leave its LDS), K split over the waves, v_mfma_f32_16x16x4_f32;
+//   * the weights of the NEXT phase are fetched from L2 into registers BEFORE the workgroup waits for its peers
+//     (they do not depend on data);
+//   * activations travel between the workgroups of a cluster through small global buffers with the write-through
+//     hand-off of MI355X_MICROARCH.md ("valid forms"): every byte stored sc1, every storing wave waits vmcnt(0),
+//     a workgroup barrier, ONE lane adds to the cluster's counter (agent scope); consumers poll that counter with
+//     an sc1 load in one lane, then a workgroup barrier, then sc1 loads of the bytes.  No cache-wide release or
+//     acquire anywhere, no grid-wide barrier: clusters never talk to each other;
+//   * attention: workgroup j scores, normalises and contracts two of the cluster's 16 rows itself, so softmax
+//     needs no cross-workgroup merge and the alignments are written normalised.
+// Every wait is bounded (PD_SPIN_LIMIT polls); on a timeout the status word is set, every workgroup of the grid
+// sees it at its next wait and the kernel drains.  All workgroups must be co-resident: the host only uses this
+// path when 8 * ceil(B / 16) compute units are free for it (api.hip).
+#include "tts_common.h"
+#include "decoder.h"
+#include <cstdio>
+
+namespace tts {
+
+#define PD_W 8
+#define PD_NW 16
+#define PD_THREADS (PD_NW * 64)
+#define PD_D 256                  // attention units = decoder units = memory depth = pre-net 1 units
+#define PD_P2 128                 // pre-net 2 units
+#define PD_LDA 516                // LDS row stride (floats) of the staged A tile: K <= 512; +4 keeps b128 reads conflict-free
+#define PD_RED_LD 20              // row stride of the per-wave partial tiles (b128 aligned)
+#define PD_SPIN_LIMIT 2000000u      // polls of ~1 us each
+
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned pd_u32x4;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pd_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)0xFFFFFFF0u, 0x00020000);
+}
+// 16-byte sc1 (write-through / L1-bypassing) accesses: aux bit 4
+__device__ __forceinline__ float4 pd_ld4(const __amdgpu_buffer_rsrc_t& rs, unsigned byte_off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16));
+}
+__device__ __forceinline__ void pd_st4(const __amdgpu_buffer_rsrc_t& rs, unsigned byte_off, float4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pd_u32x4, v), rs, (int)byte_off, 0, 16);
+}
+
+enum PdEpi { PD_ACT = 0, PD_GATES = 1, PD_CAND = 2 };
+
+#ifdef PD_TIMELINE   // tools only: s_memrealtime stamps (100 MHz) of workgroup 0 in step 100, [phase][8]
+__device__ unsigned long long* pd_dbg = nullptr;
+__device__ int pd_dbg_step = -1, pd_dbg_phase = 0;
+#define PD_STAMP(I)                                                                                       \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && pd_dbg && pd_dbg_step == 100)                             \
+        pd_dbg[pd_dbg_phase * 8 + (I)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define PD_STAMP(I)
+#endif
+
+struct PdPhase {
+    const float* a0; int lda0; int k0;   // A columns [0, k0): a0 (null = zeros), row stride lda0
+    const float* a1; int lda1;           // A columns [k0, K)
+    int K;
+    const float* Wt;                     // [N][K]
+    const float* bias;                   // [N] or null
+    int ub;                              // units of this layer owned per workgroup (32 or 16)
+    int epi, act, layer;
+    float* out; int ldo;                 // PD_ACT: activations; PD_GATES: r*h; PD_CAND: new state h
+    float* yout; int ldy;                // PD_CAND with residual: y = x + h'
+};
+
+// LDS map (floats)
+#define PD_OFF_AS 0
+#define PD_OFF_RED (16 * PD_LDA)
+#define PD_OFF_H (PD_OFF_RED + PD_NW * 16 * PD_RED_LD)
+#define PD_OFF_U (PD_OFF_H + 3 * 16 * 32)
+#define PD_OFF_CTRL (PD_OFF_U + 16 * 32)
+#define PD_OFF_SC (PD_OFF_CTRL + 16)
+size_t pd_lds_bytes(int Ts) { return ((size_t)PD_OFF_SC + 2 * (size_t)((Ts + 3) & ~3)) * sizeof(float); }
+
+// Start of a phase: signal that this workgroup's stores of the PREVIOUS phase are complete (pd_publish ran), then
+// wait until `target` arrivals have been counted on the cluster's counter.  Lane 0 of the workgroup does both; the
+// arrival is issued here, after the caller has put its weight loads in flight, because the lane that adds also
+// waits for the add's round trip before its next memory access returns.
+__device__ __forceinline__ void pd_wait(unsigned* cnt, unsigned target, int* status, int* ctrl) {
+    if (threadIdx.x == 0 && target > 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ctrl[0] == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 1023u) == 0 &&
+                    (spins > PD_SPIN_LIMIT || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ctrl[0] = 1;   // drain: no further waits in this workgroup
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// End of a phase: every storing wave waits for its (write-through) stores, then the workgroup barrier -- after it
+// one lane may signal for all of them (pd_wait of the next phase).
+__device__ __forceinline__ void pd_publish() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// One GEMM-shaped phase of the cluster: out[16 rows][this workgroup's units] = epi([a0 | a1] . Wt^T + bias).
+__device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, int j, int b0, int B, unsigned* cnt, unsigned target,
+                                         int* status) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    float* As = lds + PD_OFF_AS;
+    float* red = lds + PD_OFF_RED;
+    float* h_loc = lds + PD_OFF_H + ph.layer * (16 * 32);
+    float* u_loc = lds + PD_OFF_U;
+    int* ctrl = reinterpret_cast<int*>(lds + PD_OFF_CTRL);
+
+    const int gates = ph.epi == PD_GATES ? 2 : 1;
+    const int tpg = ph.ub >> 4;                 // 16-column tiles per gate
+    const int tiles = gates * tpg;              // 1, 2 or 4
+    const int ksl = PD_NW / tiles;              // K slices
+    const int tile = wave % tiles, slice = wave / tiles;
+    const int gate = tile / tpg, within = tile - gate * tpg;
+    const int nch = ph.K >> 4;
+
+    // ---- this wave's weight fragments: independent of every other workgroup, so they are in flight during the wait
+    const int n = gate * PD_D + j * ph.ub + 16 * within + r;
+    const float* wrow = ph.Wt + (size_t)n * ph.K + 4 * q;
+    float4 bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = slice + ksl * i;
+        bv[i] = *reinterpret_cast<const float4*>(wrow + 16 * (c < nch ? c : nch - 1));
+    }
+
+    PD_STAMP(0)
+    pd_wait(cnt, target, status, ctrl);
+    PD_STAMP(1)
+
+    // ---- stage the cluster's A tile (16 rows x K) in LDS: sc1 loads of the handed-off activations
+    {
+        const int k4 = ph.K >> 2;                 // float4 per row
+        const __amdgpu_buffer_rsrc_t r0 = pd_rsrc(ph.a0 ? ph.a0 : ph.a1), r1 = pd_rsrc(ph.a1);
+        for (int i = tid; i < 16 * k4; i += PD_THREADS) {
+            const int row = i / k4, kk = (i - row * k4) * 4;
+            const int b = b0 + row < B ? b0 + row : B - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk < ph.k0) {
+                if (ph.a0) v = pd_ld4(r0, (unsigned)(b * ph.lda0 + kk) * 4u);
+            } else {
+                v = pd_ld4(r1, (unsigned)(b * ph.lda1 + kk - ph.k0) * 4u);
+            }
+            *reinterpret_cast<float4*>(As + row * PD_LDA + kk) = v;
+        }
+    }
+    __syncthreads();
+    PD_STAMP(2)
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = slice + ksl * i;
+        if (c < nch) {   // wave-uniform
+            const float4 av = *reinterpret_cast<const float4*>(As + r * PD_LDA + 16 * c + 4 * q);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[i].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[i].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[i].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[i].w, acc, 0, 0, 0);
+        }
+    }
+    // C/D map of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[(wave * 16 + q * 4 + i) * PD_RED_LD + r] = acc[i];
+    __syncthreads();
+    PD_STAMP(3)
+
+    // ---- epilogue: thread e owns (tile, row, 4 consecutive columns); K slices added in a fixed order
+    if (tid < tiles * 64) {
+        const int et = tid >> 6, row = (tid >> 2) & 15, c4 = (tid & 3) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < ksl; ++s) {
+            const float4 t4 = *reinterpret_cast<const float4*>(red + ((et + tiles * s) * 16 + row) * PD_RED_LD + c4);
+            v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
+        }
+        const int eg = et / tpg, ew = et - eg * tpg;
+        const int cl = 16 * ew + c4;             // column inside this workgroup's unit block
+        const int unit = j * ph.ub + cl;
+        if (ph.bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(ph.bias + eg * PD_D + unit);
+            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        }
+        const bool row_ok = b0 + row < B;
+        const int b = b0 + row;
+        if (ph.epi == PD_ACT) {
+            v.x = apply_act(v.x, ph.act); v.y = apply_act(v.y, ph.act); v.z = apply_act(v.z, ph.act); v.w = apply_act(v.w, ph.act);
+            if (row_ok) pd_st4(pd_rsrc(ph.out), (unsigned)(b * ph.ldo + unit) * 4u, v);
+        } else if (ph.epi == PD_GATES) {
+            v.x = sigmoidf_(v.x); v.y = sigmoidf_(v.y); v.z = sigmoidf_(v.z); v.w = sigmoidf_(v.w);
+            if (eg == 0) {   // r: hand r*h to the candidate's K operand
+                const float4 h4 = *reinterpret_cast<const float4*>(h_loc + row * 32 + cl);
+                v.x *= h4.x; v.y *= h4.y; v.z *= h4.z; v.w *= h4.w;
+                if (row_ok) pd_st4(pd_rsrc(ph.out), (unsigned)(b * ph.ldo + unit) * 4u, v);
+            } else {         // u: stays in this workgroup
+                *reinterpret_cast<float4*>(u_loc + row * 32 + cl) = v;
+            }
+        } else {   // PD_CAND: h' = u h + (1 - u) tanh(.)
+            const float4 h4 = *reinterpret_cast<const float4*>(h_loc + row * 32 + cl);
+            const float4 u4 = *reinterpret_cast<const float4*>(u_loc + row * 32 + cl);
+            float4 hn;
+            hn.x = u4.x * h4.x + (1.0f - u4.x) * tanhf_(v.x);
+            hn.y = u4.y * h4.y + (1.0f - u4.y) * tanhf_(v.y);
+            hn.z = u4.z * h4.z + (1.0f - u4.z) * tanhf_(v.z);
+            hn.w = u4.w * h4.w + (1.0f - u4.w) * tanhf_(v.w);
+            *reinterpret_cast<float4*>(h_loc + row * 32 + cl) = hn;
+            if (row_ok) pd_st4(pd_rsrc(ph.out), (unsigned)(b * ph.ldo + unit) * 4u, hn);
+            if (ph.yout) {   // ResidualWrapper: y = x + h'; x is the first K segment of the staged tile
+                const float4 x4 = *reinterpret_cast<const float4*>(As + row * PD_LDA + unit);
+                hn.x += x4.x; hn.y += x4.y; hn.z += x4.z; hn.w += x4.w;
+                if (row_ok) pd_st4(pd_rsrc(ph.yout), (unsigned)(b * ph.ldy + unit) * 4u, hn);
+            }
+        }
+    }
+    PD_STAMP(4)
+    pd_publish();
+    PD_STAMP(5)
+}
+
+// Luong dot attention for rows 2j and 2j+1 of the cluster (TF-1.8 _luong_score / _compute_attention; dot form at
+// reference attention.py:396-400): softmax over ALL Ts positions, context = alignments . memory.
+__device__ __forceinline__ void pd_attention(const float* __restrict__ query, const float* __restrict__ keys,
+                                             const float* __restrict__ values, float* ctx, float* align_t, int Ts, float* lds,
+                                             int j, int b0, int B, unsigned* cnt, unsigned target, int* status) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = wave >> 3, hw = wave & 7, t512 = tid & 511;
+    float* qs = lds + PD_OFF_AS + half * PD_D;                        // [2][256]
+    float* part = lds + PD_OFF_AS + 2 * PD_D + half * (8 * PD_D);     // [2][8][256]
+    float* redm = lds + PD_OFF_RED + half * 16;                       // [2][8] max, then [2][8] sum at +8... see below
+    const int Tsp = (Ts + 3) & ~3;
+    float* sc = lds + PD_OFF_SC + half * Tsp;
+    int* ctrl = reinterpret_cast<int*>(lds + PD_OFF_CTRL);
+
+    const int row = b0 + 2 * j + half;
+    const bool row_ok = row < B;
+    const int rr = row_ok ? row : B - 1;
+
+    PD_STAMP(0)
+    pd_wait(cnt, target, status, ctrl);
+    PD_STAMP(1)
+
+    if (t512 < 64) *reinterpret_cast<float4*>(qs + 4 * t512) = pd_ld4(pd_rsrc(query), (unsigned)(rr * PD_D + 4 * t512) * 4u);
+    __syncthreads();
+
+    // scores: 16 lanes per key, 32 keys per pass of the row's 8 waves
+    const int sub = lane >> 4, l16 = lane & 15;
+    const float* kb = keys + (size_t)rr * Ts * PD_D;
+    for (int j0 = 0; j0 < Ts; j0 += 32) {
+        const int jj = j0 + hw * 4 + sub;
+        float s = 0.f;
+        if (jj < Ts) {
+            const float* kr = kb + (size_t)jj * PD_D;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d0 = (l16 + 16 * i) * 4;
+                const float4 kv = *reinterpret_cast<const float4*>(kr + d0);
+                const float4 qv = *reinterpret_cast<const float4*>(qs + d0);
+                s = fmaf(kv.x, qv.x, s);
+                s = fmaf(kv.y, qv.y, s);
+                s = fmaf(kv.z, qv.z, s);
+                s = fmaf(kv.w, qv.w, s);
+            }
+        }
+        s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 1);
+        if (jj < Ts && l16 == 0) sc[jj] = s;
+    }
+    __syncthreads();
+
+    PD_STAMP(2)
+    float m = -INFINITY;
+    for (int jj = t512; jj < Ts; jj += 512) m = fmaxf(m, sc[jj]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) redm[hw] = m;
+    __syncthreads();
+    m = redm[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) m = fmaxf(m, redm[i]);
+    float sum = 0.f;
+    for (int jj = t512; jj < Ts; jj += 512) {
+        const float e = __expf(sc[jj] - m);
+        sc[jj] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    __syncthreads();   // everyone has read the maxima
+    if (lane == 0) redm[hw] = sum;
+    __syncthreads();
+    sum = ((redm[0] + redm[1]) + (redm[2] + redm[3])) + ((redm[4] + redm[5]) + (redm[6] + redm[7]));
+    const float inv = 1.0f / sum;
+
+    PD_STAMP(3)
+    // context: wave hw takes positions hw, hw + 8, ...; lane d4 owns 4 consecutive depth elements (1 KB rows, coalesced)
+    const float* vb = values + (size_t)rr * Ts * PD_D + 4 * lane;
+    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+    int jj = hw;
+    for (; jj + 8 < Ts; jj += 16) {
+        const float e0 = sc[jj], e1 = sc[jj + 8];
+        const float4 v0 = *reinterpret_cast<const float4*>(vb + (size_t)jj * PD_D);
+        const float4 v1 = *reinterpret_cast<const float4*>(vb + (size_t)(jj + 8) * PD_D);
+        c0.x = fmaf(e0, v0.x, c0.x); c0.y = fmaf(e0, v0.y, c0.y); c0.z = fmaf(e0, v0.z, c0.z); c0.w = fmaf(e0, v0.w, c0.w);
+        c1.x = fmaf(e1, v1.x, c1.x); c1.y = fmaf(e1, v1.y, c1.y); c1.z = fmaf(e1, v1.z, c1.z); c1.w = fmaf(e1, v1.w, c1.w);
+    }
+    if (jj < Ts) {
+        const float e0 = sc[jj];
+        const float4 v0 = *reinterpret_cast<const float4*>(vb + (size_t)jj * PD_D);
+        c0.x = fmaf(e0, v0.x, c0.x); c0.y = fmaf(e0, v0.y, c0.y); c0.z = fmaf(e0, v0.z, c0.z); c0.w = fmaf(e0, v0.w, c0.w);
+    }
+    c0.x += c1.x; c0.y += c1.y; c0.z += c1.z; c0.w += c1.w;
+    *reinterpret_cast<float4*>(part + hw * PD_D + 4 * lane) = c0;
+    __syncthreads();
+    if (t512 < 64) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const float4 t4 = *reinterpret_cast<const float4*>(part + w * PD_D + 4 * t512);
+            a.x += t4.x; a.y += t4.y; a.z += t4.z; a.w += t4.w;
+        }
+        a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+        if (row_ok) pd_st4(pd_rsrc(ctx), (unsigned)(row * PD_D + 4 * t512) * 4u, a);
+    }
+    if (align_t && row_ok)
+        for (int k = t512; k < Ts; k += 512) align_t[(size_t)row * Ts + k] = sc[k] * inv;
+    PD_STAMP(4)
+    pd_publish();
+    PD_STAMP(5)
+}
+
+__global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int cluster = blockIdx.x / PD_W, j = blockIdx.x - cluster * PD_W;
+    const int b0 = cluster * 16;
+    unsigned* cnt = p.counters + 64 * cluster;
+    int* ctrl = reinterpret_cast<int*>(lds + PD_OFF_CTRL);
+    for (int i = tid; i < 3 * 16 * 32 + 16 * 32; i += PD_THREADS) lds[PD_OFF_H + i] = 0.f;   // zero_state
+    if (tid == 0) {
+        ctrl[0] = 0;
+        // all workgroups resident: the CUs the call pipeline held for this stream are no longer needed
+        const unsigned n = __hip_atomic_fetch_add(p.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n + 1 == gridDim.x && p.hold_flag) __hip_atomic_store(p.hold_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+
+    const int yld = p.n_steps * PD_D;
+    unsigned g = 0;   // phases completed by the cluster
+    for (int t = 0; t < p.n_steps; ++t) {
+        // ONE instance of the phase body in a loop over the step's ten phases (ten inlined copies spill)
+#pragma nounroll
+        for (int k = 0; k < 10; ++k, ++g) {
+#ifdef PD_TIMELINE
+            if (blockIdx.x == 0 && threadIdx.x == 0) { pd_dbg_step = t; pd_dbg_phase = k; }
+#endif
+            if (k == 4) {
+                pd_attention(p.h_att, p.keys, p.memory, p.ctx, p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr, p.Ts, lds, j,
+                             b0, p.B, cnt, PD_W * g, p.status);
+                continue;
+            }
+            PdPhase ph;
+            ph.lda0 = PD_D; ph.k0 = PD_D; ph.lda1 = PD_D; ph.K = 2 * PD_D; ph.ub = 32; ph.act = ACT_NONE; ph.layer = 0;
+            ph.ldo = PD_D; ph.yout = nullptr; ph.ldy = PD_D; ph.bias = nullptr;
+            switch (k) {
+                case 0:
+                    // PrenetWrapper on concat([x_t, attention_{t-1}]) (wrappers.py:122-124); x_0 = GO frame = zeros
+                    // (helpers.py:108), x_t = (y_{t-1} W_o + b_o)[-n_mels:] folded into the pre-net matrix (decoder.hip)
+                    ph.a0 = t == 0 ? nullptr : p.yhist + (size_t)(t - 1) * PD_D; ph.lda0 = yld; ph.k0 = t == 0 ? p.n_mels : PD_D;
+                    ph.a1 = p.att; ph.K = ph.k0 + PD_D;
+                    ph.Wt = t == 0 ? p.w1 : p.w1f; ph.bias = t == 0 ? p.b1 : p.b1f;
+                    ph.epi = PD_ACT; ph.act = ACT_RELU; ph.out = p.p1;
+                    break;
+                case 1:
+                    ph.a0 = p.p1; ph.a1 = p.p1; ph.K = PD_D; ph.Wt = p.w2; ph.bias = p.b2; ph.ub = 16;
+                    ph.epi = PD_ACT; ph.act = ACT_RELU; ph.out = p.p2; ph.ldo = PD_P2;
+                    break;
+                case 2:   // attention GRU (model.py:226-229): gates on [p2 ; h_att]
+                    ph.a0 = p.p2; ph.lda0 = PD_P2; ph.k0 = PD_P2; ph.a1 = p.h_att; ph.K = PD_P2 + PD_D;
+                    ph.Wt = p.ag_w; ph.bias = p.ag_b; ph.epi = PD_GATES; ph.out = p.rh;
+                    break;
+                case 3:   // ... candidate on [p2 ; r*h_att]; the new state is the attention query
+                    ph.a0 = p.p2; ph.lda0 = PD_P2; ph.k0 = PD_P2; ph.a1 = p.rh; ph.K = PD_P2 + PD_D;
+                    ph.Wt = p.ac_w; ph.bias = p.ac_b; ph.epi = PD_CAND; ph.out = p.h_att;
+                    break;
+                case 5:   // attention_layer(concat([cell_output, context])), no bias
+                    ph.a0 = p.h_att; ph.a1 = p.ctx; ph.Wt = p.al_w; ph.epi = PD_ACT; ph.out = p.att;
+                    break;
+                default: {   // 6..9: two ResidualWrapper(GRUCell) layers (model.py:254-269); the top one writes the y history
+                    const int l = (k - 6) >> 1;
+                    const bool cand = (k - 6) & 1;
+                    ph.a0 = l == 0 ? p.att : p.y0; ph.a1 = cand ? p.rh : p.h_dec[l];
+                    ph.Wt = cand ? p.g_cw[l] : p.g_gw[l]; ph.bias = cand ? p.g_cb[l] : p.g_gb[l];
+                    ph.epi = cand ? PD_CAND : PD_GATES; ph.layer = 1 + l; ph.out = cand ? p.h_dec[l] : p.rh;
+                    if (cand) { ph.yout = l == 0 ? p.y0 : p.yhist + (size_t)t * PD_D; ph.ldy = l == 0 ? PD_D : yld; }
+                } break;
+            }
+            pd_phase(ph, lds, j, b0, p.B, cnt, PD_W * g, p.status);
+        }
+    }
+}
+
+bool decoder_persistent_supports(const DecoderWeights& w, int cudnn, int B, int Ts) {
+    return !cudnn && w.local_d == 0 && w.n_layers == 2 && w.att_units == PD_D && w.dec_units == PD_D && w.mem_units == PD_D &&
+           w.prenet1_units == PD_D && w.prenet2_units == PD_P2 && w.n_mels % 16 == 0 && w.n_mels <= PD_D && B >= 1 && Ts >= 1 &&
+           pd_lds_bytes(Ts) <= 160 * 1024 && (size_t)B * Ts * PD_D * 4 < 0xFFFFFFF0ull;
+}
+
+int decoder_persistent_workgroups(int B) { return PD_W * ((B + 15) / 16); }
+
+hipError_t decoder_persistent_configure() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024);
+}
+
+// Capturable: two memsets and one launch.  `sync` = 64 unsigned per cluster + 1 (resident count) + 1 (status word).
+hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, const DecoderScratch& sc, const float* memory,
+                                      const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync,
+                                      int* hold_flag) {
+    const int clusters = (B + 15) / 16;
+    hipError_t e;
+    if ((e = hipMemsetAsync(sc.state, 0, sc.state_bytes, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(sync, 0, ((size_t)64 * clusters + 2) * sizeof(unsigned), s)) != hipSuccess) return e;
+    PdParams p;
+    p.w1 = w.prenet1_wt; p.b1 = w.prenet1_b; p.w1f = w.prenet1f_wt; p.b1f = w.prenet1f_b; p.w2 = w.prenet2_wt; p.b2 = w.prenet2_b;
+    p.ag_w = w.att_gru.gates_wt; p.ag_b = w.att_gru.gates_b; p.ac_w = w.att_gru.cand_wt; p.ac_b = w.att_gru.cand_b;
+    p.al_w = w.attn_layer_wt;
+    for (int l = 0; l < 2; ++l) {
+        p.g_gw[l] = w.gru[l].gates_wt; p.g_gb[l] = w.gru[l].gates_b; p.g_cw[l] = w.gru[l].cand_wt; p.g_cb[l] = w.gru[l].cand_b;
+        p.h_dec[l] = sc.h_dec[l];
+    }
+    p.memory = memory; p.keys = keys;
+    p.att = sc.att; p.h_att = sc.h_att; p.p1 = sc.p1; p.p2 = sc.p2; p.rh = sc.rh; p.ctx = sc.ctx_parts; p.y0 = sc.y0;
+    p.yhist = sc.yhist; p.align = align;
+    p.counters = sync; p.resident = sync + 64 * clusters; p.status = reinterpret_cast<int*>(sync + 64 * clusters + 1);
+    p.hold_flag = hold_flag;
+    p.B = B; p.Ts = Ts; p.n_steps = n_steps; p.n_mels = w.n_mels;
+#ifdef PD_TIMELINE
+    {
+        static unsigned long long* dbg = nullptr;
+        if (dbg) {
+            (void)hipStreamSynchronize(s);
+            unsigned long long hst[80];
+            (void)hipMemcpy(hst, dbg, sizeof(hst), hipMemcpyDeviceToHost);
+            for (int k = 0; k < 10; ++k) {
+                fprintf(stderr, "phase %d:", k);
+                for (int i = 0; i < 6; ++i) fprintf(stderr, " [%d]%.2f", i, (double)(hst[k * 8 + i] - hst[0]) / 100.0);
+                fprintf(stderr, "\n");
+            }
+        } else {
+            (void)hipMalloc(&dbg, 80 * sizeof(unsigned long long));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(pd_dbg), &dbg, sizeof(dbg));
+        }
+    }
+#endif
+    hipLaunchKernelGGL(dec_persistent_kernel, dim3(PD_W * clusters), dim3(PD_THREADS), pd_lds_bytes(Ts), s, p);
+    return hipGetLastError();
+}
+
+}  // namespace tts

@@ -35,6 +35,11 @@ struct GlParams {
     int cls_C[GL_MAX_CLASSES], cls_n[GL_MAX_CLASSES], cls_t0[GL_MAX_CLASSES], cls_slot0[GL_MAX_CLASSES],
         cls_first[GL_MAX_CLASSES], cls_chunks[GL_MAX_CLASSES];
     unsigned* work_counter;  // zeroed counter of THIS launch: the persistent workgroups draw item ids from it
+    // fused launch (launch_gl_fused): n_fused iterations, iteration i reads buf[i & 1] and writes buf[(i + 1) & 1]
+    int n_fused;
+    float2* buf[2];
+    unsigned* done;          // [n_items] iterations each run has completed (zeroed per launch)
+    int* status;             // raised when a wait for a neighbour run timed out (the result is then invalid)
     unsigned long long* dbg; // tools only (-DGL_TIMELINE builds): [GL waves][64] s_memrealtime stamps of workgroup 0
 };
 
@@ -45,6 +50,8 @@ void gl_build_wlane(const float* window, const float* rwss, int win, int hop, in
 void gl_plan_items(GlParams& p, int n_workers);   // needs T, B, win, hop, ncol; sets C and the item classes
 hipError_t gl_configure();
 hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int n_cus, int final_istft);
+hipError_t launch_gl_fused(hipStream_t s, const GlParams& p, int n_cus);
+bool gl_fused_supported(const GlParams& p);
 hipError_t launch_gl_mse_reduce(hipStream_t s, const float* partial, int B, int nchunks, float denom, float* mse);
 hipError_t launch_mag_ft_to_tf(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP);
 hipError_t launch_tf_to_ft(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP);

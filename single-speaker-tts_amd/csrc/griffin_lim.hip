@@ -316,9 +316,29 @@ __device__ __forceinline__ float gl_stream_load(const float* p) { return __built
 __device__ __forceinline__ void gl_stream_store(cf* p, cf v) { __builtin_nontemporal_store(v, p); }
 #define GL_STREAM_LOAD(ptr) gl_stream_load(ptr)
 #define GL_STREAM_STORE(ptr, val) gl_stream_store((ptr), (val))
+// Spectrum estimate X between iterations.  Separate launches per iteration: plain loads, streaming stores.  FUSED
+// launch (several iterations in one kernel, see gl_iter_kernel): a run's neighbours are other workgroups, possibly
+// on other XCDs, so every load of X bypasses the L1 (sc1: a row is read once per iteration anyway) and the frames
+// a neighbour reads as its halo are stored write-through (sc1); MI355X_MICROARCH.md, valid hand-off forms.
+template <bool FUSED>
+__device__ __forceinline__ cf gl_x_load(const cf* p) {
+    if (FUSED)
+        return __builtin_bit_cast(cf, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT));
+    return *p;
+}
+template <bool FUSED>
+__device__ __forceinline__ void gl_x_store(cf* p, cf v, bool shared_frame) {
+    if (FUSED && shared_frame)   // wave-uniform
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    else
+        gl_stream_store(p, v);
+}
+#define GL_FUSED_SPIN_LIMIT 4000000u
 
 // LDS control words behind the exchange buffers
-enum { CT_FLAGS = 0 /* GL_NW overlap-add progress flags */, CT_BNEXT = 8, CT_NEXT_ITEM = 9, CT_WORDS = 16 };
+enum { CT_FLAGS = 0 /* GL_NW overlap-add progress flags */, CT_BNEXT = 8, CT_NEXT_ITEM = 9, CT_ABORT = 10 /* fused launch: a wait timed out */, CT_WORDS = 16 };
 
 // One Griffin-Lim iteration (MODE 0: phase_in -> phase_out) or the final iSTFT (MODE 1: phase_in -> wav).
 // WIN_CT / HOP_CT: compile-time window / hop (0 = take them from the parameters); the reference
@@ -328,7 +348,18 @@ enum { CT_FLAGS = 0 /* GL_NW overlap-add progress flags */, CT_BNEXT = 8, CT_NEX
 // registers and pulls work items (utterance, first frame, frame count) from a global counter until the
 // launch's item list is exhausted.  Items are numbered class-major, classes in descending frame count, so
 // the big items go first and the small ones balance the tail (GlParams::cls_*).
-template <int MODE, int WIN_CT, int HOP_CT, bool MSE>
+//
+// FUSED: p.n_fused iterations in ONE launch.  An iteration needs no grid-wide barrier: frame t of iteration i + 1
+// depends on frames t - halo .. t + halo of iteration i, i.e. a run only on itself and its two neighbour runs.  The
+// item list is dealt statically (workgroup w takes items w, w + grid, ... in every iteration, so a run's interior
+// frames stay with one workgroup), iteration i reads p.buf[i & 1] and writes the other buffer, and every run keeps
+// a count of its completed iterations in p.done[]: a workgroup starts (run, i) once both neighbours show >= i --
+// they have produced its halo frames AND finished reading the frames it is about to overwrite.  Waits are bounded
+// (GL_FUSED_SPIN_LIMIT polls, then p.status is raised and every workgroup leaves); all workgroups must be
+// co-resident (the host launches at most one per free compute unit).  What it buys: the workgroups never give up
+// their compute units between iterations (no launch gaps, nothing can slip onto a CU at the boundary) and a
+// workgroup that is ahead starts the next iteration instead of waiting for the slowest one.
+template <int MODE, int WIN_CT, int HOP_CT, bool MSE, bool FUSED = false>
 __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int win = WIN_CT ? WIN_CT : p.win;
@@ -351,8 +382,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     if (p.dbg && tid == 0) p.dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
     // ---------------- one-time setup
-    if (tid == 0) ctrl[CT_NEXT_ITEM] = (int)atomicAdd(p.work_counter, 1u);
+    if (tid == 0) ctrl[CT_NEXT_ITEM] = FUSED ? (int)blockIdx.x : (int)atomicAdd(p.work_counter, 1u);
     if (tid < CT_NEXT_ITEM) ctrl[tid] = 0;
+    if (tid == 0) ctrl[CT_ABORT] = 0;
     // All twiddles live in registers for the whole kernel (every lane uses the same 34 values for every
     // frame): twr[j] = W2048^{lane + 64 j} for the real-FFT split / merge passes, tw.a[k2-1] =
     // W1024^{lane k2} and tw.b for the FFT itself.  No table in LDS, no LDS read latency inside a round.
@@ -396,6 +428,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     float warm = 0.f, warm_acc = 0.f;   // see the end of the loop body
     GL_LOAD_WINDOW(1)                   // synthesis window for the first chunk; reloaded at the end of every phase B
     const int carry_len = (2 * halo - 1) * hop + win;   // samples that consecutive chunks of a run share
+    const int n_it = FUSED ? p.n_fused : 1;
+  for (int it = 0; it < n_it; ++it) {
+    if (FUSED) item = (int)blockIdx.x;
+    const cf* x_in = FUSED ? reinterpret_cast<const cf*>(p.buf[it & 1]) : reinterpret_cast<const cf*>(p.phase_in);
+    cf* x_out = FUSED ? reinterpret_cast<cf*>(p.buf[(it + 1) & 1]) : reinterpret_cast<cf*>(p.phase_out);
     while (item < p.n_items) {
         // ---------------- decode the work item (wave-uniform scalar code): a RUN of consecutive frames of one
         // utterance, processed in chunks of p.chunk frames.  The first chunk inverse-transforms its `halo`
@@ -412,10 +449,38 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         const int run_t0 = p.cls_t0[k] + jc * run_len;
         const int slot0 = p.cls_slot0[k] + jc * p.cls_chunks[k];   // ordinal of the run's first chunk in its utterance
         const float* magb = p.mag + (size_t)b * p.T * p.FP;
-        const cf* phb = reinterpret_cast<const cf*>(p.phase_in) + (size_t)b * p.T * p.FP;
+        const cf* phb = x_in + (size_t)b * p.T * p.FP;
         unsigned next_item_reg = 0;
-        if (tid == 0) next_item_reg = atomicAdd(p.work_counter, 1u);   // consumed before the first barrier below
+        if (tid == 0) next_item_reg = FUSED ? (unsigned)item + gridDim.x : atomicAdd(p.work_counter, 1u);   // consumed before the first barrier below
         int next_item = p.n_items;
+        if (FUSED && it > 0) {
+            // both neighbour runs (same utterance) must have completed `it` iterations
+            if (tid == 0) {
+                int nb[2] = {-1, -1};
+                const int tl = run_t0 - 1, tr = run_t0 + run_len;
+#pragma unroll
+                for (int q = 0; q < GL_MAX_CLASSES; ++q)
+                    if (q < p.n_classes) {
+                        const int c0 = p.cls_t0[q], c1 = c0 + p.cls_C[q] * p.cls_n[q];
+                        if (tl >= c0 && tl < c1) nb[0] = p.cls_first[q] + ((tl - c0) / p.cls_C[q]) * p.B + b;
+                        if (tr >= c0 && tr < c1) nb[1] = p.cls_first[q] + ((tr - c0) / p.cls_C[q]) * p.B + b;
+                    }
+                unsigned spins = 0;
+                for (int q = 0; q < 2; ++q)
+                    if (nb[q] >= 0)
+                        while (__hip_atomic_load(p.done + nb[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)it) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if ((++spins & 1023u) == 0 &&
+                                (spins > GL_FUSED_SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                                __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                ctrl[CT_ABORT] = 1;
+                                break;
+                            }
+                        }
+            }
+            __syncthreads();
+            if (ctrl[CT_ABORT]) return;   // workgroup-uniform
+        }
 
       for (int cq = 0, t0 = run_t0; t0 < run_t0 + run_len; ++cq) {
         const int left = run_t0 + run_len - t0;
@@ -442,8 +507,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         int tf_ = t0 - halo + (FA);                                                        \
         tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                  \
         const cf* prow_ = phb + (size_t)tf_ * p.FP + lane;                                 \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gk[j_] = prow_[64 * j_];                  \
-        nyq = reinterpret_cast<const float*>(phb + (size_t)tf_ * p.FP + MH)[0];            \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gk[j_] = gl_x_load<FUSED>(prow_ + 64 * j_); \
+        nyq = gl_x_load<FUSED>(phb + (size_t)tf_ * p.FP + MH).x;                            \
     }
         GL_LOAD_FRAME(fa0 + R * wave)
 
@@ -588,7 +653,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             }
         } else {
             // ---------------- phase B: forward FFT of the owned frames, new unit phasors
-            cf* pob = reinterpret_cast<cf*>(p.phase_out) + (size_t)b * p.T * p.FP;
+            cf* pob = x_out + (size_t)b * p.T * p.FP;
             float mse_acc = 0.f;
             // frames are handed out dynamically (LDS counter): the wave that wins issue arbitration on
             // its SIMD takes more of them, so both waves of a SIMD finish together
@@ -649,6 +714,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
                 wave_lds_sync();
                 cf* orow = pob + (size_t)t * p.FP;
+                // (FUSED) a frame within `halo` of the run's ends is a neighbour's halo frame
+                const bool shared_frame = FUSED && (t < run_t0 + halo || t >= run_t0 + run_len - halo);
                 // next estimate: target magnitude, new phase.  Fast path: x * (rsq(|x|^2) * |S|), valid
                 // while |x|^2 stays well inside the float range; the min / max of |x|^2 over the lane's
                 // bins are tracked and the (practically never taken) exact path below redoes the frame
@@ -667,7 +734,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                     const cf x = cadd_mi(e, o);
                     const float s = fmaf(x.x, x.x, x.y * x.y);
                     const float g = __builtin_amdgcn_rsqf(s) * mg[c];   // raw v_rsq_f32: s is range-checked below
-                    GL_STREAM_STORE(orow + k, x * g);
+                    gl_x_store<FUSED>(orow + k, x * g, shared_frame);
                     s_min = fminf(s_min, s);
                     s_max = fmaxf(s_max, s);
                     if (MSE) {
@@ -685,14 +752,14 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                         const cf e = cadd_conj(zk, zr);
                         const cf o = cmul(csub_conj(zk, zr), reinterpret_cast<const cf*>(p.tw2048)[k]);
                         const cf x = cadd_mi(e, o);
-                        orow[k] = cscale(unit_phasor(x), fabsf(mrow[k]));
+                        gl_x_store<FUSED>(orow + k, cscale(unit_phasor(x), fabsf(mrow[k])), shared_frame);
                     }
                 }
                 if (lane == 0) {
                     const cf z0 = v[0];
                     const float xn = z0.x - z0.y;   // Nyquist bin, real
                     const float mn = fabsf(mrow[MH]);
-                    orow[MH] = cmk(xn < 0.f ? -mn : mn, 0.f);
+                    gl_x_store<FUSED>(orow + MH, cmk(xn < 0.f ? -mn : mn, 0.f), shared_frame);
                     if (MSE) {
                         const float d = mn - (2.0f * MH) * fabsf(xn);   // xn = X[MH] / (2 MH)
                         mse_acc += d * d;
@@ -728,7 +795,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 const int Cn = (run_t0 + run_len - (t0 + C)) < p.chunk ? (run_t0 + run_len - (t0 + C)) : p.chunk;
                 const int Rn = (Cn + GL_NW - 1) / GL_NW;
                 tfn = t0 + C - halo + 2 * halo + (Rn > ncol ? Rn : ncol) * wave;
-            } else if (next_item < p.n_items) {
+            } else if (!FUSED && next_item < p.n_items) {   // (FUSED: those rows may not be written yet)
                 int k2 = 0;
 #pragma unroll
                 for (int q = 1; q < GL_MAX_CLASSES; ++q)
@@ -743,7 +810,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             }
             if (tfn >= 0) {
                 tfn = tfn >= p.T ? p.T - 1 : tfn;
-                const float* row2 = reinterpret_cast<const float*>(p.phase_in + ((size_t)bn * p.T + tfn) * p.FP);
+                const float* row2 = reinterpret_cast<const float*>(x_in + ((size_t)bn * p.T + tfn) * p.FP);
                 warm = row2[32 * lane];   // 64 lanes x 128 B = the first 8 KB of the 8224-byte row
             }
         }
@@ -760,8 +827,15 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         }
         t0 += C;
       }   // chunks of the run
+        if (FUSED) {
+            // the run's stores are complete (every wave waits for its own, then the barrier): one lane publishes
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(p.done + item, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         item = next_item;
     }
+  }   // fused iterations
     if (warm_acc == 1.2345e30f) ctrl[CT_WORDS - 1] = 1;   // keeps the warming loads alive; never true in practice
 #ifdef GL_TIMELINE
     if (p.dbg && tid == 0) {
@@ -958,8 +1032,34 @@ hipError_t gl_configure() {
 #endif
     if ((e = gl_set_attr<0, 1102, 275, false>()) != hipSuccess) return e;
     if ((e = gl_set_attr<1, 1102, 275, false>()) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_iter_kernel<0, 1102, 275, false, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+#ifndef GL_FAST_BUILD
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_iter_kernel<0, 0, 0, false, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+#endif
     return stft_configure();
 }
+
+// p.n_fused iterations in one launch (see gl_iter_kernel, FUSED): p.buf[0] holds the current estimate, the result is
+// in p.buf[p.n_fused & 1]; p.done (n_items words) and p.status must be zeroed; every workgroup of the grid must get
+// a compute unit (n_cus = the compute units that are free for it).
+hipError_t launch_gl_fused(hipStream_t s, const GlParams& p, int n_cus) {
+    const size_t lds = gl_lds_bytes(p);
+    if (lds <= 80 * 1024 || p.n_fused < 1 || !p.buf[0] || !p.buf[1] || !p.done || !p.status) return hipErrorInvalidValue;
+    const int nwg = p.n_items < n_cus ? p.n_items : n_cus;
+    const bool ref_cfg = p.win == 1102 && p.hop == 275;
+    if (ref_cfg) hipLaunchKernelGGL((gl_iter_kernel<0, 1102, 275, false, true>), dim3(nwg), dim3(GL_THREADS), lds, s, p);
+#ifndef GL_FAST_BUILD
+    else hipLaunchKernelGGL((gl_iter_kernel<0, 0, 0, false, true>), dim3(nwg), dim3(GL_THREADS), lds, s, p);
+#else
+    else return hipErrorInvalidValue;
+#endif
+    return hipGetLastError();
+}
+// (a signal buffer of <= 80 KB would put two workgroups on a compute unit: fine for separate launches, but the fused
+// launch counts on one workgroup per free compute unit, so such configurations keep the separate launches)
+bool gl_fused_supported(const GlParams& p) { return gl_lds_bytes(p) > 80 * 1024; }
 
 // p.work_counter must point at a zeroed counter that no other launch uses.
 hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int n_cus, int final_istft) {

@@ -140,11 +140,21 @@ def test_pipelined_calls_equal_sequential(engine):
         engine.synchronize()
         return [{k: v.to_host() for k, v in o.items()} for o in outs]
 
+    # the pipelined call runs the decoder as the persistent kernel by default, the serialised one as the
+    # launch-per-layer graph (equal to rounding only): compare like with like, both ways
     try:
-        seq = run(0)
-        pip = run(1)
+        for pd in (0, 2):
+            engine.set_option('persistent_decoder', pd)
+            seq = run(0)
+            pip = run(1)
+            for a, b in zip(seq, pip):
+                for k in a:
+                    assert np.array_equal(a[k], b[k]), (pd, k)
+        engine.set_option('persistent_decoder', 1)
+        dflt = run(1)
+        for a, b in zip(dflt, pip):
+            for k in a:
+                assert np.array_equal(a[k], b[k]), ('default', k)
     finally:
         engine.set_option('pipeline', 1)
-    for a, b in zip(seq, pip):
-        for k in a:
-            assert np.array_equal(a[k], b[k]), k
+        engine.set_option('persistent_decoder', 1)

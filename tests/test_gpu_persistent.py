@@ -1,0 +1,91 @@
+"""GPU parity of the two single-launch forms: the persistent decoder (decoder_persistent.hip: clusters of
+co-resident workgroups handing activations to each other, reference tacotron/model.py:191-331) and the fused
+Griffin-Lim launch (gl_iter_kernel FUSED: all iterations of audio/synthesis.py:91-112 in one kernel).
+
+Both replace launch boundaries by bounded waits between workgroups; a hand-off that loses a race shows up here as
+a mismatch, a wait that never ends as TTS_ERR_HIP from tts_synchronize."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from oracle import tacotron_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+WIN, HOP, NFFT = 1102, 275, 2048
+
+
+@pytest.fixture()
+def persistent(engine):
+    engine.set_option('persistent_decoder', 2)   # also outside the call pipeline
+    yield engine
+    engine.set_option('persistent_decoder', 1)
+
+
+@pytest.mark.parametrize('B,Ts,S', [(1, 5, 3), (3, 37, 10), (17, 150, 6), (33, 64, 4)])
+def test_persistent_decoder_vs_oracle(persistent, hparams, weights64, B, Ts, S):
+    """Row counts that are no multiple of the 16-row cluster tile, one to three clusters, short and long memories."""
+    rng = np.random.default_rng(200 + B)
+    memory = (rng.standard_normal((B, Ts, 256)) * 1.5).astype(np.float32)
+    ref_mel, ref_al = O.decoder(memory.astype(np.float64), weights64, hparams, n_steps=S)
+    mel, al = persistent.decoder_forward(memory, S)
+    persistent.synchronize()
+    e_mel, e_al = rel_l2(mel.to_host(), ref_mel), float(np.abs(al.to_host() - ref_al).max())
+    print('persistent decoder B={} Ts={} S={}: mel rel-L2 {:.3e}, align max-abs {:.3e}'.format(B, Ts, S, e_mel, e_al))
+    assert e_mel < 1e-3
+    assert e_al < 1e-4
+    assert np.allclose(al.to_host().sum(-1), 1.0, atol=1e-5)
+
+
+def test_persistent_decoder_200_steps_b64(persistent, hparams, weights64):
+    """Config 3 through the persistent kernel: 2000 hand-offs per cluster, same bars as the launch path."""
+    rng = np.random.default_rng(7)
+    memory = (rng.standard_normal((64, 150, 256)) * 0.5).astype(np.float32)
+    dev = persistent.to_device(memory)
+    mel, al = persistent.decoder_forward(dev, 200)
+    persistent.synchronize()
+    mel, al = mel.to_host(), al.to_host()
+    persistent.set_option('persistent_decoder', 0)
+    mel0, al0 = persistent.decoder_forward(dev, 200)
+    mel0, al0 = mel0.to_host(), al0.to_host()
+    # equal to the launch-per-layer path to fp32 rounding (the K slices and the softmax are summed in another order)
+    print('persistent vs launch path: mel rel-L2 {:.3e}, align max-abs {:.3e}'.format(rel_l2(mel, mel0), float(np.abs(al - al0).max())))
+    assert rel_l2(mel, mel0) < 1e-5
+    assert np.abs(al - al0).max() < 1e-5
+    # ... and to the oracle on four of the rows, one from each cluster (the whole batch is test_config3's job)
+    rows = [0, 21, 42, 63]
+    ref_mel, ref_al = O.decoder(memory[rows].astype(np.float64), weights64, hparams)
+    e = rel_l2(mel[rows], ref_mel)
+    print('persistent decoder B=64 S=200 vs oracle rows {}: mel rel-L2 {:.3e}, align max-abs {:.3e}'.format(
+        rows, e, float(np.abs(al[:, rows] - ref_al).max())))
+    assert e < 1e-3
+    assert np.abs(al[:, rows] - ref_al).max() < 1e-4
+
+
+def test_persistent_decoder_reruns_are_bit_identical(persistent):
+    rng = np.random.default_rng(11)
+    memory = persistent.to_device(rng.standard_normal((20, 50, 256)).astype(np.float32))
+    mel, al = persistent.decoder_forward(memory, 12)
+    a, b = mel.to_host(), al.to_host()
+    for _ in range(3):
+        persistent.decoder_forward(memory, 12, mel=mel, alignments=al)
+        assert np.array_equal(a, mel.to_host()) and np.array_equal(b, al.to_host())
+
+
+@pytest.mark.parametrize('B,T,n_iter', [(3, 40, 6), (5, 333, 7), (64, 200, 5)])
+def test_fused_griffin_lim_identical_to_separate_launches(engine, B, T, n_iter):
+    """One run to several runs per workgroup, odd and even iteration counts (the result lands in either buffer)."""
+    rng = np.random.default_rng(B)
+    mag = engine.to_device((rng.random((B, 1025, T), dtype=np.float32) ** 4) * 10)
+    init = engine.to_device(rng.random((B, 1025, T), dtype=np.float32))
+    try:
+        out = []
+        for fused in (0, 1):
+            engine.set_option('gl_fused', fused)
+            wav, _ = engine.griffin_lim(mag, n_iter, WIN, HOP, NFFT, init_phase=init, want_mse=False)
+            engine.synchronize()
+            out.append(wav.to_host())
+    finally:
+        engine.set_option('gl_fused', 0)
+    assert np.isfinite(out[0]).all()
+    assert np.array_equal(out[0], out[1])

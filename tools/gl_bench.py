@@ -21,12 +21,26 @@ def main():
     ap.add_argument('--iters', type=int, default=60)
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--nocheck', action='store_true', help='ablation builds produce garbage')
+    ap.add_argument('--fused', type=int, default=None, help='override the library default (all iterations in one launch)')
+    ap.add_argument('--compare', action='store_true', help='fused against separate launches: waveforms must be identical')
     a = ap.parse_args()
     sstts = importlib.import_module('single-speaker-tts_amd')
     eng = sstts.Engine()
     rng = np.random.default_rng(0)
     mag = eng.to_device((rng.random((a.B, 1025, a.T), dtype=np.float32) ** 4) * 10)
     init = eng.to_device(rng.random((a.B, 1025, a.T), dtype=np.float32))
+    if a.compare:
+        out = []
+        for f in (0, 1):
+            eng.set_option('gl_fused', f)
+            wav, _ = eng.griffin_lim(mag, a.iters, 1102, 275, 2048, init_phase=init, want_mse=False)
+            eng.synchronize()
+            out.append(wav.to_host())
+        d = np.abs(out[0] - out[1]).max()
+        print('fused vs separate launches, %d iterations: max |diff| = %g (%s)' % (a.iters, d, 'identical' if d == 0 else 'DIFFERENT'))
+        return
+    if a.fused is not None:
+        eng.set_option('gl_fused', a.fused)
     eng.griffin_lim(mag, 2, 1102, 275, 2048, init_phase=init, want_mse=False)
     eng.set_option('profile', 1)
     eng.profile_reset()
@@ -36,7 +50,7 @@ def main():
     msf, nf = eng.profile_get('gl_final')
     per = ms / max(1, n)
     alg = 20.0 * 1025 * a.T * a.B
-    print('gl_iter: {:.1f} us/launch over {} launches -> {:.0f} GB/s algorithmic; gl_final {:.1f} us'.format(
+    print('gl_iter: {:.1f} us/iteration over {} iterations -> {:.0f} GB/s algorithmic; gl_final {:.1f} us'.format(
         per * 1e3, n, alg / (per * 1e-3) / 1e9, 1e3 * msf / max(1, nf)))
     if not a.nocheck:
         assert np.isfinite(wav.to_host()).all()
