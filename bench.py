@@ -144,6 +144,8 @@ def main():
     ap.add_argument('--pipeline', type=int, default=None, help='override the library default (stream pipelining)')
     ap.add_argument('--reserve-cus', type=int, default=None)
     ap.add_argument('--hold-lds-kb', type=int, default=None)
+    ap.add_argument('--persistent-decoder', type=int, default=None, help='override the library default (0 never, 1 pipelined, 2 always)')
+    ap.add_argument('--gl-fused', type=int, default=None, help='override the library default (all Griffin-Lim iterations in one launch)')
     ap.add_argument('--dist-selftest', action='store_true', help='rehearse the N > 1 launch path without GPU work')
     args = ap.parse_args()
 
@@ -201,6 +203,10 @@ def main():
         eng.set_option('reserve_cus', args.reserve_cus)
     if args.hold_lds_kb is not None:
         eng.set_option('hold_lds_kb', args.hold_lds_kb)
+    if args.persistent_decoder is not None:
+        eng.set_option('persistent_decoder', args.persistent_decoder)
+    if args.gl_fused is not None:
+        eng.set_option('gl_fused', args.gl_fused)
 
     # ---- this rank's shard of the synthetic batch, resident in HBM
     lo, hi = shard.shard_range(world * B_PER_GPU, world, rank)

@@ -1444,7 +1444,7 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
         const int clusters = (B + 15) / 16;
         WS(h, "dec.pd_sync", unsigned, (size_t)64 * clusters + 2, pd_sync);
         HIPCHK(h, decoder_persistent_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, alignments, pd_sync,
-                                             h->cur_hold_flag));
+                                             h->cur_hold_flag, c.force_cudnn));
         h->pd_sync = pd_sync;
         h->pd_clusters = clusters;
         h->pd_used = true;
@@ -1727,7 +1727,14 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         if (h->post_pending[parity]) HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_post_done[parity], 0));
         if (mel_out && h->post_pending[parity ^ 1])
             HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_post_done[parity ^ 1], 0));
-        if (h->reserve_cus > 0) {
+        // The persistent decoder keeps its compute units by being resident (Griffin-Lim is planned and launched for
+        // the other n_cus - reserve_cus), and the encoder in front of it may queue behind Griffin-Lim workgroups
+        // without costing the step anything: no sleepers then.  The launch-per-layer decoder (configurations the
+        // persistent kernel does not cover) still needs the reservation for its ~2000 dependent launches.
+        const bool pd_path = h->persistent_decoder && h->reserve_cus > 0 &&
+                             decoder_persistent_supports(h->dec, c.force_cudnn, B, Ts) &&
+                             decoder_persistent_workgroups(B) <= h->reserve_cus;
+        if (h->reserve_cus > 0 && !pd_path) {
             // reserve CUs for the front stream while the previous call's Griffin-Lim fills the rest
             hold_flag = h->hold_flags + (h->call_count++ & 1);
             // the persistent decoder releases its call's sleepers as soon as it is resident: the next set must not
@@ -1742,7 +1749,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     }
     rc = tts_encoder_forward(h, ids, B, Ts, memory);
     h->cur_hold_flag = hold_flag;
-    h->cur_cu_budget = hold_flag ? h->reserve_cus : 0;
+    h->cur_cu_budget = (pipelined && h->reserve_cus > 0) ? h->reserve_cus : 0;
     if (!rc) rc = tts_decoder_forward(h, memory, B, Ts, sp->n_steps, mel, align_out);
     h->cur_hold_flag = nullptr;
     h->cur_cu_budget = 0;

@@ -74,7 +74,7 @@ hipError_t decoder_enqueue(hipStream_t s, const DecoderWeights& w, const Decoder
                            const float* memory, const float* keys, int B, int Ts, int n_steps,
                            float* align, int cudnn);
 
-// ---- persistent form (decoder_persistent.hip): one launch for the whole loop, GRUCell form + global attention only
+// ---- persistent form (decoder_persistent.hip): one launch for the whole loop; both GRU formulations, global attention
 struct PdParams {
     const float *w1, *b1, *w1f, *b1f, *w2, *b2;   // pre-net (step 0 / folded / layer 2)
     const float *ag_w, *ag_b, *ac_w, *ac_b;       // attention GRU gates / candidate
@@ -88,6 +88,7 @@ struct PdParams {
     int* status;                                  // set to 1 when a wait timed out (results are then invalid)
     int* hold_flag;                               // optional: raised once every workgroup is resident (reserve.hip sleepers)
     int B, Ts, n_steps, n_mels;
+    int cudnn;                                    // CudnnCompatibleGRUCell arithmetic (gates_wt holds [r | u | hh | xi])
 };
 bool decoder_persistent_supports(const DecoderWeights& w, int cudnn, int B, int Ts);
 int decoder_persistent_workgroups(int B);         // compute units the launch needs all to itself
@@ -95,6 +96,6 @@ hipError_t decoder_persistent_configure();        // per device
 // `sync`: 64 * ceil(B / 16) + 2 unsigned words
 hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, const DecoderScratch& sc, const float* memory,
                                       const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync,
-                                      int* hold_flag);
+                                      int* hold_flag, int cudnn);
 
 }  // namespace tts

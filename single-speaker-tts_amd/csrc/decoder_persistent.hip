@@ -47,7 +47,11 @@ __device__ __forceinline__ void pd_st4(const __amdgpu_buffer_rsrc_t& rs, unsigne
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pd_u32x4, v), rs, (int)byte_off, 0, 16);
 }
 
-enum PdEpi { PD_ACT = 0, PD_GATES = 1, PD_CAND = 2 };
+// PD_GATES + PD_CAND: TF GRUCell (candidate on [x ; r*h], two hops per cell).  PD_CUDNN_RU + PD_CUDNN_HX:
+// CudnnCompatibleGRUCell (reference layers.py:560-577, model.py:226-227,257-259): c = tanh(x Wci + bci + r*(h Wch + bch));
+// all four column blocks [r | u | hh | xi] come from the same staged [x ; h] tile, r and u never leave the
+// workgroup, so the cell is ONE hop: the second pass continues on the tile of the first (`cont`).
+enum PdEpi { PD_ACT = 0, PD_GATES = 1, PD_CAND = 2, PD_CUDNN_RU = 3, PD_CUDNN_HX = 4 };
 
 #ifdef PD_TIMELINE   // tools only: s_memrealtime stamps (100 MHz) of workgroup 0 in step 100, [phase][8]
 __device__ unsigned long long* pd_dbg = nullptr;
@@ -65,6 +69,9 @@ struct PdPhase {
     int K;
     const float* Wt;                     // [N][K]
     const float* bias;                   // [N] or null
+    int row0;                            // first of the (one or two) 256-row weight blocks this phase uses
+    int cont;                            // continues on the A tile the previous phase staged: no wait, no staging
+    int more;                            // a `cont` phase follows: nothing to publish yet
     int ub;                              // units of this layer owned per workgroup (32 or 16)
     int epi, act, layer;
     float* out; int ldo;                 // PD_ACT: activations; PD_GATES: r*h; PD_CAND: new state h
@@ -76,7 +83,8 @@ struct PdPhase {
 #define PD_OFF_RED (16 * PD_LDA)
 #define PD_OFF_H (PD_OFF_RED + PD_NW * 16 * PD_RED_LD)
 #define PD_OFF_U (PD_OFF_H + 3 * 16 * 32)
-#define PD_OFF_CTRL (PD_OFF_U + 16 * 32)
+#define PD_OFF_R (PD_OFF_U + 16 * 32)
+#define PD_OFF_CTRL (PD_OFF_R + 16 * 32)
 #define PD_OFF_SC (PD_OFF_CTRL + 16)
 size_t pd_lds_bytes(int Ts) { return ((size_t)PD_OFF_SC + 2 * (size_t)((Ts + 3) & ~3)) * sizeof(float); }
 
@@ -119,9 +127,10 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, int j, i
     float* red = lds + PD_OFF_RED;
     float* h_loc = lds + PD_OFF_H + ph.layer * (16 * 32);
     float* u_loc = lds + PD_OFF_U;
+    float* r_loc = lds + PD_OFF_R;
     int* ctrl = reinterpret_cast<int*>(lds + PD_OFF_CTRL);
 
-    const int gates = ph.epi == PD_GATES ? 2 : 1;
+    const int gates = (ph.epi == PD_GATES || ph.epi == PD_CUDNN_RU || ph.epi == PD_CUDNN_HX) ? 2 : 1;
     const int tpg = ph.ub >> 4;                 // 16-column tiles per gate
     const int tiles = gates * tpg;              // 1, 2 or 4
     const int ksl = PD_NW / tiles;              // K slices
@@ -130,7 +139,7 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, int j, i
     const int nch = ph.K >> 4;
 
     // ---- this wave's weight fragments: independent of every other workgroup, so they are in flight during the wait
-    const int n = gate * PD_D + j * ph.ub + 16 * within + r;
+    const int n = ph.row0 + gate * PD_D + j * ph.ub + 16 * within + r;
     const float* wrow = ph.Wt + (size_t)n * ph.K + 4 * q;
     float4 bv[8];
 #pragma unroll
@@ -140,11 +149,11 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, int j, i
     }
 
     PD_STAMP(0)
-    pd_wait(cnt, target, status, ctrl);
+    if (!ph.cont) pd_wait(cnt, target, status, ctrl);
     PD_STAMP(1)
 
     // ---- stage the cluster's A tile (16 rows x K) in LDS: sc1 loads of the handed-off activations
-    {
+    if (!ph.cont) {
         const int k4 = ph.K >> 2;                 // float4 per row
         const __amdgpu_buffer_rsrc_t r0 = pd_rsrc(ph.a0 ? ph.a0 : ph.a1), r1 = pd_rsrc(ph.a1);
         for (int i = tid; i < 16 * k4; i += PD_THREADS) {
@@ -158,8 +167,8 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, int j, i
             }
             *reinterpret_cast<float4*>(As + row * PD_LDA + kk) = v;
         }
+        __syncthreads();
     }
-    __syncthreads();
     PD_STAMP(2)
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -180,44 +189,63 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, int j, i
     __syncthreads();
     PD_STAMP(3)
 
-    // ---- epilogue: thread e owns (tile, row, 4 consecutive columns); K slices added in a fixed order
-    if (tid < tiles * 64) {
-        const int et = tid >> 6, row = (tid >> 2) & 15, c4 = (tid & 3) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = 0; s < ksl; ++s) {
-            const float4 t4 = *reinterpret_cast<const float4*>(red + ((et + tiles * s) * 16 + row) * PD_RED_LD + c4);
-            v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
-        }
-        const int eg = et / tpg, ew = et - eg * tpg;
+    // ---- epilogue: thread e owns (row, 4 consecutive units) of every gate; K slices added in a fixed order
+    if (tid < tpg * 64) {
+        const int ew = tid >> 6, row = (tid >> 2) & 15, c4 = (tid & 3) * 4;
         const int cl = 16 * ew + c4;             // column inside this workgroup's unit block
         const int unit = j * ph.ub + cl;
-        if (ph.bias) {
-            const float4 b4 = *reinterpret_cast<const float4*>(ph.bias + eg * PD_D + unit);
-            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        float4 v[2];
+#pragma unroll
+        for (int eg = 0; eg < 2; ++eg) {
+            v[eg] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (eg < gates) {
+                const int et = eg * tpg + ew;
+                for (int s = 0; s < ksl; ++s) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(red + ((et + tiles * s) * 16 + row) * PD_RED_LD + c4);
+                    v[eg].x += t4.x; v[eg].y += t4.y; v[eg].z += t4.z; v[eg].w += t4.w;
+                }
+                if (ph.bias) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(ph.bias + ph.row0 + eg * PD_D + unit);
+                    v[eg].x += b4.x; v[eg].y += b4.y; v[eg].z += b4.z; v[eg].w += b4.w;
+                }
+            }
         }
         const bool row_ok = b0 + row < B;
         const int b = b0 + row;
+        float* hl = h_loc + row * 32 + cl;
+        float* ul = u_loc + row * 32 + cl;
+        float* rl = r_loc + row * 32 + cl;
         if (ph.epi == PD_ACT) {
-            v.x = apply_act(v.x, ph.act); v.y = apply_act(v.y, ph.act); v.z = apply_act(v.z, ph.act); v.w = apply_act(v.w, ph.act);
-            if (row_ok) pd_st4(pd_rsrc(ph.out), (unsigned)(b * ph.ldo + unit) * 4u, v);
-        } else if (ph.epi == PD_GATES) {
-            v.x = sigmoidf_(v.x); v.y = sigmoidf_(v.y); v.z = sigmoidf_(v.z); v.w = sigmoidf_(v.w);
-            if (eg == 0) {   // r: hand r*h to the candidate's K operand
-                const float4 h4 = *reinterpret_cast<const float4*>(h_loc + row * 32 + cl);
-                v.x *= h4.x; v.y *= h4.y; v.z *= h4.z; v.w *= h4.w;
-                if (row_ok) pd_st4(pd_rsrc(ph.out), (unsigned)(b * ph.ldo + unit) * 4u, v);
-            } else {         // u: stays in this workgroup
-                *reinterpret_cast<float4*>(u_loc + row * 32 + cl) = v;
+            float4 o = v[0];
+            o.x = apply_act(o.x, ph.act); o.y = apply_act(o.y, ph.act); o.z = apply_act(o.z, ph.act); o.w = apply_act(o.w, ph.act);
+            if (row_ok) pd_st4(pd_rsrc(ph.out), (unsigned)(b * ph.ldo + unit) * 4u, o);
+        } else if (ph.epi == PD_GATES || ph.epi == PD_CUDNN_RU) {
+            float4 rr4, uu4;
+            rr4.x = sigmoidf_(v[0].x); rr4.y = sigmoidf_(v[0].y); rr4.z = sigmoidf_(v[0].z); rr4.w = sigmoidf_(v[0].w);
+            uu4.x = sigmoidf_(v[1].x); uu4.y = sigmoidf_(v[1].y); uu4.z = sigmoidf_(v[1].z); uu4.w = sigmoidf_(v[1].w);
+            *reinterpret_cast<float4*>(ul) = uu4;             // u stays in this workgroup
+            if (ph.epi == PD_GATES) {                          // r*h is the candidate's K operand: hand it over
+                const float4 h4 = *reinterpret_cast<const float4*>(hl);
+                rr4.x *= h4.x; rr4.y *= h4.y; rr4.z *= h4.z; rr4.w *= h4.w;
+                if (row_ok) pd_st4(pd_rsrc(ph.out), (unsigned)(b * ph.ldo + unit) * 4u, rr4);
+            } else {
+                *reinterpret_cast<float4*>(rl) = rr4;
             }
-        } else {   // PD_CAND: h' = u h + (1 - u) tanh(.)
-            const float4 h4 = *reinterpret_cast<const float4*>(h_loc + row * 32 + cl);
-            const float4 u4 = *reinterpret_cast<const float4*>(u_loc + row * 32 + cl);
+        } else {   // PD_CAND / PD_CUDNN_HX: h' = u h + (1 - u) tanh(.)
+            const float4 h4 = *reinterpret_cast<const float4*>(hl);
+            const float4 u4 = *reinterpret_cast<const float4*>(ul);
+            float4 cin = v[0];
+            if (ph.epi == PD_CUDNN_HX) {   // v[0] = h Wch + bch, v[1] = x Wci + bci
+                const float4 r4 = *reinterpret_cast<const float4*>(rl);
+                cin.x = v[1].x + r4.x * v[0].x; cin.y = v[1].y + r4.y * v[0].y;
+                cin.z = v[1].z + r4.z * v[0].z; cin.w = v[1].w + r4.w * v[0].w;
+            }
             float4 hn;
-            hn.x = u4.x * h4.x + (1.0f - u4.x) * tanhf_(v.x);
-            hn.y = u4.y * h4.y + (1.0f - u4.y) * tanhf_(v.y);
-            hn.z = u4.z * h4.z + (1.0f - u4.z) * tanhf_(v.z);
-            hn.w = u4.w * h4.w + (1.0f - u4.w) * tanhf_(v.w);
-            *reinterpret_cast<float4*>(h_loc + row * 32 + cl) = hn;
+            hn.x = u4.x * h4.x + (1.0f - u4.x) * tanhf_(cin.x);
+            hn.y = u4.y * h4.y + (1.0f - u4.y) * tanhf_(cin.y);
+            hn.z = u4.z * h4.z + (1.0f - u4.z) * tanhf_(cin.z);
+            hn.w = u4.w * h4.w + (1.0f - u4.w) * tanhf_(cin.w);
+            *reinterpret_cast<float4*>(hl) = hn;
             if (row_ok) pd_st4(pd_rsrc(ph.out), (unsigned)(b * ph.ldo + unit) * 4u, hn);
             if (ph.yout) {   // ResidualWrapper: y = x + h'; x is the first K segment of the staged tile
                 const float4 x4 = *reinterpret_cast<const float4*>(As + row * PD_LDA + unit);
@@ -227,7 +255,8 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, int j, i
         }
     }
     PD_STAMP(4)
-    pd_publish();
+    if (ph.more) __syncthreads();   // r / u are in LDS, the partial tiles may be overwritten
+    else pd_publish();
     PD_STAMP(5)
 }
 
@@ -351,7 +380,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
     const int b0 = cluster * 16;
     unsigned* cnt = p.counters + 64 * cluster;
     int* ctrl = reinterpret_cast<int*>(lds + PD_OFF_CTRL);
-    for (int i = tid; i < 3 * 16 * 32 + 16 * 32; i += PD_THREADS) lds[PD_OFF_H + i] = 0.f;   // zero_state
+    for (int i = tid; i < 3 * 16 * 32 + 2 * 16 * 32; i += PD_THREADS) lds[PD_OFF_H + i] = 0.f;   // zero_state
     if (tid == 0) {
         ctrl[0] = 0;
         // all workgroups resident: the CUs the call pipeline held for this stream are no longer needed
@@ -365,18 +394,19 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
     for (int t = 0; t < p.n_steps; ++t) {
         // ONE instance of the phase body in a loop over the step's ten phases (ten inlined copies spill)
 #pragma nounroll
-        for (int k = 0; k < 10; ++k, ++g) {
+        for (int k = 0; k < 10; ++k) {
 #ifdef PD_TIMELINE
             if (blockIdx.x == 0 && threadIdx.x == 0) { pd_dbg_step = t; pd_dbg_phase = k; }
 #endif
             if (k == 4) {
                 pd_attention(p.h_att, p.keys, p.memory, p.ctx, p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr, p.Ts, lds, j,
                              b0, p.B, cnt, PD_W * g, p.status);
+                ++g;
                 continue;
             }
             PdPhase ph;
             ph.lda0 = PD_D; ph.k0 = PD_D; ph.lda1 = PD_D; ph.K = 2 * PD_D; ph.ub = 32; ph.act = ACT_NONE; ph.layer = 0;
-            ph.ldo = PD_D; ph.yout = nullptr; ph.ldy = PD_D; ph.bias = nullptr;
+            ph.ldo = PD_D; ph.yout = nullptr; ph.ldy = PD_D; ph.bias = nullptr; ph.row0 = 0; ph.cont = 0; ph.more = 0;
             switch (k) {
                 case 0:
                     // PrenetWrapper on concat([x_t, attention_{t-1}]) (wrappers.py:122-124); x_0 = GO frame = zeros
@@ -392,31 +422,42 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
                     break;
                 case 2:   // attention GRU (model.py:226-229): gates on [p2 ; h_att]
                     ph.a0 = p.p2; ph.lda0 = PD_P2; ph.k0 = PD_P2; ph.a1 = p.h_att; ph.K = PD_P2 + PD_D;
-                    ph.Wt = p.ag_w; ph.bias = p.ag_b; ph.epi = PD_GATES; ph.out = p.rh;
+                    ph.Wt = p.ag_w; ph.bias = p.ag_b; ph.epi = p.cudnn ? PD_CUDNN_RU : PD_GATES; ph.out = p.rh; ph.more = p.cudnn;
                     break;
-                case 3:   // ... candidate on [p2 ; r*h_att]; the new state is the attention query
+                case 3:   // ... candidate (GRUCell: on [p2 ; r*h_att], after a hop); the new state is the attention query
                     ph.a0 = p.p2; ph.lda0 = PD_P2; ph.k0 = PD_P2; ph.a1 = p.rh; ph.K = PD_P2 + PD_D;
-                    ph.Wt = p.ac_w; ph.bias = p.ac_b; ph.epi = PD_CAND; ph.out = p.h_att;
+                    ph.Wt = p.cudnn ? p.ag_w : p.ac_w; ph.bias = p.cudnn ? p.ag_b : p.ac_b; ph.out = p.h_att;
+                    ph.epi = p.cudnn ? PD_CUDNN_HX : PD_CAND; ph.row0 = p.cudnn ? 2 * PD_D : 0; ph.cont = p.cudnn;
                     break;
                 case 5:   // attention_layer(concat([cell_output, context])), no bias
                     ph.a0 = p.h_att; ph.a1 = p.ctx; ph.Wt = p.al_w; ph.epi = PD_ACT; ph.out = p.att;
                     break;
-                default: {   // 6..9: two ResidualWrapper(GRUCell) layers (model.py:254-269); the top one writes the y history
+                default: {   // 6..9: two ResidualWrapper(GRU cell) layers (model.py:254-269); the top one writes the y history
                     const int l = (k - 6) >> 1;
-                    const bool cand = (k - 6) & 1;
-                    ph.a0 = l == 0 ? p.att : p.y0; ph.a1 = cand ? p.rh : p.h_dec[l];
-                    ph.Wt = cand ? p.g_cw[l] : p.g_gw[l]; ph.bias = cand ? p.g_cb[l] : p.g_gb[l];
-                    ph.epi = cand ? PD_CAND : PD_GATES; ph.layer = 1 + l; ph.out = cand ? p.h_dec[l] : p.rh;
-                    if (cand) { ph.yout = l == 0 ? p.y0 : p.yhist + (size_t)t * PD_D; ph.ldy = l == 0 ? PD_D : yld; }
+                    const bool second = (k - 6) & 1;
+                    ph.a0 = l == 0 ? p.att : p.y0; ph.a1 = (second && !p.cudnn) ? p.rh : p.h_dec[l];
+                    ph.layer = 1 + l;
+                    if (p.cudnn) {
+                        ph.Wt = p.g_gw[l]; ph.bias = p.g_gb[l];
+                        ph.epi = second ? PD_CUDNN_HX : PD_CUDNN_RU; ph.row0 = second ? 2 * PD_D : 0;
+                        ph.cont = second; ph.more = !second;
+                    } else {
+                        ph.Wt = second ? p.g_cw[l] : p.g_gw[l]; ph.bias = second ? p.g_cb[l] : p.g_gb[l];
+                        ph.epi = second ? PD_CAND : PD_GATES;
+                    }
+                    ph.out = second ? p.h_dec[l] : p.rh;
+                    if (second) { ph.yout = l == 0 ? p.y0 : p.yhist + (size_t)t * PD_D; ph.ldy = l == 0 ? PD_D : yld; }
                 } break;
             }
             pd_phase(ph, lds, j, b0, p.B, cnt, PD_W * g, p.status);
+            if (!ph.more) ++g;
         }
     }
 }
 
 bool decoder_persistent_supports(const DecoderWeights& w, int cudnn, int B, int Ts) {
-    return !cudnn && w.local_d == 0 && w.n_layers == 2 && w.att_units == PD_D && w.dec_units == PD_D && w.mem_units == PD_D &&
+    (void)cudnn;   // both GRU formulations
+    return w.local_d == 0 && w.n_layers == 2 && w.att_units == PD_D && w.dec_units == PD_D && w.mem_units == PD_D &&
            w.prenet1_units == PD_D && w.prenet2_units == PD_P2 && w.n_mels % 16 == 0 && w.n_mels <= PD_D && B >= 1 && Ts >= 1 &&
            pd_lds_bytes(Ts) <= 160 * 1024 && (size_t)B * Ts * PD_D * 4 < 0xFFFFFFF0ull;
 }
@@ -431,7 +472,7 @@ hipError_t decoder_persistent_configure() {
 // Capturable: two memsets and one launch.  `sync` = 64 unsigned per cluster + 1 (resident count) + 1 (status word).
 hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, const DecoderScratch& sc, const float* memory,
                                       const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync,
-                                      int* hold_flag) {
+                                      int* hold_flag, int cudnn) {
     const int clusters = (B + 15) / 16;
     hipError_t e;
     if ((e = hipMemsetAsync(sc.state, 0, sc.state_bytes, s)) != hipSuccess) return e;
@@ -449,7 +490,7 @@ hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, co
     p.yhist = sc.yhist; p.align = align;
     p.counters = sync; p.resident = sync + 64 * clusters; p.status = reinterpret_cast<int*>(sync + 64 * clusters + 1);
     p.hold_flag = hold_flag;
-    p.B = B; p.Ts = Ts; p.n_steps = n_steps; p.n_mels = w.n_mels;
+    p.B = B; p.Ts = Ts; p.n_steps = n_steps; p.n_mels = w.n_mels; p.cudnn = cudnn;
 #ifdef PD_TIMELINE
     {
         static unsigned long long* dbg = nullptr;

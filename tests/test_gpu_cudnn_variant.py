@@ -56,3 +56,29 @@ def test_cudnn_differs_from_grucell(cudnn_setup, engine, hparams):
     a = eng.postnet_forward(mel).to_host()
     ref = O.post_process(mel.astype(np.float64), O.cast_weights(w, np.float64), hp)
     assert rel_l2(a, ref) < 1e-3
+
+
+@pytest.mark.parametrize('B,Ts,S', [(2, 9, 4), (19, 60, 12)])
+def test_cudnn_persistent_decoder(cudnn_setup, B, Ts, S):
+    """CudnnCompatibleGRUCell through the persistent kernel: r, u, h W_ch and x W_ci from ONE staged [x ; h] tile, one
+    hand-off per cell.  Against the oracle and against the launch-per-layer path."""
+    hp, w, eng = cudnn_setup
+    rng = np.random.default_rng(40 + B)
+    memory = (rng.standard_normal((B, Ts, 256)) * 1.5).astype(np.float32)
+    ref_mel, ref_al = O.decoder(memory.astype(np.float64), O.cast_weights(w, np.float64), hp, n_steps=S)
+    dev = eng.to_device(memory)
+    try:
+        eng.set_option('persistent_decoder', 2)
+        mel, al = eng.decoder_forward(dev, S)
+        eng.synchronize()
+        mel, al = mel.to_host(), al.to_host()
+        eng.set_option('persistent_decoder', 0)
+        mel0, al0 = eng.decoder_forward(dev, S)
+        mel0, al0 = mel0.to_host(), al0.to_host()
+    finally:
+        eng.set_option('persistent_decoder', 1)
+    e_mel, e_al = rel_l2(mel, ref_mel), float(np.abs(al - ref_al).max())
+    print('cudnn persistent decoder B={} Ts={} S={}: mel rel-L2 {:.3e}, align max-abs {:.3e}; vs launch path {:.3e}'.format(
+        B, Ts, S, e_mel, e_al, rel_l2(mel, mel0)))
+    assert e_mel < 1e-3 and e_al < 1e-4
+    assert rel_l2(mel, mel0) < 1e-5 and np.abs(al - al0).max() < 1e-4

@@ -10,8 +10,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BM 128
 #define BN 128
-#define BK 32
-#define LDS_LD (BK + 4)
+
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -25,7 +24,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     const int m0 = m_blk * BM;
     const int n0 = (seq % nyb) * BN;
     if (n0 >= N || m0 >= M) return;
-    constexpr int NBUF = V == 0 ? 1 : 2;
+    constexpr int BK = V == 2 ? 64 : 32;
+    constexpr int LDS_LD = BK + 4;
+    constexpr int NBUF = V == 1 ? 2 : 1;
+    constexpr int NLD = BK / 8;      // float4 per thread and operand per tile (4 rows x BK/32 column groups)
     __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -34,26 +36,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     const int kq = tid & 7;
     const float* a_row[4];
     const float* b_row[4];
+    float4 ra[NLD], rb[NLD];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (tid >> 3) + 32 * i;
         a_row[i] = A + (size_t)min(m0 + row, M - 1) * K;
         b_row[i] = Wt + (size_t)min(n0 + row, N - 1) * K;
     }
-    float4 ra[4], rb[4];
     auto load_tile = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = ld4(a_row[i] + kt + 4 * kq);
-            rb[i] = ld4(b_row[i] + kt + 4 * kq);
+        for (int i = 0; i < NLD; ++i) {
+            ra[i] = ld4(a_row[i & 3] + kt + 4 * kq + 32 * (i >> 2));
+            rb[i] = ld4(b_row[i & 3] + kt + 4 * kq + 32 * (i >> 2));
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (tid >> 3) + 32 * i;
-            *reinterpret_cast<float4*>(&As[buf][row * LDS_LD + 4 * kq]) = ra[i];
-            *reinterpret_cast<float4*>(&Bs[buf][row * LDS_LD + 4 * kq]) = rb[i];
+        for (int i = 0; i < NLD; ++i) {
+            const int row = (tid >> 3) + 32 * (i & 3);
+            *reinterpret_cast<float4*>(&As[buf][row * LDS_LD + 4 * kq + 32 * (i >> 2)]) = ra[i];
+            *reinterpret_cast<float4*>(&Bs[buf][row * LDS_LD + 4 * kq + 32 * (i >> 2)]) = rb[i];
         }
     };
     f32x16 acc[2][2];
@@ -80,14 +82,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
             }
     };
-    if (V == 0) {
+    if (V >= 4) {   // ablations (wrong results): 4 = no global loads in the loop, 5 = also no LDS stores, 6 = also no barriers
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < K; kt += BK) {
+            if (V == 4) store_tile(0);
+            if (V <= 5) __syncthreads();
+#pragma unroll
+            for (int q = 0; q < BK / 8; ++q) compute(0, q);
+            if (V <= 5) __syncthreads();
+        }
+    } else if (V != 1) {
         load_tile(0);
         for (int kt = 0; kt < K; kt += BK) {
             store_tile(0);
             __syncthreads();
             if (kt + BK < K) load_tile(kt + BK);
+            if (V == 3) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) compute(0, q);
+            for (int q = 0; q < BK / 8; ++q) compute(0, q);
+            if (V == 3) __builtin_amdgcn_s_setprio(0);
             __syncthreads();
         }
     } else {
@@ -147,7 +162,7 @@ double run(const float* A, const float* Wt, float* C, int M, int N, int K, std::
 
 int main() {
     const int shapes[][3] = {{8192, 8192, 1024}, {64000, 256, 3072}, {64000, 1024, 256}};
-    for (int coarse = 0; coarse < 2; ++coarse)
+    for (int coarse = 0; coarse < 1; ++coarse)
     for (auto& s : shapes) {
         printf("%s operands\n", coarse ? "16-bit" : "full-mantissa");
         const int M = s[0], N = s[1], K = s[2];
@@ -164,6 +179,9 @@ int main() {
         std::vector<float> c0, c1;
         run<0>(A, Wt, C, M, N, K, &c0);
         run<1>(A, Wt, C, M, N, K, &c1);
+        run<4>(A, Wt, C, M, N, K, &c1);
+        run<5>(A, Wt, C, M, N, K, &c1);
+        run<6>(A, Wt, C, M, N, K, &c1);
         double md = 0;
         for (size_t i = 0; i < c0.size(); i += 97) md = fmax(md, fabs((double)c0[i] - c1[i]));
         printf("   max |V0 - V1| = %g\n", md);
