@@ -74,7 +74,7 @@ hipError_t decoder_enqueue(hipStream_t s, const DecoderWeights& w, const Decoder
                            const float* memory, const float* keys, int B, int Ts, int n_steps,
                            float* align, int cudnn);
 
-// ---- persistent form (decoder_persistent.hip): one launch for the whole loop; both GRU formulations, global attention
+// ---- persistent form (decoder_persistent.hip): one launch for the whole loop; both GRU formulations, global and local attention
 struct PdParams {
     const float *w1, *b1, *w1f, *b1f, *w2, *b2;   // pre-net (step 0 / folded / layer 2)
     const float *ag_w, *ag_b, *ac_w, *ac_b;       // attention GRU gates / candidate
@@ -89,6 +89,10 @@ struct PdParams {
     int* hold_flag;                               // optional: raised once every workgroup is resident (reserve.hip sleepers)
     int B, Ts, n_steps, n_mels;
     int cudnn;                                    // CudnnCompatibleGRUCell arithmetic (gates_wt holds [r | u | hh | xi])
+    int local_d, local_gaussian, local_predictive;   // LocalLuongAttention (0 = global attention)
+    const float *local_wp, *local_vp;
+    float* p_hist;                                // [n_steps][B] predicted centres (predictive mode)
+    int* err_flag;                                // raised when a predicted window leaves the memory
 };
 bool decoder_persistent_supports(const DecoderWeights& w, int cudnn, int B, int Ts);
 int decoder_persistent_workgroups(int B);         // compute units the launch needs all to itself

@@ -262,9 +262,20 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, int j, i
 
 // Luong dot attention for rows 2j and 2j+1 of the cluster (TF-1.8 _luong_score / _compute_attention; dot form at
 // reference attention.py:396-400): softmax over ALL Ts positions, context = alignments . memory.
-__device__ __forceinline__ void pd_attention(const float* __restrict__ query, const float* __restrict__ keys,
+// LocalLuongAttention (reference attention.py:32-342; decoder.hip has the launch-per-layer form): only the window
+// of 2D+1 positions around the step index (monotonic) or around the predicted centre p = Ts sigmoid(v_p . tanh(W_p h))
+// is scored; the reported alignments are zero outside it and, with `gaussian`, weighted as the reference writes it.
+struct PdLocal {
+    int d, gaussian, predictive, step;
+    const float* wp; const float* vp;   // [256][256] (q @ W_p), [256]
+    float* p_hist_t;                    // [B] predicted centres of this step
+    int* err_flag;
+};
+template <bool LOCAL>   // the global form stays inline (one instance in the step loop); the windowed one is a call
+__device__ __forceinline__ void pd_attention_body(const float* __restrict__ query, const float* __restrict__ keys,
                                              const float* __restrict__ values, float* ctx, float* align_t, int Ts, float* lds,
-                                             int j, int b0, int B, unsigned* cnt, unsigned target, int* status) {
+                                             int j, int b0, int B, unsigned* cnt, unsigned target, int* status,
+                                             const PdLocal lc) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = wave >> 3, hw = wave & 7, t512 = tid & 511;
     float* qs = lds + PD_OFF_AS + half * PD_D;                        // [2][256]
@@ -285,13 +296,54 @@ __device__ __forceinline__ void pd_attention(const float* __restrict__ query, co
     if (t512 < 64) *reinterpret_cast<float4*>(qs + 4 * t512) = pd_ld4(pd_rsrc(query), (unsigned)(rr * PD_D + 4 * t512) * 4u);
     __syncthreads();
 
+    // scored positions [w_lo, w_lo + w_n): the whole memory, or the local window
+    int w_lo = 0, w_n = Ts;
+    float pc = 0.f;   // window centre as the gaussian sees it
+    if (LOCAL && lc.d > 0) {
+        w_n = 2 * lc.d + 1;
+        if (lc.predictive) {
+            // (q W_p)[n]: thread (n, half of k); then v_p . tanh(.) over the row's 512 threads
+            const int n = t512 & 255, kh = t512 >> 8;
+            float a0 = 0.f, a1 = 0.f;
+            const float* wpn = lc.wp + (size_t)(128 * kh) * PD_D + n;
+            for (int k = 0; k < 128; k += 2) {
+                a0 = fmaf(qs[128 * kh + k], wpn[(size_t)k * PD_D], a0);
+                a1 = fmaf(qs[128 * kh + k + 1], wpn[(size_t)(k + 1) * PD_D], a1);
+            }
+            part[kh * PD_D + n] = a0 + a1;
+            __syncthreads();
+            float v = 0.f;
+            if (t512 < 256) v = tanhf_(part[t512] + part[PD_D + t512]) * lc.vp[t512];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) redm[hw] = v;   // waves 4..7 of the row hold zeros
+            __syncthreads();
+            const float p = (float)Ts * sigmoidf_((redm[0] + redm[1]) + (redm[2] + redm[3]));
+            const int c = (int)floorf(p);
+            // a window that leaves the memory: the reference's padding arithmetic fails there (decoder.hip)
+            if (t512 == 0 && row_ok) {
+                lc.p_hist_t[row] = p;
+                if (c - lc.d < 0 || c + lc.d + 1 > Ts) *lc.err_flag = 1;
+            }
+            w_lo = min(max(c - lc.d, 0), Ts - w_n);
+            pc = p;
+            __syncthreads();   // part / redm are reused below
+        } else {
+            int c = lc.step > lc.d ? lc.step : lc.d;
+            const int hi = Ts - (lc.d + 1);
+            c = c < hi ? c : hi;
+            w_lo = c - lc.d;
+            pc = (float)c;
+        }
+    }
+
     // scores: 16 lanes per key, 32 keys per pass of the row's 8 waves
     const int sub = lane >> 4, l16 = lane & 15;
-    const float* kb = keys + (size_t)rr * Ts * PD_D;
-    for (int j0 = 0; j0 < Ts; j0 += 32) {
+    const float* kb = keys + ((size_t)rr * Ts + w_lo) * PD_D;
+    for (int j0 = 0; j0 < w_n; j0 += 32) {
         const int jj = j0 + hw * 4 + sub;
         float s = 0.f;
-        if (jj < Ts) {
+        if (jj < w_n) {
             const float* kr = kb + (size_t)jj * PD_D;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -308,13 +360,13 @@ __device__ __forceinline__ void pd_attention(const float* __restrict__ query, co
         s += __shfl_xor(s, 4);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 1);
-        if (jj < Ts && l16 == 0) sc[jj] = s;
+        if (jj < w_n && l16 == 0) sc[jj] = s;
     }
     __syncthreads();
 
     PD_STAMP(2)
     float m = -INFINITY;
-    for (int jj = t512; jj < Ts; jj += 512) m = fmaxf(m, sc[jj]);
+    for (int jj = t512; jj < w_n; jj += 512) m = fmaxf(m, sc[jj]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if (lane == 0) redm[hw] = m;
@@ -323,7 +375,7 @@ __device__ __forceinline__ void pd_attention(const float* __restrict__ query, co
 #pragma unroll
     for (int i = 1; i < 8; ++i) m = fmaxf(m, redm[i]);
     float sum = 0.f;
-    for (int jj = t512; jj < Ts; jj += 512) {
+    for (int jj = t512; jj < w_n; jj += 512) {
         const float e = __expf(sc[jj] - m);
         sc[jj] = e;
         sum += e;
@@ -338,17 +390,17 @@ __device__ __forceinline__ void pd_attention(const float* __restrict__ query, co
 
     PD_STAMP(3)
     // context: wave hw takes positions hw, hw + 8, ...; lane d4 owns 4 consecutive depth elements (1 KB rows, coalesced)
-    const float* vb = values + (size_t)rr * Ts * PD_D + 4 * lane;
+    const float* vb = values + ((size_t)rr * Ts + w_lo) * PD_D + 4 * lane;
     float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
     int jj = hw;
-    for (; jj + 8 < Ts; jj += 16) {
+    for (; jj + 8 < w_n; jj += 16) {
         const float e0 = sc[jj], e1 = sc[jj + 8];
         const float4 v0 = *reinterpret_cast<const float4*>(vb + (size_t)jj * PD_D);
         const float4 v1 = *reinterpret_cast<const float4*>(vb + (size_t)(jj + 8) * PD_D);
         c0.x = fmaf(e0, v0.x, c0.x); c0.y = fmaf(e0, v0.y, c0.y); c0.z = fmaf(e0, v0.z, c0.z); c0.w = fmaf(e0, v0.w, c0.w);
         c1.x = fmaf(e1, v1.x, c1.x); c1.y = fmaf(e1, v1.y, c1.y); c1.z = fmaf(e1, v1.z, c1.z); c1.w = fmaf(e1, v1.w, c1.w);
     }
-    if (jj < Ts) {
+    if (jj < w_n) {
         const float e0 = sc[jj];
         const float4 v0 = *reinterpret_cast<const float4*>(vb + (size_t)jj * PD_D);
         c0.x = fmaf(e0, v0.x, c0.x); c0.y = fmaf(e0, v0.y, c0.y); c0.z = fmaf(e0, v0.z, c0.z); c0.w = fmaf(e0, v0.w, c0.w);
@@ -366,11 +418,31 @@ __device__ __forceinline__ void pd_attention(const float* __restrict__ query, co
         a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
         if (row_ok) pd_st4(pd_rsrc(ctx), (unsigned)(row * PD_D + 4 * t512) * 4u, a);
     }
-    if (align_t && row_ok)
-        for (int k = t512; k < Ts; k += 512) align_t[(size_t)row * Ts + k] = sc[k] * inv;
+    if (align_t && row_ok) {
+        // the reference pads the window back to the memory length (attention.py:85-92) and, with `gaussian`, weights
+        // it by exp(-(j - p)^2 / 2 * (D/2)^2) as written at attention.py:73-80 (the context uses the plain softmax)
+        const float gk = 0.5f * (0.5f * lc.d) * (0.5f * lc.d);
+        for (int k = t512; k < Ts; k += 512) {
+            const int jw = k - w_lo;
+            float a = 0.f;
+            if (jw >= 0 && jw < w_n) {
+                a = sc[jw] * inv;
+                if (LOCAL && lc.d > 0 && lc.gaussian) {
+                    const float dist = (float)k - pc;
+                    a *= __expf(-(dist * dist) * gk);
+                }
+            }
+            align_t[(size_t)row * Ts + k] = a;
+        }
+    }
     PD_STAMP(4)
     pd_publish();
     PD_STAMP(5)
+}
+__device__ __attribute__((noinline)) void pd_attention_local(const float* query, const float* keys, const float* values, float* ctx,
+                                                             float* align_t, int Ts, float* lds, int j, int b0, int B, unsigned* cnt,
+                                                             unsigned target, int* status, const PdLocal lc) {
+    pd_attention_body<true>(query, keys, values, ctx, align_t, Ts, lds, j, b0, B, cnt, target, status, lc);
 }
 
 __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) {
@@ -399,8 +471,13 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
             if (blockIdx.x == 0 && threadIdx.x == 0) { pd_dbg_step = t; pd_dbg_phase = k; }
 #endif
             if (k == 4) {
-                pd_attention(p.h_att, p.keys, p.memory, p.ctx, p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr, p.Ts, lds, j,
-                             b0, p.B, cnt, PD_W * g, p.status);
+                PdLocal lc;
+                lc.d = p.local_d; lc.gaussian = p.local_gaussian; lc.predictive = p.local_predictive; lc.step = t;
+                lc.wp = p.local_wp; lc.vp = p.local_vp; lc.p_hist_t = p.p_hist ? p.p_hist + (size_t)t * p.B : nullptr;
+                lc.err_flag = p.err_flag;
+                float* align_t = p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr;
+                if (p.local_d > 0) pd_attention_local(p.h_att, p.keys, p.memory, p.ctx, align_t, p.Ts, lds, j, b0, p.B, cnt, PD_W * g, p.status, lc);
+                else pd_attention_body<false>(p.h_att, p.keys, p.memory, p.ctx, align_t, p.Ts, lds, j, b0, p.B, cnt, PD_W * g, p.status, lc);
                 ++g;
                 continue;
             }
@@ -457,7 +534,8 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
 
 bool decoder_persistent_supports(const DecoderWeights& w, int cudnn, int B, int Ts) {
     (void)cudnn;   // both GRU formulations
-    return w.local_d == 0 && w.n_layers == 2 && w.att_units == PD_D && w.dec_units == PD_D && w.mem_units == PD_D &&
+    if (w.local_d > 0 && Ts < 2 * w.local_d + 1) return false;
+    return w.n_layers == 2 && w.att_units == PD_D && w.dec_units == PD_D && w.mem_units == PD_D &&
            w.prenet1_units == PD_D && w.prenet2_units == PD_P2 && w.n_mels % 16 == 0 && w.n_mels <= PD_D && B >= 1 && Ts >= 1 &&
            pd_lds_bytes(Ts) <= 160 * 1024 && (size_t)B * Ts * PD_D * 4 < 0xFFFFFFF0ull;
 }
@@ -491,6 +569,9 @@ hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, co
     p.counters = sync; p.resident = sync + 64 * clusters; p.status = reinterpret_cast<int*>(sync + 64 * clusters + 1);
     p.hold_flag = hold_flag;
     p.B = B; p.Ts = Ts; p.n_steps = n_steps; p.n_mels = w.n_mels; p.cudnn = cudnn;
+    p.local_d = w.local_d; p.local_gaussian = w.local_gaussian; p.local_predictive = w.local_d > 0 && w.local_predictive;
+    p.local_wp = w.local_wp; p.local_vp = w.local_vp; p.p_hist = sc.p_hist; p.err_flag = sc.err_flag;
+    if (p.local_predictive && (e = hipMemsetAsync(sc.err_flag, 0, sizeof(int), s)) != hipSuccess) return e;
 #ifdef PD_TIMELINE
     {
         static unsigned long long* dbg = nullptr;

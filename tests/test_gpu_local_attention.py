@@ -31,8 +31,10 @@ def _setup(hparams, weights, D, gaussian):
     (5, 30, 12, 3, True),      # small D, 7 positions split over 4 attention slices
     (2, 150, 30, 1, False),    # 3 positions: some slices empty
 ])
-def test_local_attention_decoder(hparams, weights, weights64, B, Ts, S, D, gaussian):
+@pytest.mark.parametrize('pd', [0, 2], ids=['launch-per-layer', 'persistent'])
+def test_local_attention_decoder(hparams, weights, weights64, B, Ts, S, D, gaussian, pd):
     hp, eng = _setup(hparams, weights, D, gaussian)
+    eng.set_option('persistent_decoder', pd)
     try:
         rng = np.random.default_rng(100 * B + D)
         memory = rng.standard_normal((B, Ts, 256)).astype(np.float32) * 0.5
@@ -128,10 +130,12 @@ def _setup_predictive(hparams, D, gaussian, seed=11, vp_scale=1.0, vp_shift=0.0)
 
 @pytest.mark.parametrize('B,Ts,S,D,gaussian,vp_scale', [(3, 60, 12, 10, True, 1.0), (4, 90, 20, 5, False, 4.0),
                                                         (2, 150, 9, 10, True, 8.0)])
-def test_predictive_local_attention_decoder(hparams, B, Ts, S, D, gaussian, vp_scale):
+@pytest.mark.parametrize('pd', [0, 2], ids=['launch-per-layer', 'persistent'])
+def test_predictive_local_attention_decoder(hparams, B, Ts, S, D, gaussian, vp_scale, pd):
     """LocalLuongAttention in PREDICTIVE mode (reference tacotron/attention.py:246-258): the window centre
     p = T_s sigmoid(v_p^T tanh(W_p h)) is predicted per utterance and step; larger v_p spreads the centres."""
     hp, eng, w = _setup_predictive(hparams, D, gaussian, vp_scale=vp_scale)
+    eng.set_option('persistent_decoder', pd)
     try:
         assert len(eng.manifest()) == len(pkg('tacotron.weights').manifest(hp))
         rng = np.random.default_rng(7 * B + D)
@@ -152,11 +156,13 @@ def test_predictive_local_attention_decoder(hparams, B, Ts, S, D, gaussian, vp_s
         eng.close()
 
 
-def test_predictive_window_leaving_the_memory_is_an_error(hparams):
+@pytest.mark.parametrize('pd', [0, 2], ids=['launch-per-layer', 'persistent'])
+def test_predictive_window_leaving_the_memory_is_an_error(hparams, pd):
     """Where the predicted window leaves the memory the reference's padding arithmetic (attention.py:288-304)
     breaks and TensorFlow fails at run time; the library reports TTS_ERR_UNSUPPORTED, the oracle raises."""
     # T_s = 2D+1: only floor(p) == D keeps the window inside, and a large v_p spreads p = 21 sigmoid(.) well beyond
     hp, eng, w = _setup_predictive(hparams, 10, True, vp_scale=8.0)
+    eng.set_option('persistent_decoder', pd)
     try:
         memory = np.random.default_rng(1).standard_normal((2, 21, 256)).astype(np.float32)
         w64 = {k: v.astype(np.float64) for k, v in w.items()}
