@@ -101,8 +101,8 @@ int tts_set_stream(tts_handle_t h, void* hip_stream);
  * complete when the call is made), "reserve_cus" (default 32: compute units kept free of
  * Griffin-Lim workgroups for that second stream, 0 = none), "hold_lds_kb" (default 64: LDS one sleeper workgroup
  * of that reservation allocates), "persistent_decoder" (the whole decoder loop as ONE launch of co-resident
- * workgroup clusters, GRUCell form + global attention only: 1 = under the call pipeline (default), 2 = whenever the
- * configuration allows, 0 = never; tts_synchronize reports TTS_ERR_HIP if one of its bounded waits timed out),
+ * workgroup clusters, two decoder GRU layers, at most 64 utterances under the pipeline: 1 = under the call pipeline
+ * with more than 48 utterances per call, where it pays (default), 2 = whenever the configuration allows, 0 = never; tts_synchronize reports TTS_ERR_HIP if one of its bounded waits timed out),
  * "gl_fused" (default 0; 1 = all Griffin-Lim iterations of a call in one launch when no per-iteration mse is
  * asked for: identical waveforms, same bounded-wait error report). */
 int tts_set_option(tts_handle_t h, const char* key, int value);

@@ -79,10 +79,13 @@ struct tts_handle_s {
     bool front_pending = false;     // ev_front_done has been recorded at least once
     unsigned syn_calls = 0;
     int syn_shape[3] = {0, 0, 0};   // (B, Ts, n_steps) of the previous tts_synthesize call
-    // persistent decoder (decoder_persistent.hip).  1 (default): under the call pipeline, where it takes the decoder
-    // from ~21 to ~17 ms and no longer disturbs Griffin-Lim with launch boundaries; a stand-alone decoder call keeps
-    // the launch-per-layer graph, which is faster on an idle chip (9.4 against 14.6 ms at B = 64).  2: always
-    // (where the configuration allows it).  0: never.
+    // persistent decoder (decoder_persistent.hip).  1 (default): under the call pipeline AND with more than 48
+    // utterances per call -- there the step is bound by post-net + Griffin-Lim, and the persistent kernel (17 ms
+    // under that load against 21 for the launch-per-layer graph, no launch boundaries that disturb Griffin-Lim, no
+    // sleeper workgroups) is worth 0.1-0.4 ms per step.  With fewer utterances the step is bound by the decoder
+    // itself, and on a lightly loaded chip the launch-per-layer graph is the faster decoder (9.4 against 15 ms alone
+    // at B = 64; tools/pipeline_sweep.py: 16.0 against 19.6 ms per call at B = 32), so it stays.  2: whenever the
+    // configuration allows it.  0: never.
     int persistent_decoder = 1;
     int gl_fused = 0;                // all Griffin-Lim iterations of a call in one launch (gl_iter_kernel, FUSED): same
                                      // waveforms, measured no faster, so off unless asked for
@@ -1433,7 +1436,7 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
     if ((rc = run_single(h, dense_group(memory, mem, h->mem_wt, nullptr, keys, A, B * Ts, A, mem, ACT_NONE)))) return rc;
 
     const int pd_budget = h->cur_cu_budget > 0 ? h->cur_cu_budget : h->n_cus_dev;
-    const bool pd_wanted = h->persistent_decoder >= 2 || (h->persistent_decoder == 1 && h->cur_cu_budget > 0);
+    const bool pd_wanted = h->persistent_decoder >= 2 || (h->persistent_decoder == 1 && h->cur_cu_budget > 0 && B > 48);
     const bool use_pd = pd_wanted && decoder_persistent_supports(h->dec, c.force_cudnn, B, Ts) &&
                         decoder_persistent_workgroups(B) <= pd_budget;
     if (use_pd) {
@@ -1731,7 +1734,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         // the other n_cus - reserve_cus), and the encoder in front of it may queue behind Griffin-Lim workgroups
         // without costing the step anything: no sleepers then.  The launch-per-layer decoder (configurations the
         // persistent kernel does not cover) still needs the reservation for its ~2000 dependent launches.
-        const bool pd_path = h->persistent_decoder && h->reserve_cus > 0 &&
+        const bool pd_path = (h->persistent_decoder >= 2 || (h->persistent_decoder == 1 && B > 48)) && h->reserve_cus > 0 &&
                              decoder_persistent_supports(h->dec, c.force_cudnn, B, Ts) &&
                              decoder_persistent_workgroups(B) <= h->reserve_cus;
         if (h->reserve_cus > 0 && !pd_path) {
