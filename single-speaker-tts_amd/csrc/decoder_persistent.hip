@@ -53,12 +53,13 @@ __device__ __forceinline__ void pd_st4(const __amdgpu_buffer_rsrc_t& rs, unsigne
 // workgroup, so the cell is ONE hop: the second pass continues on the tile of the first (`cont`).
 enum PdEpi { PD_ACT = 0, PD_GATES = 1, PD_CAND = 2, PD_CUDNN_RU = 3, PD_CUDNN_HX = 4 };
 
-#ifdef PD_TIMELINE   // tools only: s_memrealtime stamps (100 MHz) of workgroup 0 in step 100, [phase][8]
+#ifdef PD_TIMELINE   // tools only: s_memrealtime stamps (100 MHz) of workgroup 0 in step 100, [phase][8], kept in LDS
 __device__ unsigned long long* pd_dbg = nullptr;
-__device__ int pd_dbg_step = -1, pd_dbg_phase = 0;
-#define PD_STAMP(I)                                                                                       \
-    if (blockIdx.x == 0 && threadIdx.x == 0 && pd_dbg && pd_dbg_step == 100)                             \
-        pd_dbg[pd_dbg_phase * 8 + (I)] = __builtin_amdgcn_s_memrealtime();
+__device__ __shared__ int pd_tl_step, pd_tl_phase;
+__device__ __shared__ float* pd_tl_lds;
+#define PD_STAMP(I)                                                                                              \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && pd_tl_step == 100)                                               \
+        reinterpret_cast<unsigned long long*>(pd_tl_lds)[pd_tl_phase * 8 + (I)] = __builtin_amdgcn_s_memrealtime();
 #else
 #define PD_STAMP(I)
 #endif
@@ -86,7 +87,11 @@ struct PdPhase {
 #define PD_OFF_R (PD_OFF_U + 16 * 32)
 #define PD_OFF_CTRL (PD_OFF_R + 16 * 32)
 #define PD_OFF_SC (PD_OFF_CTRL + 16)
+#ifdef PD_TIMELINE
+size_t pd_lds_bytes(int Ts) { return ((size_t)PD_OFF_SC + 2 * (size_t)((Ts + 3) & ~3)) * sizeof(float) + 1024; }
+#else
 size_t pd_lds_bytes(int Ts) { return ((size_t)PD_OFF_SC + 2 * (size_t)((Ts + 3) & ~3)) * sizeof(float); }
+#endif
 
 // Start of a phase: signal that this workgroup's stores of the PREVIOUS phase are complete (pd_publish ran), then
 // wait until `target` arrivals have been counted on the cluster's counter.  Lane 0 of the workgroup does both; the
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
 #pragma nounroll
         for (int k = 0; k < 10; ++k) {
 #ifdef PD_TIMELINE
-            if (blockIdx.x == 0 && threadIdx.x == 0) { pd_dbg_step = t; pd_dbg_phase = k; }
+            if (threadIdx.x == 0) { pd_tl_step = t; pd_tl_phase = k; pd_tl_lds = lds + ((PD_OFF_SC + 2 * ((p.Ts + 3) & ~3) + 1) & ~1); }
 #endif
             if (k == 4) {
                 PdLocal lc;
@@ -530,6 +535,10 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
             if (!ph.more) ++g;
         }
     }
+#ifdef PD_TIMELINE
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 80 && pd_dbg) pd_dbg[threadIdx.x] = reinterpret_cast<unsigned long long*>(pd_tl_lds)[threadIdx.x];
+#endif
 }
 
 bool decoder_persistent_supports(const DecoderWeights& w, int cudnn, int B, int Ts) {
@@ -544,7 +553,7 @@ int decoder_persistent_workgroups(int B) { return PD_W * ((B + 15) / 16); }
 
 hipError_t decoder_persistent_configure() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               160 * 1024);
+                               160 * 1024 - 64);
 }
 
 // Capturable: two memsets and one launch.  `sync` = 64 unsigned per cluster + 1 (resident count) + 1 (status word).

@@ -43,5 +43,5 @@ i=0
 for G in "$G1" "$G2" "$G3"; do i=$((i+1)); rm -rf $O/mfma/p$i; rocprofv3 --kernel-trace --pmc $G --output-format csv -d $O/mfma/p$i -- python3 $R/tools/net_bench.py > $O/mfma_p$i.log 2>&1; done
 python3 $R/tools/pmc_summary.py $O/mfma gemm_f32_kernel bigru_kernel > $O/${TAG}_gemm_mfma_counters.txt; head -30 $O/${TAG}_gemm_mfma_counters.txt
 echo "== stage benchmarks"
-( echo "# tools/gemm_bench.py"; python3 $R/tools/gemm_bench.py; echo; echo "# tools/net_bench.py"; python3 $R/tools/net_bench.py; echo; echo "# tools/dec_bench.py"; python3 $R/tools/dec_bench.py; echo; echo "# tools/gl_bench.py"; python3 $R/tools/gl_bench.py; echo; echo "# tools/latency_bench.py"; python3 $R/tools/latency_bench.py ) > $O/${TAG}_stage_benchmarks.txt 2>&1
+( echo "# tools/gemm_bench.py"; python3 $R/tools/gemm_bench.py; echo; echo "# tools/net_bench.py"; python3 $R/tools/net_bench.py; echo; echo "# tools/dec_bench.py"; python3 $R/tools/dec_bench.py; echo; echo "# tools/gl_bench.py"; python3 $R/tools/gl_bench.py; echo; echo "# tools/latency_bench.py"; python3 $R/tools/latency_bench.py; echo; echo "# tools/pipeline_sweep.py"; python3 $R/tools/pipeline_sweep.py ) > $O/${TAG}_stage_benchmarks.txt 2>&1
 tail -12 $O/${TAG}_stage_benchmarks.txt
