@@ -10,7 +10,7 @@ W = importlib.import_module('single-speaker-tts_amd.tacotron.weights')
 eng = sstts.Engine()
 eng.load_weights(W.synthetic_weights(0))
 rng = np.random.default_rng(0)
-for B in (1, 4, 8, 16, 32, 48, 64):
+for B in [int(x) for x in os.environ.get('SWEEP_B', '1,4,8,16,32,48,64').split(',')]:
     ids = rng.integers(2, 39, (B, 150)).astype(np.int32)
     ids[:, -1] = 1
     d_ids = eng.to_device(ids)
