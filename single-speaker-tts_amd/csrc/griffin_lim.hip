@@ -316,24 +316,41 @@ __device__ __forceinline__ float gl_stream_load(const float* p) { return __built
 __device__ __forceinline__ void gl_stream_store(cf* p, cf v) { __builtin_nontemporal_store(v, p); }
 #define GL_STREAM_LOAD(ptr) gl_stream_load(ptr)
 #define GL_STREAM_STORE(ptr, val) gl_stream_store((ptr), (val))
-// Spectrum estimate X between iterations.  Separate launches per iteration: plain loads, streaming stores.  FUSED
-// launch (several iterations in one kernel, see gl_iter_kernel): a run's neighbours are other workgroups, possibly
-// on other XCDs, so every load of X bypasses the L1 (sc1: a row is read once per iteration anyway) and the frames
-// a neighbour reads as its halo are stored write-through (sc1); MI355X_MICROARCH.md, valid hand-off forms.
+// The state between iterations is the UNIT PHASOR of every bin, 32 bits each (round 2; the estimate X = |S| e^{i phi} it
+// stands for is rebuilt in phase A from |S|, which phase A reads anyway from then on and phase B no longer does:
+// 4 B phasor + 4 B |S| in, 4 B phasor out = 12 instead of 20 bytes per bin and iteration through a memory path that
+// gives a compute unit ~21 GB/s however many waves ask, tools/stream_microbench.hip).  Code: the component of
+// SMALLER magnitude as a float (|.| <= 0.7072) whose two lowest mantissa bits say which component it is (bit 1: the
+// real part) and carry the sign of the other one (bit 0); the other one is sqrt(1 - small^2) >= 0.7071, well
+// conditioned.  Worst-case error of a decoded component 1.7e-7 (two dropped mantissa bits of the small one), the size
+// of fp32 rounding in the old x * rsq(|x|^2) * |S| product.
+__device__ __forceinline__ unsigned gl_pack_phasor(cf x, float rs) {   // x: any scale, rs = 1 / |x|
+    const bool sw = fabsf(x.x) < fabsf(x.y);
+    const float small = (sw ? x.x : x.y) * rs;
+    const float big = sw ? x.y : x.x;
+    return (__float_as_uint(small) & ~3u) | (sw ? 2u : 0u) | (__float_as_uint(big) >> 31);
+}
+__device__ __forceinline__ cf gl_unpack_phasor(unsigned c, float mag) {   // -> mag * phasor
+    const float sm = __uint_as_float(c & ~3u);
+    const float bg = __uint_as_float(__float_as_uint(__builtin_amdgcn_sqrtf(fmaf(-sm, sm, 1.0f))) | (c << 31));
+    const bool sw = (c & 2u) != 0u;
+    return cmk((sw ? sm : bg) * mag, (sw ? bg : sm) * mag);
+}
+// Separate launches per iteration: plain loads, streaming stores.  FUSED launch (several iterations in one kernel, see
+// gl_iter_kernel): a run's neighbours are other workgroups, possibly on other XCDs, so every load of the state bypasses
+// the L1 (sc1: a row is read once per iteration anyway) and the frames a neighbour reads as its halo are stored
+// write-through (sc1); MI355X_MICROARCH.md, valid hand-off forms.
 template <bool FUSED>
-__device__ __forceinline__ cf gl_x_load(const cf* p) {
-    if (FUSED)
-        return __builtin_bit_cast(cf, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT));
+__device__ __forceinline__ unsigned gl_c_load(const unsigned* p) {
+    if (FUSED) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
 }
 template <bool FUSED>
-__device__ __forceinline__ void gl_x_store(cf* p, cf v, bool shared_frame) {
+__device__ __forceinline__ void gl_c_store(unsigned* p, unsigned v, bool shared_frame) {
     if (FUSED && shared_frame)   // wave-uniform
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
-        gl_stream_store(p, v);
+        __builtin_nontemporal_store(v, p);
 }
 #define GL_FUSED_SPIN_LIMIT 4000000u
 
@@ -431,8 +448,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
     const int n_it = FUSED ? p.n_fused : 1;
   for (int it = 0; it < n_it; ++it) {
     if (FUSED) item = (int)blockIdx.x;
-    const cf* x_in = FUSED ? reinterpret_cast<const cf*>(p.buf[it & 1]) : reinterpret_cast<const cf*>(p.phase_in);
-    cf* x_out = FUSED ? reinterpret_cast<cf*>(p.buf[(it + 1) & 1]) : reinterpret_cast<cf*>(p.phase_out);
+    const unsigned* x_in = reinterpret_cast<const unsigned*>(FUSED ? p.buf[it & 1] : p.phase_in);
+    unsigned* x_out = reinterpret_cast<unsigned*>(FUSED ? p.buf[(it + 1) & 1] : p.phase_out);
     while (item < p.n_items) {
         // ---------------- decode the work item (wave-uniform scalar code): a RUN of consecutive frames of one
         // utterance, processed in chunks of p.chunk frames.  The first chunk inverse-transforms its `halo`
@@ -449,7 +466,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         const int run_t0 = p.cls_t0[k] + jc * run_len;
         const int slot0 = p.cls_slot0[k] + jc * p.cls_chunks[k];   // ordinal of the run's first chunk in its utterance
         const float* magb = p.mag + (size_t)b * p.T * p.FP;
-        const cf* phb = x_in + (size_t)b * p.T * p.FP;
+        const unsigned* phb = x_in + (size_t)b * p.T * p.FP;
         unsigned next_item_reg = 0;
         if (tid == 0) next_item_reg = FUSED ? (unsigned)item + gridDim.x : atomicAdd(p.work_counter, 1u);   // consumed before the first barrier below
         int next_item = p.n_items;
@@ -500,15 +517,20 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         // hits in cache, and the row never has to be staged through LDS.  UNCONDITIONAL loads (the frame
         // index is clamped instead of branching): registers filled under a branch stay in scratch memory,
         // and hipcc then waits for the loads right after issuing them.
-        cf gk[16];
-        float nyq;
+        unsigned gc[16];   // phasor codes of bins lane + 64 j ...
+        float gs[16];      // ... and their target magnitudes
+        unsigned nyq_c;
+        float nyq_s;
 #define GL_LOAD_FRAME(FA)                                                                  \
     {                                                                                      \
         int tf_ = t0 - halo + (FA);                                                        \
         tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                  \
-        const cf* prow_ = phb + (size_t)tf_ * p.FP + lane;                                 \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gk[j_] = gl_x_load<FUSED>(prow_ + 64 * j_); \
-        nyq = gl_x_load<FUSED>(phb + (size_t)tf_ * p.FP + MH).x;                            \
+        const unsigned* prow_ = phb + (size_t)tf_ * p.FP + lane;                           \
+        const float* srow_ = magb + (size_t)tf_ * p.FP + lane;                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = gl_c_load<FUSED>(prow_ + 64 * j_); \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_STREAM_LOAD(srow_ + 64 * j_);   \
+        nyq_c = gl_c_load<FUSED>(phb + (size_t)tf_ * p.FP + MH);                           \
+        nyq_s = magb[(size_t)tf_ * p.FP + MH];                                             \
     }
         GL_LOAD_FRAME(fa0 + R * wave)
 
@@ -527,8 +549,10 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             const bool ok = fa < nA && tf >= 0 && tf < p.T;
             cf v[16];
             if (ok) {
-                cf gm[16];
-                mirror_bins(gk, gm, ex, lane, cmk(nyq, 0.f));
+                cf gk[16], gm[16];   // X[k] = |S[k]| * phasor[k]
+#pragma unroll
+                for (int j = 0; j < 16; ++j) gk[j] = gl_unpack_phasor(gc[j], fabsf(gs[j]));
+                mirror_bins(gk, gm, ex, lane, cmk(gl_unpack_phasor(nyq_c, fabsf(nyq_s)).x, 0.f));
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     cf xk = gk[j];
@@ -653,7 +677,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             }
         } else {
             // ---------------- phase B: forward FFT of the owned frames, new unit phasors
-            cf* pob = x_out + (size_t)b * p.T * p.FP;
+            unsigned* pob = x_out + (size_t)b * p.T * p.FP;
             float mse_acc = 0.f;
             // frames are handed out dynamically (LDS counter): the wave that wins issue arbitration on
             // its SIMD takes more of them, so both waves of a SIMD finish together
@@ -672,9 +696,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 cf v[16];
                 // target magnitudes of this frame (needed only after the FFT: the loads fly meanwhile)
                 const float* mrow = magb + (size_t)t * p.FP;
-                float mg[16];
+                float mg[16];   // only the mse needs the magnitudes here: the state is the phasor alone
+                if (MSE) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) mg[c] = fabsf(GL_STREAM_LOAD(mrow + lane + 64 * c));
+                    for (int c = 0; c < 16; ++c) mg[c] = fabsf(GL_STREAM_LOAD(mrow + lane + 64 * c));
+                }
                 const int ylo = t * hop + wpad - MH;          // y index of window sample 0
                 const bool edge = ylo < 0 || ylo + win > L;   // wave-uniform: reflect padding needed
                 if (!edge) {
@@ -713,7 +739,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
                 wave_lds_sync();
-                cf* orow = pob + (size_t)t * p.FP;
+                unsigned* orow = pob + (size_t)t * p.FP;
                 // (FUSED) a frame within `halo` of the run's ends is a neighbour's halo frame
                 const bool shared_frame = FUSED && (t < run_t0 + halo || t >= run_t0 + run_len - halo);
                 // next estimate: target magnitude, new phase.  Fast path: x * (rsq(|x|^2) * |S|), valid
@@ -733,8 +759,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                     const cf o = cmul(csub_conj(zk, zmr[c]), twr[c]);
                     const cf x = cadd_mi(e, o);
                     const float s = fmaf(x.x, x.x, x.y * x.y);
-                    const float g = __builtin_amdgcn_rsqf(s) * mg[c];   // raw v_rsq_f32: s is range-checked below
-                    gl_x_store<FUSED>(orow + k, x * g, shared_frame);
+                    // raw v_rsq_f32: s is range-checked below
+                    gl_c_store<FUSED>(orow + k, gl_pack_phasor(x, __builtin_amdgcn_rsqf(s)), shared_frame);
                     s_min = fminf(s_min, s);
                     s_max = fmaxf(s_max, s);
                     if (MSE) {
@@ -752,14 +778,14 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                         const cf e = cadd_conj(zk, zr);
                         const cf o = cmul(csub_conj(zk, zr), reinterpret_cast<const cf*>(p.tw2048)[k]);
                         const cf x = cadd_mi(e, o);
-                        gl_x_store<FUSED>(orow + k, cscale(unit_phasor(x), fabsf(mrow[k])), shared_frame);
+                        gl_c_store<FUSED>(orow + k, gl_pack_phasor(unit_phasor(x), 1.0f), shared_frame);
                     }
                 }
                 if (lane == 0) {
                     const cf z0 = v[0];
                     const float xn = z0.x - z0.y;   // Nyquist bin, real
                     const float mn = fabsf(mrow[MH]);
-                    gl_x_store<FUSED>(orow + MH, cmk(xn < 0.f ? -mn : mn, 0.f), shared_frame);
+                    gl_c_store<FUSED>(orow + MH, xn < 0.f ? 1u : 0u, shared_frame);   // phasor (-1, 0) / (1, 0)
                     if (MSE) {
                         const float d = mn - (2.0f * MH) * fabsf(xn);   // xn = X[MH] / (2 MH)
                         mse_acc += d * d;
@@ -811,7 +837,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             if (tfn >= 0) {
                 tfn = tfn >= p.T ? p.T - 1 : tfn;
                 const float* row2 = reinterpret_cast<const float*>(x_in + ((size_t)bn * p.T + tfn) * p.FP);
-                warm = row2[32 * lane];   // 64 lanes x 128 B = the first 8 KB of the 8224-byte row
+                warm = row2[16 * lane];   // 64 lanes x 64 B = the 4112-byte row
             }
         }
 #endif
@@ -1324,7 +1350,8 @@ __global__ void phase_init_kernel(const float* init_ft, uint64_t seed, const flo
             sincospif(2.0f * tile[tx][i], &sn, &cs);
             const size_t o = ((size_t)b * T + t) * FP + f;
             const float m = f < F ? fabsf(mag_tf[o]) : 0.f;
-            out[o] = cmk(m * cs, m * sn);   // X0 = |S| exp(2 pi i u)
+            (void)m;
+            reinterpret_cast<unsigned*>(out)[o] = gl_pack_phasor(cmk(cs, sn), 1.0f);   // phasor of exp(2 pi i u)
         }
     }
 }
