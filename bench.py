@@ -322,7 +322,9 @@ def main():
             'roofline': {'kernel': 'gl_iter_kernel<0> (one Griffin-Lim iteration, iSTFT+STFT fused)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'launch_ms': gl_launch_ms, 'launch_ms_alone': gl_alone_ms,
-                         'algorithmic_bytes_per_launch': alg_bytes},
+                         'algorithmic_bytes_per_launch': alg_bytes,
+                         'note': 'achieved = algorithmic bytes (20 B per bin and iteration, SURVEY.md 8(d)) / launch time; the kernel '
+                                 'itself moves 12 B per bin (32-bit phasor code in and out, 4 B magnitude in), which is what traffic shows'},
             'roofline_mfma': {'kernel': 'gemm_f32_kernel (post-net projection 1: conv1d k=3, 1024 -> 256, max-pool in the loader, M = {})'.format(M),
                               'bound': 'mfma', 'achieved': gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
                               'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',

@@ -322,8 +322,9 @@ __device__ __forceinline__ void gl_stream_store(cf* p, cf v) { __builtin_nontemp
 // gives a compute unit ~21 GB/s however many waves ask, tools/stream_microbench.hip).  Code: the component of
 // SMALLER magnitude as a float (|.| <= 0.7072) whose two lowest mantissa bits say which component it is (bit 1: the
 // real part) and carry the sign of the other one (bit 0); the other one is sqrt(1 - small^2) >= 0.7071, well
-// conditioned.  Worst-case error of a decoded component 1.7e-7 (two dropped mantissa bits of the small one), the size
-// of fp32 rounding in the old x * rsq(|x|^2) * |S| product.
+// conditioned.  Worst-case error of a decoded component 3e-7 (two dropped mantissa bits of the small one plus the fp32
+// rounding of x / |x|; tests/test_host_logic.py::test_phasor_code_emulation), the size of the rounding in the old
+// x * rsq(|x|^2) * |S| product.
 __device__ __forceinline__ unsigned gl_pack_phasor(cf x, float rs) {   // x: any scale, rs = 1 / |x|
     const bool sw = fabsf(x.x) < fabsf(x.y);
     const float small = (sw ? x.x : x.y) * rs;

@@ -16,7 +16,7 @@ for B in [int(x) for x in os.environ.get('SWEEP_B', '1,4,8,16,32,48,64').split('
     d_ids = eng.to_device(ids)
     kw = dict(n_steps=200, ref_db=6.02, max_db=99.89, power=1.3, n_iter=60, win_length=1102, hop_length=275, seed=1)
     res = []
-    for pd in (0, 1):
+    for pd in (0, 2):
         eng.set_option('persistent_decoder', pd)
         out = eng.synthesize(d_ids, **kw)
         for _ in range(3):
