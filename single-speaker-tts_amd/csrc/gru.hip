@@ -7,12 +7,15 @@
 // The input halves (x W_x + b for r, u, c and both directions) are one big MFMA GEMM done
 // beforehand; this kernel is the strictly sequential part.  It is latency bound (T dependent
 // steps of a 128 -> 384 mat-vec), so the design minimises the dependent chain of one step:
-//   * one 1024-thread workgroup per (utterance, direction): 16 waves = 4 per SIMD hide the LDS and
-//     transcendental latencies of each other;
-//   * the recurrent weights live in VGPRs for the whole sequence; every gate column is split
-//     over 4 lanes (K/4 = 32 FMAs each), every candidate column over 8 lanes (16 FMAs each), and
-//     the partial sums are combined with DPP shuffles inside the wave (no LDS round trip);
-//   * the state lives in LDS in a padded layout whose four K-quarters fall into different banks;
+//   * one 512-thread workgroup per (utterance, direction): thread (unit j, K quarter kq) owns the r, u AND candidate
+//     columns of unit j over 32 of the 128 k -- 96 recurrent weights in VGPRs for the whole sequence, so r, u, the
+//     candidate and the state of a unit all end up in the same four lanes and only r*h has to cross the workgroup;
+//   * the three dot products run on v_pk_fma_f32 (two consecutive k per instruction) and are reduced over the quad
+//     with DPP operands (no LDS round trip);
+//   * two workgroup barriers per step (GRUCell form: after r*h is published, after the new state is; the
+//     CudnnCompatibleGRUCell form needs only the second) of 8 waves instead of three of 16 (the 1024-thread kernel
+//     it replaces: 2540 cycles per step, 900 of them at barriers);
+//   * the state lives in LDS, ping-pong, in a padded layout whose four K-quarters fall into different banks;
 //   * the next step's input projections are prefetched while the current step computes.
 //
 //   GRUCell [TF-1.8]       : [r|u] = sig(xg + h Wgh);  c = tanh(xc + (r*h) Wch);  h' = u h + (1-u) c
@@ -21,12 +24,11 @@
 
 namespace tts {
 
-#define GRU_THREADS 1024
+#define GRU_THREADS 512
 #define GRU_QPAD 36   // floats per K-quarter of the state in LDS (32 + 4: quarters hit different banks)
 
-// Lane sums with DPP operands (v_add_f32_dpp, no LDS round trip: hipcc lowers __shfl_xor to ds_bpermute_b32, a
-// dependent LDS access per reduction level).  After gru_sum4 every lane of a quad holds the quad's sum; gru_sum8
-// is valid in the first lane of each group of eight.
+// Quad sum with DPP operands (v_add_f32_dpp, no LDS round trip: hipcc lowers __shfl_xor to ds_bpermute_b32, a
+// dependent LDS access per reduction level).  Every lane of the quad ends up with the sum.
 template <int CTRL>
 __device__ __forceinline__ float gru_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -36,10 +38,22 @@ __device__ __forceinline__ float gru_sum4(float v) {
     v += gru_dpp<0x4E>(v);    // quad_perm [2,3,0,1]: lane ^ 2
     return v;
 }
-__device__ __forceinline__ float gru_sum8(float v) {
-    v = gru_sum4(v);
-    v += gru_dpp<0x104>(v);   // row_shl:4: lane i takes lane i + 4
-    return v;
+typedef float gru_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gru_f2 gru_pk_fma(gru_f2 a, gru_f2 b, gru_f2 c) {   // (a.x b.x + c.x, a.y b.y + c.y)
+    gru_f2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// sum_k q[k] * w[k] over this lane's 32 k (w as 16 pairs), two packed accumulators
+__device__ __forceinline__ float gru_dot32(const float* q, const gru_f2 (&w)[16]) {
+    gru_f2 a = {0.f, 0.f}, b = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 32; i += 4) {
+        const float4 hv = *reinterpret_cast<const float4*>(q + i);
+        a = gru_pk_fma((gru_f2){hv.x, hv.y}, w[i / 2], a);
+        b = gru_pk_fma((gru_f2){hv.z, hv.w}, w[i / 2 + 1], b);
+    }
+    return (a.x + a.y) + (b.x + b.y);
 }
 
 template <int H, bool CUDNN>
@@ -50,115 +64,66 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_kernel(const float* __restr
     const int b = blockIdx.x;
     const int d = blockIdx.y;        // 0 = forward, 1 = backward
     const int tid = threadIdx.x;
-    // phase 1 mapping: gate column gc (0..2H-1), K quarter kq
-    const int gc = tid >> 2, kq = tid & 3;
-    // phase 2 mapping: candidate column cc (0..H-1), K eighth ke
-    const int cc = tid >> 3, ke = tid & 7;
+    const int j = tid >> 2, kq = tid & 3;   // unit, K quarter
 
-    __shared__ __attribute__((aligned(16))) float hs[4 * GRU_QPAD];    // state, quarter-padded
-    __shared__ __attribute__((aligned(16))) float rhs[4 * GRU_QPAD];   // r*h (GRUCell) for phase 2
-    __shared__ float us[H];
-    __shared__ float rs[H];
+    // state, quarter-padded, two copies: step s reads copy s & 1 and writes the other one, so the barrier at the end of
+    // a step is all that separates a step's reads from the next write of the same words
+    __shared__ __attribute__((aligned(16))) float hs[2][4 * GRU_QPAD];
+    __shared__ __attribute__((aligned(16))) float rhs[4 * GRU_QPAD];   // r*h (GRUCell form)
 
     const size_t wstride = (size_t)H * 2 * H + (size_t)H * H + (CUDNN ? H : 0);
-    const float* wg_g = wrec + d * wstride;          // [H][2H]
+    const float* wg_g = wrec + d * wstride;          // [H][2H]: columns [r | u]
     const float* wc_g = wg_g + (size_t)H * 2 * H;    // [H][H]
     const float* bch_g = wc_g + (size_t)H * H;       // [H] (cudnn)
 
-    float wg[32];   // Wgh[32 kq + i][gc]
-    float wc[16];   // Wch[16 ke + i][cc]
+    gru_f2 wr[16], wu[16], wc[16];   // (W[32 kq + 2 i][col], W[32 kq + 2 i + 1][col]) for col = r_j, u_j, c_j
 #pragma unroll
-    for (int i = 0; i < 32; ++i) wg[i] = wg_g[(size_t)(32 * kq + i) * (2 * H) + gc];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) wc[i] = wc_g[(size_t)(16 * ke + i) * H + cc];
+    for (int i = 0; i < 16; ++i) {
+        const size_t k0 = 32 * kq + 2 * i;
+        wr[i] = (gru_f2){wg_g[k0 * (2 * H) + j], wg_g[(k0 + 1) * (2 * H) + j]};
+        wu[i] = (gru_f2){wg_g[k0 * (2 * H) + H + j], wg_g[(k0 + 1) * (2 * H) + H + j]};
+        wc[i] = (gru_f2){wc_g[k0 * H + j], wc_g[(k0 + 1) * H + j]};
+    }
     float bch = 0.f;
-    if (CUDNN) bch = bch_g[cc];
+    if (CUDNN) bch = bch_g[j];
 
-    if (tid < 4 * GRU_QPAD) { hs[tid] = 0.f; rhs[tid] = 0.f; }
+    if (tid < 4 * GRU_QPAD) { hs[0][tid] = 0.f; hs[1][tid] = 0.f; rhs[tid] = 0.f; }
     __syncthreads();
 
-    const float* xb = xproj + (size_t)b * T * xld + (size_t)d * 3 * H;
-    float* ob = out + (size_t)b * T * 2 * H + (size_t)d * H;
+    const float* xb = xproj + (size_t)b * T * xld + (size_t)d * 3 * H + j;
+    float* ob = out + (size_t)b * T * 2 * H + (size_t)d * H + j;
+    const int slot = (j >> 5) * GRU_QPAD + (j & 31);   // unit j in the quarter-padded layout
 
     int t = d ? T - 1 : 0;
     const int dt = d ? -1 : 1;
-    // lane kq == 0 of every gate column / lane ke == 0 of every candidate column owns the input term
-    float xg = (kq == 0) ? xb[(size_t)t * xld + gc] : 0.f;
-    float xc = (ke == 0) ? xb[(size_t)t * xld + 2 * H + cc] : 0.f;
-    float hreg = 0.f;   // h[cc] (valid in the ke == 0 lanes)
+    // the four lanes of a unit load the same three input terms (one request each after coalescing)
+    float xr = xb[(size_t)t * xld], xu = xb[(size_t)t * xld + H], xc = xb[(size_t)t * xld + 2 * H];
+    float hreg = 0.f;   // h[j], kept by all four lanes of the unit
 
     for (int s = 0; s < T; ++s, t += dt) {
-        float xg_n = 0.f, xc_n = 0.f;
+        float xr_n = 0.f, xu_n = 0.f, xc_n = 0.f;
         if (s + 1 < T) {
-            const size_t o = (size_t)(t + dt) * xld;
-            if (kq == 0) xg_n = xb[o + gc];
-            if (ke == 0) xc_n = xb[o + 2 * H + cc];
+            const float* xn = xb + (size_t)(t + dt) * xld;
+            xr_n = xn[0]; xu_n = xn[H]; xc_n = xn[2 * H];
         }
-
-        // ---- phase 1: gates.  4 lanes per column, 32 FMAs each, DPP-reduced.
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        const float* hq = hs + kq * GRU_QPAD;
-#pragma unroll
-        for (int i = 0; i < 32; i += 4) {
-            const float4 hv = *reinterpret_cast<const float4*>(hq + i);
-            a0 = fmaf(hv.x, wg[i + 0], a0);
-            a1 = fmaf(hv.y, wg[i + 1], a1);
-            a2 = fmaf(hv.z, wg[i + 2], a2);
-            a3 = fmaf(hv.w, wg[i + 3], a3);
-        }
-        const float g = gru_sum4((a0 + a1) + (a2 + a3));
-        float pc = 0.f;
+        const float* hq = hs[s & 1] + kq * GRU_QPAD;
+        const float r = sigmoidf_(xr + gru_sum4(gru_dot32(hq, wr)));
+        const float u = sigmoidf_(xu + gru_sum4(gru_dot32(hq, wu)));
+        float c;
         if (CUDNN) {
-            // candidate's recurrent part does not depend on r here: compute it in the same phase
-            const float* he = hs + (ke >> 1) * GRU_QPAD + (ke & 1) * 16;
-            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; i += 4) {
-                const float4 hv = *reinterpret_cast<const float4*>(he + i);
-                p0 = fmaf(hv.x, wc[i + 0], p0);
-                p1 = fmaf(hv.y, wc[i + 1], p1);
-                p2 = fmaf(hv.z, wc[i + 2], p2);
-                p3 = fmaf(hv.w, wc[i + 3], p3);
-            }
-            pc = gru_sum8((p0 + p1) + (p2 + p3));
-        }
-        if (kq == 0) {
-            const float gate = sigmoidf_(xg + g);
-            if (gc < H) {
-                rs[gc] = gate;
-            } else {
-                us[gc - H] = gate;
-            }
-        }
-        __syncthreads();
-
-        if (!CUDNN) {
-            // r*h in the quarter-padded layout (one thread per unit), then phase 2 on it
-            if (tid < H) rhs[(tid >> 5) * GRU_QPAD + (tid & 31)] = rs[tid] * hs[(tid >> 5) * GRU_QPAD + (tid & 31)];
+            // the candidate's recurrent part does not depend on r: same pass over h
+            c = tanhf_(xc + r * (gru_sum4(gru_dot32(hq, wc)) + bch));
+        } else {
+            if (kq == 0) rhs[slot] = r * hreg;
             __syncthreads();
-            const float* he = rhs + (ke >> 1) * GRU_QPAD + (ke & 1) * 16;
-            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; i += 4) {
-                const float4 hv = *reinterpret_cast<const float4*>(he + i);
-                p0 = fmaf(hv.x, wc[i + 0], p0);
-                p1 = fmaf(hv.y, wc[i + 1], p1);
-                p2 = fmaf(hv.z, wc[i + 2], p2);
-                p3 = fmaf(hv.w, wc[i + 3], p3);
-            }
-            pc = gru_sum8((p0 + p1) + (p2 + p3));
+            c = tanhf_(xc + gru_sum4(gru_dot32(rhs + kq * GRU_QPAD, wc)));
         }
-        if (ke == 0) {
-            const float c = CUDNN ? tanhf_(xc + rs[cc] * (pc + bch)) : tanhf_(xc + pc);
-            const float u = us[cc];
-            const float hn = u * hreg + (1.0f - u) * c;
-            hreg = hn;
-            ob[(size_t)t * 2 * H + cc] = hn;
+        hreg = u * hreg + (1.0f - u) * c;
+        if (kq == 0) {
+            ob[(size_t)t * 2 * H] = hreg;
+            hs[(s + 1) & 1][slot] = hreg;
         }
-        xg = xg_n;
-        xc = xc_n;
-        // every read of hs of this step happened before the barrier(s) above: publish the new state
-        if (ke == 0) hs[(cc >> 5) * GRU_QPAD + (cc & 31)] = hreg;
+        xr = xr_n; xu = xu_n; xc = xc_n;
         __syncthreads();
     }
 }
