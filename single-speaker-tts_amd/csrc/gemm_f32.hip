@@ -99,13 +99,58 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
     // in L1 / L2) instead of Cin/BK tiles apart.  The weight tile follows the same map.
     const int ktaps = K / g.Cin;
     const bool tap_inner = ktaps > 1 && (g.Cin % BK) == 0;
-    auto load_tile = [&](int kt) {
-        int kbase = kt;
+    // Whenever all 32 k of a tile share one tap (dense layers: always tap 0; tap_inner convolutions: by construction)
+    // the tile's (tap, first k) pair is wave-uniform and advances by a compare per tile -- no integer division in the
+    // loop, and the tap masks of a row are three bits computed once.  Only a convolution whose channel count is no
+    // multiple of the tile depth (the post-net bank, 80 channels) takes the per-lane division.
+    const bool uniform_tap = ktaps == 1 || tap_inner;
+    int cur_tap = 0, cur_kb = 0;   // of the NEXT tile load_tile is asked for (tiles are requested in order)
+    {
+        const int k_first = g.kt1 > 0 ? g.kt0 : 0;
         if (tap_inner) {
-            const int it = kt / BK;
-            kbase = (it % ktaps) * g.Cin + (it / ktaps) * BK;
+            const int it = k_first / BK;
+            cur_tap = it % ktaps;
+            cur_kb = cur_tap * g.Cin + (it / ktaps) * BK;
+        } else {
+            cur_kb = k_first;
         }
-        const int kk = kbase + 4 * kq;
+    }
+    unsigned tapmask[4];   // bit t: tap t of this row lies inside the sequence (taps 0..2; wider kernels take the general path)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned m = 0;
+        for (int t = 0; t < 3; ++t) {
+            const int ts = a_t[i] - g.padl + t;
+            if (a_ok[i] && ts >= 0 && ts < g.T) m |= 1u << t;
+            if (a_ok[i] && ts >= 0 && ts + 1 < g.T) m |= 1u << (4 + t);   // ... and the row after it (max-pool loader)
+        }
+        tapmask[i] = m;
+    }
+    const bool fast = uniform_tap && ktaps <= 3;
+    auto load_tile = [&](int kt) {
+        if (fast) {
+            const int kk = cur_kb + 4 * kq;
+            const bool kin = kk < K;
+            const int tap = cur_tap;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = kin && ((tapmask[i] >> tap) & 1u);
+                const unsigned off = ok ? (unsigned)(a_off[i] + kk) * 4u : 0xFFFFFFFFu;
+                float4 v = buf4(a_rs, off);
+                if (g.pool) v = max4(v, buf4(a_rs, (kin && ((tapmask[i] >> (4 + tap)) & 1u)) ? off + (unsigned)g.lda * 4u : off));
+                ra[i] = v;
+                rb[i] = buf4(b_rs, (b_ok[i] && kin) ? (unsigned)(b_off[i] + kk) * 4u : 0xFFFFFFFFu);
+            }
+            // advance to the next tile: tap inner, channel chunk outer
+            if (tap_inner) {
+                if (++cur_tap == ktaps) { cur_tap = 0; cur_kb += BK - (ktaps - 1) * g.Cin; }
+                else cur_kb += g.Cin;
+            } else {
+                cur_kb += BK;
+            }
+            return;
+        }
+        const int kk = kt + 4 * kq;
         const bool kin = kk < K;
         const int tap = kk / g.Cin;  // all four floats share the tap (Cin % 4 == 0)
 #pragma unroll
@@ -143,14 +188,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
         store_tile();
         __syncthreads();
         if (kt + BK < k_end) load_tile(kt + BK);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 a[2], b[2];
+        // Two register sets for the LDS fragments: the ds_read_b128 of MFMA step q + 1 are requested before the 16 MFMAs
+        // of step q are issued, so a step never starts by waiting for LDS (hipcc leaves part of that latency exposed
+        // when the steps are written as one loop: 105 -> 119 TFLOP/s on the 64000 x 256 x 3072 shape in
+        // tools/gemm_microbench.hip).
+        auto frag = [&](int q, float4 (&a)[2], float4 (&b)[2]) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 a[t] = *reinterpret_cast<const float4*>(&As[(wm * 64 + t * 32 + li) * LDS_LD + 8 * q + 4 * lh]);
                 b[t] = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + t * 32 + li) * LDS_LD + 8 * q + 4 * lh]);
             }
+        };
+        auto mma = [&](const float4 (&a)[2], const float4 (&b)[2]) {
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -160,6 +209,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
                 }
+        };
+        {
+            float4 a0[2], b0[2], a1[2], b1[2];
+            frag(0, a0, b0);
+            frag(1, a1, b1);
+            mma(a0, b0);
+            frag(2, a0, b0);
+            mma(a1, b1);
+            frag(3, a1, b1);
+            mma(a0, b0);
+            mma(a1, b1);
         }
         __syncthreads();
     }

@@ -43,11 +43,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
         a_row[i] = A + (size_t)min(m0 + row, M - 1) * K;
         b_row[i] = Wt + (size_t)min(n0 + row, N - 1) * K;
     }
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (int)0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt), 0, (int)0xFFFFFFF0u, 0x00020000);
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            ra[i] = ld4(a_row[i & 3] + kt + 4 * kq + 32 * (i >> 2));
-            rb[i] = ld4(b_row[i & 3] + kt + 4 * kq + 32 * (i >> 2));
+            if (V == 9) {   // what gemm_f32.hip does: raw buffer loads, 32-bit byte offsets
+                const unsigned oa = (unsigned)((a_row[i & 3] - A) + kt + 4 * kq + 32 * (i >> 2)) * 4u;
+                const unsigned ob = (unsigned)((b_row[i & 3] - Wt) + kt + 4 * kq + 32 * (i >> 2)) * 4u;
+                ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)oa, 0, 0));
+                rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, (int)ob, 0, 0));
+            } else {
+                ra[i] = ld4(a_row[i & 3] + kt + 4 * kq + 32 * (i >> 2));
+                rb[i] = ld4(b_row[i & 3] + kt + 4 * kq + 32 * (i >> 2));
+            }
         }
     };
     auto store_tile = [&](int buf) {
@@ -82,7 +92,45 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
             }
     };
-    if (V >= 4) {   // ablations (wrong results): 4 = no global loads in the loop, 5 = also no LDS stores, 6 = also no barriers
+    auto frag = [&](int buf, int q, float4 (&a)[2], float4 (&b)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            a[t] = *reinterpret_cast<const float4*>(&As[buf][(wm * 64 + t * 32 + li) * LDS_LD + 8 * q + 4 * lh]);
+            b[t] = *reinterpret_cast<const float4*>(&Bs[buf][(wn * 64 + t * 32 + li) * LDS_LD + 8 * q + 4 * lh]);
+        }
+    };
+    auto mma = [&](const float4 (&a)[2], const float4 (&b)[2]) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
+            }
+    };
+    if (V == 7 || V == 8 || V == 9) {   // LDS fragments of step q + 1 requested before the MFMAs of step q (two register sets)
+        load_tile(0);
+        if (V == 8) { store_tile(0); __syncthreads(); }
+        for (int kt = 0; kt < K; kt += BK) {
+            if (V == 7 || V == 9) {
+                store_tile(0);
+                __syncthreads();
+                if (kt + BK < K) load_tile(kt + BK);
+            }
+            float4 a0[2], b0[2], a1[2], b1[2];
+            frag(0, 0, a0, b0);
+            frag(0, 1, a1, b1);
+            mma(a0, b0);
+            frag(0, 2, a0, b0);
+            mma(a1, b1);
+            frag(0, 3, a1, b1);
+            mma(a0, b0);
+            mma(a1, b1);
+            if (V == 7 || V == 9) __syncthreads();
+        }
+    } else if (V >= 4) {   // ablations (wrong results): 4 = no global loads in the loop, 5 = also no LDS stores, 6 = also no barriers
         load_tile(0);
         store_tile(0);
         __syncthreads();
@@ -179,9 +227,15 @@ int main() {
         std::vector<float> c0, c1;
         run<0>(A, Wt, C, M, N, K, &c0);
         run<1>(A, Wt, C, M, N, K, &c1);
-        run<4>(A, Wt, C, M, N, K, &c1);
-        run<5>(A, Wt, C, M, N, K, &c1);
         run<6>(A, Wt, C, M, N, K, &c1);
+        run<8>(A, Wt, C, M, N, K, &c1);
+        run<7>(A, Wt, C, M, N, K, &c1);
+        run<9>(A, Wt, C, M, N, K, &c1);
+        {
+            double md7 = 0;
+            for (size_t i = 0; i < c0.size(); i += 97) md7 = fmax(md7, fabs((double)c0[i] - c1[i]));
+            printf("   max |V0 - V7| = %g\n", md7);
+        }
         double md = 0;
         for (size_t i = 0; i < c0.size(); i += 97) md = fmax(md, fabs((double)c0[i] - c1[i]));
         printf("   max |V0 - V1| = %g\n", md);
