@@ -881,7 +881,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     // one zeroed work counter per launch (the persistent workgroups draw their item ids from it)
     WS(h, "gl.counters", unsigned, (size_t)n_iter + 1, counters);
     HIPCHK(h, hipMemsetAsync(counters, 0, ((size_t)n_iter + 1) * sizeof(unsigned), h->stream));
-    HIPCHK(h, launch_phase_init(h->stream, init_ft, seed, mag_int, ph0, B, F, T, FP));
+    HIPCHK(h, launch_phase_init(h->stream, init_ft, seed, ph0, B, F, T, FP));
     float2* cur = ph0;
     float2* nxt = ph1;
     // One launch for all iterations when nothing per-iteration is asked for (gl_iter_kernel, FUSED); `free_cus`

@@ -55,8 +55,7 @@ bool gl_fused_supported(const GlParams& p);
 hipError_t launch_gl_mse_reduce(hipStream_t s, const float* partial, int B, int nchunks, float denom, float* mse);
 hipError_t launch_mag_ft_to_tf(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP);
 hipError_t launch_tf_to_ft(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP);
-hipError_t launch_phase_init(hipStream_t s, const float* init_ft, uint64_t seed, const float* mag_tf, void* out, int B,
-                             int F, int T, int FP);
+hipError_t launch_phase_init(hipStream_t s, const float* init_ft, uint64_t seed, void* out, int B, int F, int T, int FP);
 hipError_t launch_denorm_power(hipStream_t s, const float* lin, float* mag, size_t rows, int F, int FP,
                                float ref_db, float max_db, float power, int* below_flag);
 hipError_t launch_peak_normalize(hipStream_t s, float* wav, int B, int n);

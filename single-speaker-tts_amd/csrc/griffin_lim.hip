@@ -1328,8 +1328,10 @@ __device__ __forceinline__ float u01(uint64_t seed, uint64_t idx) {
     return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
-// angles = exp(2 pi i u): u from init (B,F,T) reference layout or from the seed; out (B,T,FP)
-__global__ void phase_init_kernel(const float* init_ft, uint64_t seed, const float* mag_tf, cf* out, int F, int T, int FP) {
+// angles = exp(2 pi i u): u from init (B,F,T) reference layout or from the seed; out (B,T,FP) phasor codes (no magnitudes
+// needed: the state is the phasor alone).  Running it on a side stream beside the post-net was tried and cost 1.3 ms
+// per step instead of saving 0.17: a third busy stream slows the Griffin-Lim launches of the main one.
+__global__ void phase_init_kernel(const float* init_ft, uint64_t seed, unsigned* out, int F, int T, int FP) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const int f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
@@ -1349,18 +1351,13 @@ __global__ void phase_init_kernel(const float* init_ft, uint64_t seed, const flo
         if (t < T && f < FP) {
             float sn, cs;
             sincospif(2.0f * tile[tx][i], &sn, &cs);
-            const size_t o = ((size_t)b * T + t) * FP + f;
-            const float m = f < F ? fabsf(mag_tf[o]) : 0.f;
-            (void)m;
-            reinterpret_cast<unsigned*>(out)[o] = gl_pack_phasor(cmk(cs, sn), 1.0f);   // phasor of exp(2 pi i u)
+            out[((size_t)b * T + t) * FP + f] = gl_pack_phasor(cmk(cs, sn), 1.0f);   // phasor of exp(2 pi i u)
         }
     }
 }
-hipError_t launch_phase_init(hipStream_t s, const float* init_ft, uint64_t seed, const float* mag_tf, void* out, int B,
-                             int F, int T, int FP) {
+hipError_t launch_phase_init(hipStream_t s, const float* init_ft, uint64_t seed, void* out, int B, int F, int T, int FP) {
     dim3 grid((T + 31) / 32, (FP + 31) / 32, B);
-    hipLaunchKernelGGL(phase_init_kernel, grid, dim3(32, 8), 0, s, init_ft, seed, mag_tf, reinterpret_cast<cf*>(out),
-                       F, T, FP);
+    hipLaunchKernelGGL(phase_init_kernel, grid, dim3(32, 8), 0, s, init_ft, seed, reinterpret_cast<unsigned*>(out), F, T, FP);
     return hipGetLastError();
 }
 
