@@ -9,10 +9,11 @@
 //   librosa.output.write_wav(norm=True)    reference audio/io.py:53 (peak normalisation)
 //   linear_scale_spectrogram / mel         reference audio/features.py:5-86, 116-145
 //
-// Internal layout: frame-major.  mag [B][T][FP] float and a ping-pong pair of float2 spectrum
-// estimates X = |S| e^{i phi} [B][T][FP], FP = 1028 (F = 1025 padded so that every row is 16-byte
-// aligned).  One frame's spectrum is a contiguous row, which is also how the network produces it
-// (B,T,F): the reference's (F,T) transpose exists only at the C ABI.
+// Internal layout: frame-major.  mag [B][T][FP] float and a ping-pong pair of 32-bit unit-phasor codes
+// e^{i phi} [B][T][FP] (gl_pack_phasor; the estimate X = |S| e^{i phi} is rebuilt from mag where it is
+// consumed), FP = 1028 (F = 1025 padded so that every row is 16-byte aligned).  One frame's spectrum is a
+// contiguous row, which is also how the network produces it (B,T,F): the reference's (F,T) transpose
+// exists only at the C ABI.
 //
 // One Griffin-Lim iteration is ONE kernel of PERSISTENT workgroups (512 threads, one per compute unit) that
 // draw work items from a global counter.  An item is a RUN of consecutive frames of one utterance, walked
@@ -25,16 +26,16 @@
 //   hazard (wave w round r vs wave w+1 rounds < r - (R - ncol)) is ordered by per-wave progress flags in
 //   LDS, so there are no atomics, no workgroup barriers inside the phase, and the summation order of every
 //   sample is fixed (bit-reproducible).  Round 0 stores instead of accumulating, so the buffer is never
-//   cleared.  The next round's spectrum row is prefetched into registers (bins k = lane + 64 j, read once)
-//   while the current frame's FFT runs; the mirrored bins 1024 - k of the real-FFT split pass come through
+//   cleared.  The next round's row (phasor codes and magnitudes of bins k = lane + 64 j, read once) is
+//   prefetched into registers while the current frame's FFT runs; the mirrored bins 1024 - k of the real-FFT split pass come through
 //   the wave's exchange buffer (mirror_bins), not from a second pass over the row.  The window-sum-square
 //   normalisation of librosa's istft is folded into the synthesis window (a per-sample table only for the
 //   frames at the utterance ends), so the signal is final when the overlap-add is.
 //   Phase B forward-FFTs the C owned frames straight from LDS (reflect padding at the utterance edges is an
 //   index map; frames handed out dynamically so both waves of a SIMD finish together) and stores
-//   the next estimate X = |S| * unit phasor.
-// The time-domain signal never goes to HBM; per bin and iteration the algorithmic traffic is
-// 8 B X in + 4 B |S| + 8 B X out.  The cut of an utterance into runs (as many as divide evenly over the
+//   the code of the new unit phasor (the magnitudes are not read in this phase).
+// The time-domain signal never goes to HBM; per bin and iteration the ALGORITHMIC traffic (what the
+// roofline is priced on) is 8 B X in + 4 B |S| + 8 B X out; what really moves is 4 B code + 4 B |S| in, 4 B code out.  The cut of an utterance into runs (as many as divide evenly over the
 // compute units actually available) is planned on the host: gl_plan_items.
 //
 // FFT: real 2048-point transforms as 1024-point complex FFTs with a split/merge pass.  One wave
