@@ -5,6 +5,58 @@
 #include <vector>
 using namespace tts;
 
+namespace tts {
+// Experiment (not faster: 1.77 against 1.61 us per FFT and wave at two waves per SIMD, equal at one -- the FFT is bound
+// by VALU issue, ~290 instructions at one per 4.1 cycles and SIMD, not by its LDS round trip):
+// Two independent FFTs of one wave, staggered through the wave's ONE exchange buffer: while the LDS transpose of the
+// first is in flight the wave issues the radix-4 stage of the second, and the last radix-16 stage of the first covers
+// the transpose of the second (a wave has only one other wave on its SIMD to hide a round trip behind).
+template <typename TW>
+__device__ __forceinline__ void fft1024_x2(cf (&v0)[16], cf (&v1)[16], cf* ex, const TW& tw, int lane) {
+    fft16(v0);
+    fft16(v1);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) { v0[k2] = cmul(v0[k2], tw.a_at(k2)); v1[k2] = cmul(v1[k2], tw.a_at(k2)); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        swap_bit4(v0[4 * i + 0], v0[4 * i + 1]); swap_bit4(v1[4 * i + 0], v1[4 * i + 1]);
+        swap_bit4(v0[4 * i + 2], v0[4 * i + 3]); swap_bit4(v1[4 * i + 2], v1[4 * i + 3]);
+        swap_bit5(v0[4 * i + 0], v0[4 * i + 2]); swap_bit5(v1[4 * i + 0], v1[4 * i + 2]);
+        swap_bit5(v0[4 * i + 1], v0[4 * i + 3]); swap_bit5(v1[4 * i + 1], v1[4 * i + 3]);
+    }
+    const int a = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r4(v0[4 * i], v0[4 * i + 1], v0[4 * i + 2], v0[4 * i + 3]);
+#pragma unroll
+        for (int d = 1; d < 4; ++d) v0[4 * i + d] = cmul(v0[4 * i + d], tw.b[d - 1]);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) ex[(16 * d + kq + 4 * i) * E2S + a] = v0[4 * i + d];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int x = 0; x < 16; ++x) v0[x] = ex[lane * E2S + x];   // in flight during the radix-4 stage of the second
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r4(v1[4 * i], v1[4 * i + 1], v1[4 * i + 2], v1[4 * i + 3]);
+#pragma unroll
+        for (int d = 1; d < 4; ++d) v1[4 * i + d] = cmul(v1[4 * i + d], tw.b[d - 1]);
+    }
+    wave_lds_sync();   // the reads of the first are complete: the buffer is free
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) ex[(16 * d + kq + 4 * i) * E2S + a] = v1[4 * i + d];
+    wave_lds_sync();
+#pragma unroll
+    for (int x = 0; x < 16; ++x) v1[x] = ex[lane * E2S + x];   // in flight during the last stage of the first
+    fft16(v0);
+    wave_lds_sync();
+    fft16(v1);
+}
+
+}  // namespace tts
+
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void fft_loop_kernel(const cf* tw1024, float* out, int iters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -26,6 +78,51 @@ __global__ __launch_bounds__(NW * 64) void fft_loop_kernel(const cf* tw1024, flo
     float s = 0.f;
     for (int j = 0; j < 16; ++j) s += v[j].x + v[j].y;
     out[blockIdx.x * NW * 64 + tid] = s;
+}
+
+// register-resident twiddles (what gl_iter_kernel uses), one FFT at a time or two staggered (fft1024_x2)
+template <int NW, int X2>
+__global__ __launch_bounds__(NW * 64) void fft_reg_kernel(const cf* tw1024, float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf* ex_all = reinterpret_cast<cf*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cf* ex = ex_all + wave * EX_CPLX;
+    FftTwReg tw;
+    for (int k2 = 1; k2 < 16; ++k2) tw.a[k2 - 1] = tw1024[(lane * k2) & 1023];
+    for (int d = 1; d < 4; ++d) tw.b[d - 1] = tw1024[16 * (lane & 15) * d];
+    cf v[16], w[16];
+    for (int j = 0; j < 16; ++j) { v[j] = cmk(0.001f * (lane + j), 0.002f * (lane - j)); w[j] = cmk(0.003f * (lane - j), 0.001f * (lane + 2 * j)); }
+    for (int it = 0; it < iters; ++it) {
+        if (X2) {
+            fft1024_x2(v, w, ex, tw, lane);
+        } else {
+            fft1024(v, ex, tw, lane);
+            fft1024(w, ex, tw, lane);
+        }
+        for (int j = 0; j < 16; ++j) { v[j] = cscale(v[j], 1.0f / 32.0f); w[j] = cscale(w[j], 1.0f / 32.0f); }
+    }
+    float s = 0.f;
+    for (int j = 0; j < 16; ++j) s += v[j].x + v[j].y + w[j].x - w[j].y;
+    out[blockIdx.x * NW * 64 + tid] = s;
+}
+template <int NW, int X2>
+void run_reg(const cf* tw, float* out, int blocks, int iters, int extra_lds) {
+    const size_t lds = (size_t)(NW * EX_CPLX) * sizeof(cf) + extra_lds;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_reg_kernel<NW, X2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL((fft_reg_kernel<NW, X2>), dim3(blocks), dim3(NW * 64), lds, 0, tw, out, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    hipLaunchKernelGGL((fft_reg_kernel<NW, X2>), dim3(blocks), dim3(NW * 64), lds, 0, tw, out, iters);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    float h0 = 0;
+    hipMemcpy(&h0, out + 5, sizeof(float), hipMemcpyDeviceToHost);
+    printf("register twiddles NW=%d %s: %.3f us per FFT per wave (checksum %g), err=%s\n", NW, X2 ? "two staggered" : "one at a time",
+           ms * 1e3 / iters / 2, h0, hipGetErrorString(hipGetLastError()));
 }
 
 template <int NW>
@@ -50,13 +147,17 @@ int main() {
     std::vector<cf> t1(1024);
     for (int k = 0; k < 1024; ++k) {
         const double a = -2.0 * M_PI * k / 1024.0;
-        t1[k] = make_float2((float)cos(a), (float)sin(a));
+        t1[k] = (cf){(float)cos(a), (float)sin(a)};
     }
     cf* tw; float* out;
     hipMalloc(&tw, 1024 * sizeof(cf));
     hipMalloc(&out, 4096 * 1024 * sizeof(float));
     hipMemcpy(tw, t1.data(), 1024 * sizeof(cf), hipMemcpyHostToDevice);
     const int iters = 200;
+    run_reg<8, 0>(tw, out, 256, iters, 80 * 1024);
+    run_reg<8, 1>(tw, out, 256, iters, 80 * 1024);
+    run_reg<4, 0>(tw, out, 256, iters, 110 * 1024);
+    run_reg<4, 1>(tw, out, 256, iters, 110 * 1024);
     run<4>(tw, out, 256, iters, 100 * 1024);   // 1 WG/CU, 1 wave per SIMD
     run<8>(tw, out, 256, iters, 60 * 1024);    // 1 WG/CU, 2 waves per SIMD
     run<8>(tw, out, 512, iters, 60 * 1024);    // 2 rounds of WGs
