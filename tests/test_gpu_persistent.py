@@ -22,9 +22,10 @@ def persistent(engine):
     engine.set_option('persistent_decoder', 1)
 
 
-@pytest.mark.parametrize('B,Ts,S', [(1, 5, 3), (3, 37, 10), (17, 150, 6), (33, 64, 4)])
+@pytest.mark.parametrize('B,Ts,S', [(1, 5, 3), (3, 37, 10), (17, 150, 6), (33, 64, 4), (16, 1, 3), (2, 401, 3), (80, 33, 3)])
 def test_persistent_decoder_vs_oracle(persistent, hparams, weights64, B, Ts, S):
-    """Row counts that are no multiple of the 16-row cluster tile, one to three clusters, short and long memories."""
+    """Row counts that are no multiple of the 16-row cluster tile, one to five clusters (80 utterances = 40 workgroups),
+    memories of 1 and of 401 positions (the score / context loops run 1 and 13 passes)."""
     rng = np.random.default_rng(200 + B)
     memory = (rng.standard_normal((B, Ts, 256)) * 1.5).astype(np.float32)
     ref_mel, ref_al = O.decoder(memory.astype(np.float64), weights64, hparams, n_steps=S)
