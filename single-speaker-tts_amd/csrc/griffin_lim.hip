@@ -320,21 +320,26 @@ __device__ __forceinline__ void gl_stream_store(cf* p, cf v) { __builtin_nontemp
 // The state between iterations is the UNIT PHASOR of every bin, 32 bits each (round 2; the estimate X = |S| e^{i phi} it
 // stands for is rebuilt in phase A from |S|, which phase A reads anyway from then on and phase B no longer does:
 // 4 B phasor + 4 B |S| in, 4 B phasor out = 12 instead of 20 bytes per bin and iteration through a memory path that
-// gives a compute unit ~21 GB/s however many waves ask, tools/stream_microbench.hip).  Code: the component of
-// SMALLER magnitude as a float (|.| <= 0.7072) whose two lowest mantissa bits say which component it is (bit 1: the
-// real part) and carry the sign of the other one (bit 0); the other one is sqrt(1 - small^2) >= 0.7071, well
-// conditioned.  Worst-case error of a decoded component 3e-7 (two dropped mantissa bits of the small one plus the fp32
-// rounding of x / |x|; tests/test_host_logic.py::test_phasor_code_emulation), the size of the rounding in the old
-// x * rsq(|x|^2) * |S| product.
-__device__ __forceinline__ unsigned gl_pack_phasor(cf x, float rs) {   // x: any scale, rs = 1 / |x|
+// gives a compute unit ~21 GB/s however many waves ask, tools/stream_microbench.hip).  Code: r = small / |big|, the
+// component of SMALLER magnitude over the magnitude of the other (|r| <= 1, a float), whose two lowest mantissa bits
+// say which component the small one is (bit 1: the real part) and carry the sign of the big one (bit 0).  Decoding:
+// |big| = rsq(1 + r^2) >= 0.707, small = r |big| -- well conditioned everywhere.  No normalisation by |x| is needed
+// to encode (the ratio does not see the scale), and the zero bin needs no special path: 0 / max(0, tiny) = 0 decodes
+// to (1, 0), numpy's exp(1j * angle(0)) (and -0.0 + 0j to (-1, 0), also numpy's).  Worst-case error of a decoded
+// component 3e-7 (two dropped mantissa bits of r, one v_rcp_f32, one v_rsq_f32; tests/test_host_logic.py::
+// test_phasor_code_emulation), the size of the rounding in the x * rsq(|x|^2) * |S| product it replaces.
+__device__ __forceinline__ unsigned gl_pack_phasor(cf x) {   // x: any scale
     const bool sw = fabsf(x.x) < fabsf(x.y);
-    const float small = (sw ? x.x : x.y) * rs;
+    const float small = sw ? x.x : x.y;
     const float big = sw ? x.y : x.x;
-    return (__float_as_uint(small) & ~3u) | (sw ? 2u : 0u) | (__float_as_uint(big) >> 31);
+    const float r = small * __builtin_amdgcn_rcpf(fmaxf(fabsf(big), 1.0e-30f));
+    return (__float_as_uint(r) & ~3u) | (sw ? 2u : 0u) | (__float_as_uint(big) >> 31);
 }
 __device__ __forceinline__ cf gl_unpack_phasor(unsigned c, float mag) {   // -> mag * phasor
-    const float sm = __uint_as_float(c & ~3u);
-    const float bg = __uint_as_float(__float_as_uint(__builtin_amdgcn_sqrtf(fmaf(-sm, sm, 1.0f))) | (c << 31));
+    const float r = __uint_as_float(c & ~3u);
+    const float ba = __builtin_amdgcn_rsqf(fmaf(r, r, 1.0f));            // |big|
+    const float sm = r * ba;
+    const float bg = __uint_as_float(__float_as_uint(ba) | (c << 31));
     const bool sw = (c & 2u) != 0u;
     return cmk((sw ? sm : bg) * mag, (sw ? bg : sm) * mag);
 }
@@ -744,11 +749,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 unsigned* orow = pob + (size_t)t * p.FP;
                 // (FUSED) a frame within `halo` of the run's ends is a neighbour's halo frame
                 const bool shared_frame = FUSED && (t < run_t0 + halo || t >= run_t0 + run_len - halo);
-                // next estimate: target magnitude, new phase.  Fast path: x * (rsq(|x|^2) * |S|), valid
-                // while |x|^2 stays well inside the float range; the min / max of |x|^2 over the lane's
-                // bins are tracked and the (practically never taken) exact path below redoes the frame
-                // otherwise.
-                float s_min = 3.0e38f, s_max = 0.f;
+                // next estimate: the phase of every bin, as its code (any scale, zero bins included: gl_pack_phasor)
                 cf zmr[16];   // all mirrored bins first: one LDS latency for the pass instead of one per bin
 #pragma unroll
                 for (int c = 0; c < 16; ++c) zmr[c] = ex[(MH - (lane + 64 * c)) & (MH - 1)];
@@ -760,27 +761,10 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                     const cf e = cadd_conj(zk, zmr[c]);
                     const cf o = cmul(csub_conj(zk, zmr[c]), twr[c]);
                     const cf x = cadd_mi(e, o);
-                    const float s = fmaf(x.x, x.x, x.y * x.y);
-                    // raw v_rsq_f32: s is range-checked below
-                    gl_c_store<FUSED>(orow + k, gl_pack_phasor(x, __builtin_amdgcn_rsqf(s)), shared_frame);
-                    s_min = fminf(s_min, s);
-                    s_max = fmaxf(s_max, s);
+                    gl_c_store<FUSED>(orow + k, gl_pack_phasor(x), shared_frame);
                     if (MSE) {
-                        const float d = mg[c] - (float)MH * sqrtf(s);   // x = X / MH
+                        const float d = mg[c] - (float)MH * sqrtf(fmaf(x.x, x.x, x.y * x.y));   // x = X / MH
                         mse_acc += d * d;
-                    }
-                }
-                if (__builtin_expect(__any(!(s_min > 1.0e-30f && s_max < 1.0e30f)), 0)) {
-                    // exact path: zero / tiny / huge bins (angle(0) = 0, range-safe normalisation)
-#pragma unroll 1
-                    for (int c = 0; c < 16; ++c) {
-                        const int k = lane + 64 * c;
-                        const cf zk = ex[k];
-                        const cf zr = ex[(MH - k) & (MH - 1)];
-                        const cf e = cadd_conj(zk, zr);
-                        const cf o = cmul(csub_conj(zk, zr), reinterpret_cast<const cf*>(p.tw2048)[k]);
-                        const cf x = cadd_mi(e, o);
-                        gl_c_store<FUSED>(orow + k, gl_pack_phasor(unit_phasor(x), 1.0f), shared_frame);
                     }
                 }
                 if (lane == 0) {
@@ -1352,7 +1336,7 @@ __global__ void phase_init_kernel(const float* init_ft, uint64_t seed, unsigned*
         if (t < T && f < FP) {
             float sn, cs;
             sincospif(2.0f * tile[tx][i], &sn, &cs);
-            out[((size_t)b * T + t) * FP + f] = gl_pack_phasor(cmk(cs, sn), 1.0f);   // phasor of exp(2 pi i u)
+            out[((size_t)b * T + t) * FP + f] = gl_pack_phasor(cmk(cs, sn));   // phasor of exp(2 pi i u)
         }
     }
 }

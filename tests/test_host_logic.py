@@ -278,33 +278,40 @@ def test_overlap_add_round_schedule_is_race_free(C, ncol, cont):
 
 def test_phasor_code_emulation():
     """The Griffin-Lim state between iterations is a 32-bit code per bin (griffin_lim.hip, gl_pack_phasor /
-    gl_unpack_phasor): the component of smaller magnitude as a float whose two lowest mantissa bits say which one it
-    is and carry the sign of the other.  numpy emulation of exactly those bit operations: the decoded phasor is within
-    4e-7 of the exact unit phasor for random angles, the axes, the diagonals and values next to them."""
+    gl_unpack_phasor): r = small / |big| (the component of smaller magnitude over the magnitude of the other) as a
+    float whose two lowest mantissa bits say which component the small one is and carry the sign of the big one.
+    numpy emulation of exactly those operations: the decoded phasor is within 4e-7 of the exact unit phasor for random
+    angles at any scale, on the axes, the diagonals and next to them, and the zero bin decodes to (1, 0)."""
     rng = np.random.default_rng(5)
     ang = np.concatenate([rng.uniform(-np.pi, np.pi, 200000), np.arange(-8, 9) * (np.pi / 4),
                           np.arange(-8, 9) * (np.pi / 4) + 1e-6, np.arange(-8, 9) * (np.pi / 4) - 3e-4])
     scale = np.exp(rng.uniform(-20, 20, ang.size))                 # the FFT output is not normalised
     x = (np.cos(ang) * scale).astype(np.float32)
     y = (np.sin(ang) * scale).astype(np.float32)
-    rs = (1.0 / np.sqrt(x.astype(np.float64) ** 2 + y.astype(np.float64) ** 2)).astype(np.float32)
-    # pack
-    sw = np.abs(x) < np.abs(y)
-    small = (np.where(sw, x, y) * rs).astype(np.float32)
-    big = np.where(sw, y, x)
-    code = (small.view(np.uint32) & ~np.uint32(3)) | np.where(sw, np.uint32(2), np.uint32(0)) | (big.view(np.uint32) >> np.uint32(31))
-    # unpack (mag = 1)
-    sm = (code & ~np.uint32(3)).view(np.float32)
-    bg = np.sqrt((np.float32(1.0) - sm * sm).astype(np.float32)).astype(np.float32)
-    bg = (bg.view(np.uint32) | (code << np.uint32(31))).view(np.float32)
-    swd = (code & np.uint32(2)) != 0
-    ux, uy = np.where(swd, sm, bg), np.where(swd, bg, sm)
+
+    def pack(x, y):
+        sw = np.abs(x) < np.abs(y)
+        small, big = np.where(sw, x, y), np.where(sw, y, x)
+        r = (small * (np.float32(1.0) / np.maximum(np.abs(big), np.float32(1e-30)))).astype(np.float32)
+        return (r.view(np.uint32) & ~np.uint32(3)) | np.where(sw, np.uint32(2), np.uint32(0)) | (big.view(np.uint32) >> np.uint32(31))
+
+    def unpack(code):
+        r = (code & ~np.uint32(3)).view(np.float32)
+        ba = (np.float32(1.0) / np.sqrt((r * r + np.float32(1.0)).astype(np.float32))).astype(np.float32)
+        sm = (r * ba).astype(np.float32)
+        bg = (ba.view(np.uint32) | (code << np.uint32(31))).view(np.float32)
+        swd = (code & np.uint32(2)) != 0
+        return np.where(swd, sm, bg), np.where(swd, bg, sm)
+
+    code = pack(x, y)
+    ux, uy = unpack(code)
     err = np.maximum(np.abs(ux - np.cos(ang)), np.abs(uy - np.sin(ang)))
-    assert err.max() < 4e-7, err.max()                            # 2^-22 from the two dropped bits + fp32 rounding of x, y, 1/|x|
-    assert np.all(np.abs(sm) <= 0.70711)                           # the stored component is the small one
-    assert np.abs(ux * ux + uy * uy - 1.0).max() < 3e-7
-    # the two codes the kernel writes without packing: Nyquist / DC phasors (1, 0) and (-1, 0)
-    for c, want in ((np.uint32(0), (1.0, 0.0)), (np.uint32(1), (-1.0, 0.0))):
-        s0 = (np.array([c]) & ~np.uint32(3)).view(np.float32)
-        b0 = (np.sqrt(np.float32(1.0) - s0 * s0).astype(np.float32).view(np.uint32) | (np.array([c]) << np.uint32(31))).view(np.float32)
-        assert (float(b0[0]), float(s0[0])) == want
+    assert err.max() < 4e-7, err.max()
+    assert np.all(np.abs((code & ~np.uint32(3)).view(np.float32)) <= 1.0)          # the stored ratio is small / |big|
+    assert np.abs(ux * ux + uy * uy - 1.0).max() < 4e-7
+    # zero bins (angle(0) = 0 -> 1 + 0j, reference audio/synthesis.py:109) and the codes the kernel writes directly
+    z = np.zeros(1, np.float32)
+    assert [float(v[0]) for v in unpack(pack(z, z))] == [1.0, 0.0]
+    assert [float(v[0]) for v in unpack(pack(-z, z))] == [-1.0, 0.0]               # np.angle(-0.0 + 0j) = pi
+    for c, want in ((np.uint32(0), [1.0, 0.0]), (np.uint32(1), [-1.0, 0.0])):      # Nyquist / DC phasors
+        assert [float(v[0]) for v in unpack(np.array([c], np.uint32))] == want
