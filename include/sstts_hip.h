@@ -97,8 +97,9 @@ int tts_set_stream(tts_handle_t h, void* hip_stream);
 /* Options: "use_graph" (decoder loop replayed from a hipGraph, default 1), "profile" (record
  * per-stage HIP events, default 0), "pipeline" (default 1: tts_synthesize runs the encoder and
  * the decoder loop of a call on a second stream so that they overlap the Griffin-Lim iterations of
- * the PREVIOUS call still in flight; only while the library owns its stream, and inputs must be
- * complete when the call is made), "reserve_cus" (default 32: compute units kept free of
+ * the PREVIOUS call still in flight; inputs must be complete when the call is made, which is why 1 applies
+ * only while the library owns its stream -- 2 pipelines on a stream adopted with tts_set_stream as well, the
+ * caller vouching for its inputs), "reserve_cus" (default 32: compute units kept free of
  * Griffin-Lim workgroups for that second stream, 0 = none), "hold_lds_kb" (default 64: LDS one sleeper workgroup
  * of that reservation allocates), "persistent_decoder" (the whole decoder loop as ONE launch of co-resident
  * workgroup clusters, two decoder GRU layers, at most 64 utterances under the pipeline: 1 = under the call pipeline

@@ -219,6 +219,10 @@ class Engine(object):
         if stream is not None:
             self._check(self.lib.tts_set_stream(self.handle, c_void_p(stream)))
 
+    def set_stream(self, stream):
+        """Adopt a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); None: a stream of the library's own."""
+        self._check(self.lib.tts_set_stream(self.handle, c_void_p(stream) if stream else None))
+
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
         if rc != TTS_OK:

@@ -1707,7 +1707,9 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     // synchronises every stream -- under the CU reservation that would park the host on the sleepers' 100 ms bound.
     const bool same_shape = h->syn_shape[0] == B && h->syn_shape[1] == Ts && h->syn_shape[2] == sp->n_steps;
     h->syn_shape[0] = B; h->syn_shape[1] = Ts; h->syn_shape[2] = sp->n_steps;
-    const bool pipelined = h->pipeline && h->own_stream && same_shape;
+    // (a borrowed stream is pipelined only on request, pipeline = 2: the caller then vouches that the inputs of a call
+    //  are complete when it is made -- the library cannot tell them from the previous call's work on that stream)
+    const bool pipelined = h->pipeline && (h->own_stream || h->pipeline >= 2) && same_shape;
     if (pipelined) {
         if (!h->front) {
             int prio_least = 0, prio_greatest = 0;

@@ -160,3 +160,38 @@ def test_pipelined_calls_equal_sequential(engine):
     finally:
         engine.set_option('pipeline', 1)
         engine.set_option('persistent_decoder', 1)
+
+
+def test_pipelining_on_an_adopted_stream(engine):
+    """tts_set_stream + pipeline = 2: calls on a caller's stream (a plain hipStream_t here, what
+    torch.cuda.current_stream().cuda_stream is) overlap like those on the library's own, with identical results;
+    pipeline = 1 on an adopted stream stays serialised."""
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    stream = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
+    batches = [bench_ids(4, 30, 60 + i) for i in range(4)]
+    inits = [np.random.default_rng(10 + i).random((4, 1025, 40)).astype(np.float32) for i in range(4)]
+    dev_ids = [engine.to_device(b) for b in batches]
+    dev_init = [engine.to_device(x) for x in inits]
+
+    def run():
+        outs = [engine.synthesize(dev_ids[i], 8, 6.02, 99.89, 1.3, 6, WIN, HOP, init_phase=dev_init[i], want_mel=True)
+                for i in range(4)]
+        engine.synchronize()
+        return [{k: v.to_host() for k, v in o.items() if v is not None} for o in outs]
+
+    try:
+        engine.set_option('pipeline', 0)
+        ref = run()
+        engine.set_stream(stream.value)
+        for mode in (1, 2):
+            engine.set_option('pipeline', mode)
+            got = run()
+            for a, b in zip(ref, got):
+                for k in a:
+                    assert np.array_equal(a[k], b[k]), (mode, k)
+    finally:
+        engine.set_stream(None)
+        engine.set_option('pipeline', 1)
+        hip.hipStreamDestroy(stream)
