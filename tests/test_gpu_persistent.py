@@ -63,13 +63,18 @@ def test_persistent_decoder_200_steps_b64(persistent, hparams, weights64):
     assert np.abs(al[:, rows] - ref_al).max() < 1e-4
 
 
-def test_persistent_decoder_reruns_are_bit_identical(persistent):
+@pytest.mark.parametrize('B,Ts,S,reruns', [(20, 50, 12, 3), (64, 150, 200, 4)])
+def test_persistent_decoder_reruns_are_bit_identical(persistent, B, Ts, S, reruns):
+    """Every hand-off is a race the protocol has to win: a stale read anywhere in the up to 2000 hops per cluster would
+    show up as a difference between runs of the same input (the arithmetic itself has a fixed order)."""
     rng = np.random.default_rng(11)
-    memory = persistent.to_device(rng.standard_normal((20, 50, 256)).astype(np.float32))
-    mel, al = persistent.decoder_forward(memory, 12)
+    memory = persistent.to_device(rng.standard_normal((B, Ts, 256)).astype(np.float32))
+    mel, al = persistent.decoder_forward(memory, S)
+    persistent.synchronize()
     a, b = mel.to_host(), al.to_host()
-    for _ in range(3):
-        persistent.decoder_forward(memory, 12, mel=mel, alignments=al)
+    for _ in range(reruns):
+        persistent.decoder_forward(memory, S, mel=mel, alignments=al)
+        persistent.synchronize()
         assert np.array_equal(a, mel.to_host()) and np.array_equal(b, al.to_host())
 
 
