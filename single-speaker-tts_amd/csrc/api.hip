@@ -527,6 +527,7 @@ int sync_all(tts_handle_t h) {
         h->pd_used = false;
         int status = 0;
         HIPCHK(h, hipMemcpy(&status, h->pd_sync + 64 * h->pd_clusters + 1, sizeof(int), hipMemcpyDeviceToHost));
+        if (status) HIPCHK(h, hipMemset(h->pd_sync + 64 * h->pd_clusters + 1, 0, sizeof(int)));
         if (status)
             return fail(h, TTS_ERR_HIP,
                         "persistent decoder: a workgroup waited for its cluster longer than the bound (not all "
@@ -1446,6 +1447,8 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
         }
         const int clusters = (B + 15) / 16;
         WS(h, "dec.pd_sync", unsigned, (size_t)64 * clusters + 2, pd_sync);
+        if (pd_sync != h->pd_sync || clusters != h->pd_clusters)   // new buffer / new layout: the sticky status word starts clean
+            HIPCHK(h, hipMemsetAsync(pd_sync + 64 * clusters + 1, 0, sizeof(unsigned), h->stream));
         HIPCHK(h, decoder_persistent_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, alignments, pd_sync,
                                              h->cur_hold_flag, c.force_cudnn));
         h->pd_sync = pd_sync;

@@ -556,14 +556,17 @@ hipError_t decoder_persistent_configure() {
                                160 * 1024 - 64);
 }
 
-// Capturable: two memsets and one launch.  `sync` = 64 unsigned per cluster + 1 (resident count) + 1 (status word).
+// Capturable: two memsets and one launch.  `sync` = 64 unsigned per cluster + 1 (resident count) + 1 (status word,
+// zeroed by the caller when the buffer is created and after it has been read).
 hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, const DecoderScratch& sc, const float* memory,
                                       const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync,
                                       int* hold_flag, int cudnn) {
     const int clusters = (B + 15) / 16;
     hipError_t e;
     if ((e = hipMemsetAsync(sc.state, 0, sc.state_bytes, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(sync, 0, ((size_t)64 * clusters + 2) * sizeof(unsigned), s)) != hipSuccess) return e;
+    // counters and resident count start at zero for every launch; the status word behind them is sticky (the host
+    // clears it when it has read it, api.hip), so a timeout is not lost when several calls are queued before a sync
+    if ((e = hipMemsetAsync(sync, 0, ((size_t)64 * clusters + 1) * sizeof(unsigned), s)) != hipSuccess) return e;
     PdParams p;
     p.w1 = w.prenet1_wt; p.b1 = w.prenet1_b; p.w1f = w.prenet1f_wt; p.b1f = w.prenet1f_b; p.w2 = w.prenet2_wt; p.b2 = w.prenet2_b;
     p.ag_w = w.att_gru.gates_wt; p.ag_b = w.att_gru.gates_b; p.ac_w = w.att_gru.cand_wt; p.ac_b = w.att_gru.cand_b;
