@@ -29,7 +29,9 @@ __device__ __forceinline__ float4 max4(float4 a, float4 b) {
 
 // DENORM: instantiation with the de-normalising second output (final Dense layer only; keeps the
 // powf out of the register allocation of every other GEMM)
-template <bool DENORM>
+// POOL: instantiation whose A loader takes max(x[t], x[t+1]) (the two k = 3 projections that follow a max-pool): kept
+// apart so that every other GEMM carries neither its second load nor its registers.
+template <bool DENORM, bool POOL>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
     const GemmGroup& g = batch.g[blockIdx.z];
     const int M = g.M, N = g.N, K = g.K;
@@ -99,12 +101,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
     // in L1 / L2) instead of Cin/BK tiles apart.  The weight tile follows the same map.
     const int ktaps = K / g.Cin;
     const bool tap_inner = ktaps > 1 && (g.Cin % BK) == 0;
-    // Whenever all 32 k of a tile share one tap (dense layers: always tap 0; tap_inner convolutions: by construction)
-    // the tile's (tap, first k) pair is wave-uniform and advances by a compare per tile -- no integer division in the
-    // loop, and the tap masks of a row are three bits computed once.  Only a convolution whose channel count is no
-    // multiple of the tile depth (the post-net bank, 80 channels) takes the per-lane division.
+    // No integer division in the loop.  Whenever all 32 k of a tile share one tap (dense layers: always tap 0; tap_inner
+    // convolutions: by construction) the tile's (tap, first k) pair is wave-uniform and advances by a compare per
+    // tile.  Otherwise (the post-net bank: 80 channels, tiles straddle taps) every thread carries the tap and the
+    // channel of its own four k and advances them by the tile depth.  The tap masks of a row are bits computed once:
+    // bit t = tap t of the row lies inside the sequence (up to 16 taps), bit 16 + t = so does the row after it (the
+    // max-pool loader, k = 3 only).  Wider kernels than 16 taps take the general path with its division.
     const bool uniform_tap = ktaps == 1 || tap_inner;
-    int cur_tap = 0, cur_kb = 0;   // of the NEXT tile load_tile is asked for (tiles are requested in order)
+    int cur_tap = 0, cur_kb = 0;   // uniform case: of the NEXT tile load_tile is asked for (tiles are requested in order)
+    int my_tap = 0, my_ch = 0;     // per-thread case: tap and channel of this thread's four k in the next tile
     {
         const int k_first = g.kt1 > 0 ? g.kt0 : 0;
         if (tap_inner) {
@@ -114,39 +119,49 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
         } else {
             cur_kb = k_first;
         }
+        if (!POOL && !uniform_tap) {
+            const int kk0 = k_first + 4 * kq;
+            my_tap = kk0 / g.Cin;
+            my_ch = kk0 - my_tap * g.Cin;
+        }
     }
-    unsigned tapmask[4];   // bit t: tap t of this row lies inside the sequence (taps 0..2; wider kernels take the general path)
+    unsigned tapmask[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         unsigned m = 0;
-        for (int t = 0; t < 3; ++t) {
+        const int nt = POOL ? 3 : (ktaps < 16 ? ktaps : 16);
+        for (int t = 0; t < nt; ++t) {
             const int ts = a_t[i] - g.padl + t;
             if (a_ok[i] && ts >= 0 && ts < g.T) m |= 1u << t;
-            if (a_ok[i] && ts >= 0 && ts + 1 < g.T) m |= 1u << (4 + t);   // ... and the row after it (max-pool loader)
+            if (POOL && a_ok[i] && ts >= 0 && ts + 1 < g.T) m |= 1u << (16 + t);
         }
         tapmask[i] = m;
     }
-    const bool fast = uniform_tap && ktaps <= 3;
+    const bool fast = POOL ? (uniform_tap && ktaps <= 3) : ktaps <= 16;
     auto load_tile = [&](int kt) {
         if (fast) {
-            const int kk = cur_kb + 4 * kq;
+            const bool per_thread = !POOL && !uniform_tap;
+            const int tap = per_thread ? my_tap : cur_tap;
+            const int kk = per_thread ? my_tap * g.Cin + my_ch : cur_kb + 4 * kq;
             const bool kin = kk < K;
-            const int tap = cur_tap;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool ok = kin && ((tapmask[i] >> tap) & 1u);
                 const unsigned off = ok ? (unsigned)(a_off[i] + kk) * 4u : 0xFFFFFFFFu;
                 float4 v = buf4(a_rs, off);
-                if (g.pool) v = max4(v, buf4(a_rs, (kin && ((tapmask[i] >> (4 + tap)) & 1u)) ? off + (unsigned)g.lda * 4u : off));
+                if (POOL) v = max4(v, buf4(a_rs, (kin && ((tapmask[i] >> (16 + tap)) & 1u)) ? off + (unsigned)g.lda * 4u : off));
                 ra[i] = v;
                 rb[i] = buf4(b_rs, (b_ok[i] && kin) ? (unsigned)(b_off[i] + kk) * 4u : 0xFFFFFFFFu);
             }
-            // advance to the next tile: tap inner, channel chunk outer
-            if (tap_inner) {
+            // advance to the next tile
+            if (tap_inner) {          // tap inner, channel chunk outer
                 if (++cur_tap == ktaps) { cur_tap = 0; cur_kb += BK - (ktaps - 1) * g.Cin; }
                 else cur_kb += g.Cin;
-            } else {
+            } else if (uniform_tap) {
                 cur_kb += BK;
+            } else if (!POOL) {
+                my_ch += BK;
+                while (my_ch >= g.Cin) { my_ch -= g.Cin; ++my_tap; }
             }
             return;
         }
@@ -159,7 +174,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
             const bool ok = a_ok[i] && kin && ts >= 0 && ts < g.T;
             const unsigned off = ok ? (unsigned)(a_off[i] + kk) * 4u : 0xFFFFFFFFu;
             float4 v = buf4(a_rs, off);
-            if (g.pool) v = max4(v, buf4(a_rs, (ok && ts + 1 < g.T) ? off + (unsigned)g.lda * 4u : off));
+            if (POOL) v = max4(v, buf4(a_rs, (ok && ts + 1 < g.T) ? off + (unsigned)g.lda * 4u : off));
             ra[i] = v;
             rb[i] = buf4(b_rs, (b_ok[i] && kin) ? (unsigned)(b_off[i] + kk) * 4u : 0xFFFFFFFFu);
         }
@@ -299,8 +314,13 @@ hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups) {
     dim3 grid((m_blocks + 7) / 8 * 8, (max_n + BN - 1) / BN, n_groups);   // M-blocks padded to the XCD count (see the tile map)
     bool denorm = false;
     for (int i = 0; i < n_groups; ++i) denorm = denorm || b.g[i].C2 != nullptr;
-    if (denorm) hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, s, b);
-    else hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, s, b);
+    bool pool = false;
+    for (int i = 0; i < n_groups; ++i) pool = pool || b.g[i].pool != 0;
+    for (int i = 0; i < n_groups; ++i)
+        if (pool && (!b.g[i].pool || b.g[i].C2)) return hipErrorInvalidValue;   // a pooled launch is homogeneous, never de-normalising
+    if (pool) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, b);
+    else if (denorm) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, b);
     return hipGetLastError();
 }
 
