@@ -916,7 +916,10 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
                 p.dbg = tl;
             }
 #endif
-            HIPCHK(h, launch_gl_iter(h->stream, p, n_cus, 0));
+            // no more workgroups than the plan counts on: one that finds its compute unit taken (the call pipeline's other
+            // stream) would start when the first of the others leaves, load its tables, find no item and only
+            // lengthen the launch
+            HIPCHK(h, launch_gl_iter(h->stream, p, free_cus, 0));
             std::swap(cur, nxt);
         }
 #ifdef GL_TIMELINE
@@ -968,7 +971,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
         p.wav = wav;
         p.peak_partial = peak_normalize ? msep : nullptr;   // the mse partials are consumed by now
         p.work_counter = counters + n_iter;
-        HIPCHK(h, launch_gl_iter(h->stream, p, n_cus, 1));
+        HIPCHK(h, launch_gl_iter(h->stream, p, free_cus, 1));
     }
     if (peak_normalize) HIPCHK(h, launch_peak_scale(h->stream, wav, B, hop * (T - 1), msep, nchunks));
     return TTS_OK;

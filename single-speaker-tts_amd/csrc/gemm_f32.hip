@@ -14,6 +14,7 @@
 // that each lane fetches its 4 consecutive k values with one ds_read_b128 for both operands.
 #include "tts_common.h"
 #include <cstring>
+#include <type_traits>
 
 namespace tts {
 
@@ -188,6 +189,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
         }
     };
 
+    // 32 x 32 blocks of this wave that lie entirely past M or N get no MFMAs (wave-uniform): the final Dense has
+    // N = 1025 = 8 tiles + one column, the second post-net projection N = 80 -- a quarter to three quarters of the
+    // edge tile's matrix work is on padding.  Their accumulators stay zero and the epilogue never stores them.
+    bool blk_live[2][2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+            blk_live[tm][tn] = (m0 + wm * 64 + tm * 32 < M) && (n0 + wn * 64 + tn * 32 < N);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -199,6 +209,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
     const int k_begin = g.kt1 > 0 ? g.kt0 : 0;
     const int k_end = g.kt1 > 0 ? g.kt1 : K;
     load_tile(k_begin);
+    // the k loop, instantiated twice: EDGE = false is the loop of every full tile (no tests between the MFMAs),
+    // EDGE = true the one of a wave that owns a padded block
+    auto k_loop = [&](auto edge_c) {
+    constexpr bool EDGE = decltype(edge_c)::value;
     for (int kt = k_begin; kt < k_end; kt += BK) {
         store_tile();
         __syncthreads();
@@ -219,6 +233,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
+                    if (EDGE && !blk_live[tm][tn]) continue;   // wave-uniform
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
@@ -238,6 +253,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
         }
         __syncthreads();
     }
+    };
+    if (blk_live[0][0] && blk_live[0][1] && blk_live[1][0] && blk_live[1][1]) k_loop(std::false_type{});
+    else k_loop(std::true_type{});
 
     // ---- epilogue.  C/D map of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     if (g.epi == EPI_HIGHWAY) {

@@ -38,6 +38,9 @@ __device__ __forceinline__ float gru_sum4(float v) {
     v += gru_dpp<0x4E>(v);    // quad_perm [2,3,0,1]: lane ^ 2
     return v;
 }
+// Workgroup barrier that orders LDS accesses only: nothing one thread writes to global memory is read by another
+// thread of this kernel, so a step must not wait for its output store (or the prefetched inputs) at the barrier.
+__device__ __forceinline__ void gru_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 typedef float gru_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ gru_f2 gru_pk_fma(gru_f2 a, gru_f2 b, gru_f2 c) {   // (a.x b.x + c.x, a.y b.y + c.y)
     gru_f2 d;
@@ -96,36 +99,52 @@ __global__ __launch_bounds__(GRU_THREADS) void bigru_kernel(const float* __restr
 
     int t = d ? T - 1 : 0;
     const int dt = d ? -1 : 1;
-    // the four lanes of a unit load the same three input terms (one request each after coalescing)
-    float xr = xb[(size_t)t * xld], xu = xb[(size_t)t * xld + H], xc = xb[(size_t)t * xld + 2 * H];
+    // Input terms of step s (the four lanes of a unit load the same three words: one request each after coalescing)
+    // live in three register sets that rotate by NAME (the loop is unrolled by three): the set a step has consumed is
+    // refilled for step s + 3 by unconditional loads (the step index is clamped, not tested).  A load under a branch,
+    // or a register-to-register rotation of the sets, makes the compiler wait with vmcnt(0) inside the step -- for the
+    // loads it has just issued, i.e. the whole global-load latency on the critical path of every step.
+    auto xrow = [&](int s) {
+        const int sc = s < T ? s : T - 1;
+        return xb + (size_t)(d ? T - 1 - sc : sc) * xld;
+    };
+    float xa[3] = {xrow(0)[0], xrow(0)[H], xrow(0)[2 * H]};
+    float xb1[3] = {xrow(1)[0], xrow(1)[H], xrow(1)[2 * H]};
+    float xc2[3] = {xrow(2)[0], xrow(2)[H], xrow(2)[2 * H]};
     float hreg = 0.f;   // h[j], kept by all four lanes of the unit
 
-    for (int s = 0; s < T; ++s, t += dt) {
-        float xr_n = 0.f, xu_n = 0.f, xc_n = 0.f;
-        if (s + 1 < T) {
-            const float* xn = xb + (size_t)(t + dt) * xld;
-            xr_n = xn[0]; xu_n = xn[H]; xc_n = xn[2 * H];
-        }
-        const float* hq = hs[s & 1] + kq * GRU_QPAD;
-        const float r = sigmoidf_(xr + gru_sum4(gru_dot32(hq, wr)));
-        const float u = sigmoidf_(xu + gru_sum4(gru_dot32(hq, wu)));
-        float c;
-        if (CUDNN) {
-            // the candidate's recurrent part does not depend on r: same pass over h
-            c = tanhf_(xc + r * (gru_sum4(gru_dot32(hq, wc)) + bch));
-        } else {
-            if (kq == 0) rhs[slot] = r * hreg;
-            __syncthreads();
-            c = tanhf_(xc + gru_sum4(gru_dot32(rhs + kq * GRU_QPAD, wc)));
-        }
-        hreg = u * hreg + (1.0f - u) * c;
-        if (kq == 0) {
-            ob[(size_t)t * 2 * H] = hreg;
-            hs[(s + 1) & 1][slot] = hreg;
-        }
-        xr = xr_n; xu = xu_n; xc = xc_n;
-        __syncthreads();
+    int s = 0;
+#define GRU_STEP(X)                                                                            \
+    {                                                                                          \
+        const float* hq = hs[s & 1] + kq * GRU_QPAD;                                           \
+        const float r = sigmoidf_(X[0] + gru_sum4(gru_dot32(hq, wr)));                         \
+        const float u = sigmoidf_(X[1] + gru_sum4(gru_dot32(hq, wu)));                         \
+        float c;                                                                               \
+        if (CUDNN) { /* the candidate's recurrent part does not depend on r: same pass over h */ \
+            c = tanhf_(X[2] + r * (gru_sum4(gru_dot32(hq, wc)) + bch));                        \
+        } else {                                                                               \
+            if (kq == 0) rhs[slot] = r * hreg;                                                 \
+            gru_lds_barrier();                                                                 \
+            c = tanhf_(X[2] + gru_sum4(gru_dot32(rhs + kq * GRU_QPAD, wc)));                   \
+        }                                                                                      \
+        hreg = u * hreg + (1.0f - u) * c;                                                      \
+        if (kq == 0) {                                                                         \
+            ob[(size_t)t * 2 * H] = hreg;                                                      \
+            hs[(s + 1) & 1][slot] = hreg;                                                      \
+        }                                                                                      \
+        const float* xn = xrow(s + 3);                                                         \
+        X[0] = xn[0]; X[1] = xn[H]; X[2] = xn[2 * H];                                          \
+        ++s; t += dt;                                                                          \
+        gru_lds_barrier();                                                                     \
     }
+    while (s + 3 <= T) {
+        GRU_STEP(xa)
+        GRU_STEP(xb1)
+        GRU_STEP(xc2)
+    }
+    if (s < T) GRU_STEP(xa)
+    if (s < T) GRU_STEP(xb1)
+#undef GRU_STEP
 }
 
 size_t bigru_wrec_floats(int H, int cudnn) {

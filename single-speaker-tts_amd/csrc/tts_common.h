@@ -17,11 +17,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3 };
 enum Epi { EPI_STD = 0, EPI_HIGHWAY = 1 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// Reciprocals are v_rcp_f32 (1 ulp): `1.0f / x` compiles to the IEEE division sequence (v_div_scale, v_rcp, four
+// fmas, v_div_fmas, v_div_fixup: ten dependent instructions), which sits three times on the critical path of every
+// GRU step.  rcp(inf) = 0 and rcp(1) = 1, so the limits stay exact.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
     // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, abs error ~1e-7.
     float e = __expf(2.0f * x);
-    return 1.0f - 2.0f / (e + 1.0f);
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 // reference tacotron/inference.py:96-101,175 + audio/conversion.py:102,51: clip -> dB -> magnitude -> ** power
 __device__ __forceinline__ float denorm_db(float x, float ref_db, float range_db) {
