@@ -131,6 +131,19 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Progress flags of the overlap-add (LDS words polled / written by single lanes).  The pointer is cast to the LDS
+// address space explicitly: a `volatile int*` derived from the dynamic shared array stays a GENERIC pointer (address
+// space inference skips volatile accesses), and the access becomes flat_load / flat_store ... sc0 sc1 followed by
+// s_waitcnt vmcnt(0) -- every round then waits for the next frame's prefetched spectrum row before its overlap-add
+// instead of in the next round's unpacking.  These are ds_read_b32 / ds_write_b32 and touch lgkmcnt only.
+typedef __attribute__((address_space(3))) int gl_lds_int;
+__device__ __forceinline__ int gl_flag_load(int* p) {
+    return __hip_atomic_load((gl_lds_int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void gl_flag_store(int* p, int v) {
+    __hip_atomic_store((gl_lds_int*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS hand-off between lanes of ONE wave.  The LDS unit executes one wave's DS operations in
     // issue order, so a ds_read issued after a ds_write of the same wave observes it for every
@@ -605,8 +618,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             }
             const int need = r - (R - ncol);
             if (need > 0 && wave + 1 < GL_NW) {
-                volatile int* flag = ctrl + CT_FLAGS + wave + 1;
-                while (*flag < need) __builtin_amdgcn_s_sleep(1);
+                while (gl_flag_load(ctrl + CT_FLAGS + wave + 1) < need) __builtin_amdgcn_s_sleep(1);
             }
             asm volatile("" ::: "memory");
             float* sf = sig + fa * hop;
@@ -648,7 +660,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 }
             }
             asm volatile("" ::: "memory");
-            if (lane == 0) *reinterpret_cast<volatile int*>(ctrl + CT_FLAGS + wave) = r + 1;
+            if (lane == 0) gl_flag_store(ctrl + CT_FLAGS + wave, r + 1);
         }
         // this wave is done with the synthesis window: fetch the analysis window of phase B into the same
         // registers now, so that the loads fly while the wave waits for the others at the barrier
