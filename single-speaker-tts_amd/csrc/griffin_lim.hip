@@ -345,16 +345,23 @@ __device__ __forceinline__ unsigned gl_pack_phasor(cf x) {   // x: any scale
     const bool sw = fabsf(x.x) < fabsf(x.y);
     const float small = sw ? x.x : x.y;
     const float big = sw ? x.y : x.x;
-    const float r = small * __builtin_amdgcn_rcpf(fmaxf(fabsf(big), 1.0e-30f));
+    // max(|big|, tiny) as ONE instruction: fmaxf(fabsf(big), c) compiles to a canonicalising v_max(|big|, |big|) first
+    float den;
+    asm("v_max_f32_e64 %0, |%1|, %2" : "=v"(den) : "v"(big), "v"(1.0e-30f));
+    const float r = small * __builtin_amdgcn_rcpf(den);
     return (__float_as_uint(r) & ~3u) | (sw ? 2u : 0u) | (__float_as_uint(big) >> 31);
 }
+// mag >= 0 (every producer of the internal magnitude buffer writes |S|: gl_to_internal_kernel, the de-normalising
+// epilogues).  The two flag bits are NOT stripped from r before it is used: they are at most 3 ulp of r, exactly
+// what stripping (a truncation) costs.
 __device__ __forceinline__ cf gl_unpack_phasor(unsigned c, float mag) {   // -> mag * phasor
-    const float r = __uint_as_float(c & ~3u);
+    const float r = __uint_as_float(c);
     const float ba = __builtin_amdgcn_rsqf(fmaf(r, r, 1.0f));            // |big|
     const float sm = r * ba;
     const float bg = __uint_as_float(__float_as_uint(ba) | (c << 31));
     const bool sw = (c & 2u) != 0u;
-    return cmk((sw ? sm : bg) * mag, (sw ? bg : sm) * mag);
+    const cf ph = cmk(sw ? sm : bg, sw ? bg : sm);
+    return cmk(ph.x * mag, ph.y * mag);
 }
 // Separate launches per iteration: plain loads, streaming stores.  FUSED launch (several iterations in one kernel, see
 // gl_iter_kernel): a run's neighbours are other workgroups, possibly on other XCDs, so every load of the state bypasses
@@ -571,8 +578,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             if (ok) {
                 cf gk[16], gm[16];   // X[k] = |S[k]| * phasor[k]
 #pragma unroll
-                for (int j = 0; j < 16; ++j) gk[j] = gl_unpack_phasor(gc[j], fabsf(gs[j]));
-                mirror_bins(gk, gm, ex, lane, cmk(gl_unpack_phasor(nyq_c, fabsf(nyq_s)).x, 0.f));
+                for (int j = 0; j < 16; ++j) gk[j] = gl_unpack_phasor(gc[j], gs[j]);
+                const cf nyq = cmk(gl_unpack_phasor(nyq_c, nyq_s).x, 0.f);
+                mirror_bins(gk, gm, ex, lane, nyq);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     cf xk = gk[j];
@@ -590,7 +598,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             }
             // the row is consumed: fetch the next round's frame into the same registers now, it lands
             // while this frame's FFT runs
-            if (r + 1 < R) GL_LOAD_FRAME(fa + 1)
+            if (r + 1 < R) GL_LOAD_FRAME(fa + 1)   // (requested before the mirror / split passes instead: 3 % slower)
             if (ok) {
                 fft1024(v, ex, tw, lane);
                 // z[m] = conj(v)/MH, m = lane + 64 c: x[2m] = Re, x[2m+1] = Im

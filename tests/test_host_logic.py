@@ -296,7 +296,7 @@ def test_phasor_code_emulation():
         return (r.view(np.uint32) & ~np.uint32(3)) | np.where(sw, np.uint32(2), np.uint32(0)) | (big.view(np.uint32) >> np.uint32(31))
 
     def unpack(code):
-        r = (code & ~np.uint32(3)).view(np.float32)
+        r = code.view(np.float32)   # the flag bits are not stripped: 3 ulp of r at most, what stripping costs too
         ba = (np.float32(1.0) / np.sqrt((r * r + np.float32(1.0)).astype(np.float32))).astype(np.float32)
         sm = (r * ba).astype(np.float32)
         bg = (ba.view(np.uint32) | (code << np.uint32(31))).view(np.float32)
@@ -311,7 +311,10 @@ def test_phasor_code_emulation():
     assert np.abs(ux * ux + uy * uy - 1.0).max() < 4e-7
     # zero bins (angle(0) = 0 -> 1 + 0j, reference audio/synthesis.py:109) and the codes the kernel writes directly
     z = np.zeros(1, np.float32)
-    assert [float(v[0]) for v in unpack(pack(z, z))] == [1.0, 0.0]
-    assert [float(v[0]) for v in unpack(pack(-z, z))] == [-1.0, 0.0]               # np.angle(-0.0 + 0j) = pi
+    def near(v, want):   # a flag bit left in a zero ratio is a denormal (1e-45), not a phase
+        return float(v[0][0]) == want[0] and abs(float(v[1][0]) - want[1]) < 1e-40
+
+    assert near(unpack(pack(z, z)), [1.0, 0.0])
+    assert near(unpack(pack(-z, z)), [-1.0, 0.0])                                  # np.angle(-0.0 + 0j) = pi
     for c, want in ((np.uint32(0), [1.0, 0.0]), (np.uint32(1), [-1.0, 0.0])):      # Nyquist / DC phasors
-        assert [float(v[0]) for v in unpack(np.array([c], np.uint32))] == want
+        assert near(unpack(np.array([c], np.uint32)), want)
