@@ -33,6 +33,16 @@ namespace tts {
 #define PD_LDA 516                // LDS row stride (floats) of the staged A tile: K <= 512; +4 keeps b128 reads conflict-free
 #define PD_RED_LD 20              // row stride of the per-wave partial tiles (b128 aligned)
 #define PD_SPIN_LIMIT 2000000u      // polls of ~1 us each
+// attention: key passes (32 positions each) / value rows per wave in flight together.  Same-box decoder times alone /
+// beside Griffin-Lim: one pass and two rows at a time (round-2 start) 15.16 / 17.29 ms, 2 and 4: 14.87 / 17.24, 2 and 8:
+// 15.05 / 17.27, 3 and 8: 15.78 / 17.60 (the prefetched keys live across the wait for the cluster and spill).  The phase
+// is bound by the cluster's arrival skew, not by its dependent memory trips.
+#ifndef PD_KB
+#define PD_KB 2
+#endif
+#ifndef PD_VB
+#define PD_VB 4
+#endif
 
 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned pd_u32x4;
 
@@ -153,25 +163,45 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, int j, i
         bv[i] = *reinterpret_cast<const float4*>(wrow + 16 * (c < nch ? c : nch - 1));
     }
 
+    // ---- where this thread's (at most two) float4 of the cluster's A tile come from and go to: computed before the
+    // wait as well (an integer division per element; behind the wait it was ~0.6 us of every phase)
+    unsigned soff[2];   // byte offset into a0 (ssel 0) or a1 (ssel 1); ssel 2 = zeros
+    int sdst[2], ssel[2];
+    if (!ph.cont) {
+        const int k4 = ph.K >> 2;                 // float4 per row
+        const int total = 16 * k4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * PD_THREADS;
+            const int ic = i < total ? i : 0;
+            const int row = ic / k4, kk = (ic - row * k4) * 4;
+            const int b = b0 + row < B ? b0 + row : B - 1;
+            sdst[u] = i < total ? row * PD_LDA + kk : -1;
+            const bool first = kk < ph.k0;
+            ssel[u] = i >= total ? 3 : (first ? (ph.a0 ? 0 : 2) : 1);
+            soff[u] = first ? (unsigned)(b * ph.lda0 + kk) * 4u : (unsigned)(b * ph.lda1 + kk - ph.k0) * 4u;
+        }
+    }
+
     PD_STAMP(0)
     if (!ph.cont) pd_wait(cnt, target, status, ctrl);
     PD_STAMP(1)
 
-    // ---- stage the cluster's A tile (16 rows x K) in LDS: sc1 loads of the handed-off activations
+    // ---- stage the cluster's A tile (16 rows x K) in LDS: sc1 loads of the handed-off activations.  K <= 512: at most
+    // two float4 per thread, BOTH requested before either is written to LDS (written as a loop of load-then-store the
+    // second request waited for the first: two fabric round trips per phase instead of one)
     if (!ph.cont) {
-        const int k4 = ph.K >> 2;                 // float4 per row
         const __amdgpu_buffer_rsrc_t r0 = pd_rsrc(ph.a0 ? ph.a0 : ph.a1), r1 = pd_rsrc(ph.a1);
-        for (int i = tid; i < 16 * k4; i += PD_THREADS) {
-            const int row = i / k4, kk = (i - row * k4) * 4;
-            const int b = b0 + row < B ? b0 + row : B - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kk < ph.k0) {
-                if (ph.a0) v = pd_ld4(r0, (unsigned)(b * ph.lda0 + kk) * 4u);
-            } else {
-                v = pd_ld4(r1, (unsigned)(b * ph.lda1 + kk - ph.k0) * 4u);
-            }
-            *reinterpret_cast<float4*>(As + row * PD_LDA + kk) = v;
+        float4 sv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            sv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ssel[u] == 0) sv[u] = pd_ld4(r0, soff[u]);
+            else if (ssel[u] == 1) sv[u] = pd_ld4(r1, soff[u]);
         }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (sdst[u] >= 0) *reinterpret_cast<float4*>(As + sdst[u]) = sv[u];
         __syncthreads();
     }
     PD_STAMP(2)
@@ -294,6 +324,22 @@ __device__ __forceinline__ void pd_attention_body(const float* __restrict__ quer
     const bool row_ok = row < B;
     const int rr = row_ok ? row : B - 1;
 
+    // Scores: 16 lanes per key, 32 keys per pass of the row's 8 waves, PD_KB passes requested together (a pass per
+    // round trip to L2 / the Infinity Cache was five dependent trips per step at Ts = 150).  The keys do not depend on
+    // the query: with the global form the first PD_KB passes are requested BEFORE the wait for the cluster.
+    const int sub = lane >> 4, l16 = lane & 15;
+    float4 kpre[PD_KB][4];
+    auto load_keys = [&](const float* kbase, int j0, int n_pos) {
+#pragma unroll
+        for (int q = 0; q < PD_KB; ++q) {
+            const int jj = j0 + 32 * q + hw * 4 + sub;
+            const float* kr = kbase + (size_t)(jj < n_pos ? jj : n_pos - 1) * PD_D;   // clamped, never branched on
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kpre[q][i] = *reinterpret_cast<const float4*>(kr + (l16 + 16 * i) * 4);
+        }
+    };
+    if (!LOCAL) load_keys(keys + (size_t)rr * Ts * PD_D, 0, Ts);
+
     PD_STAMP(0)
     pd_wait(cnt, target, status, ctrl);
     PD_STAMP(1)
@@ -342,30 +388,28 @@ __device__ __forceinline__ void pd_attention_body(const float* __restrict__ quer
         }
     }
 
-    // scores: 16 lanes per key, 32 keys per pass of the row's 8 waves
-    const int sub = lane >> 4, l16 = lane & 15;
     const float* kb = keys + ((size_t)rr * Ts + w_lo) * PD_D;
-    for (int j0 = 0; j0 < w_n; j0 += 32) {
-        const int jj = j0 + hw * 4 + sub;
-        float s = 0.f;
-        if (jj < w_n) {
-            const float* kr = kb + (size_t)jj * PD_D;
+    for (int j0 = 0; j0 < w_n; j0 += 32 * PD_KB) {
+        if (LOCAL || j0 > 0) load_keys(kb, j0, w_n);
+#pragma unroll
+        for (int q = 0; q < PD_KB; ++q) {
+            const int jj = j0 + 32 * q + hw * 4 + sub;
+            float s = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int d0 = (l16 + 16 * i) * 4;
-                const float4 kv = *reinterpret_cast<const float4*>(kr + d0);
-                const float4 qv = *reinterpret_cast<const float4*>(qs + d0);
+                const float4 kv = kpre[q][i];
+                const float4 qv = *reinterpret_cast<const float4*>(qs + (l16 + 16 * i) * 4);
                 s = fmaf(kv.x, qv.x, s);
                 s = fmaf(kv.y, qv.y, s);
                 s = fmaf(kv.z, qv.z, s);
                 s = fmaf(kv.w, qv.w, s);
             }
+            s += __shfl_xor(s, 8);
+            s += __shfl_xor(s, 4);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 1);
+            if (jj < w_n && l16 == 0) sc[jj] = s;
         }
-        s += __shfl_xor(s, 8);
-        s += __shfl_xor(s, 4);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 1);
-        if (jj < w_n && l16 == 0) sc[jj] = s;
     }
     __syncthreads();
 
@@ -394,23 +438,24 @@ __device__ __forceinline__ void pd_attention_body(const float* __restrict__ quer
     const float inv = 1.0f / sum;
 
     PD_STAMP(3)
-    // context: wave hw takes positions hw, hw + 8, ...; lane d4 owns 4 consecutive depth elements (1 KB rows, coalesced)
+    // context: wave hw takes positions hw, hw + 8, ...; lane d4 owns 4 consecutive depth elements (1 KB rows, coalesced);
+    // PD_VB rows requested together (two per trip were ten dependent trips per step at Ts = 150)
     const float* vb = values + ((size_t)rr * Ts + w_lo) * PD_D + 4 * lane;
-    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
-    int jj = hw;
-    for (; jj + 8 < w_n; jj += 16) {
-        const float e0 = sc[jj], e1 = sc[jj + 8];
-        const float4 v0 = *reinterpret_cast<const float4*>(vb + (size_t)jj * PD_D);
-        const float4 v1 = *reinterpret_cast<const float4*>(vb + (size_t)(jj + 8) * PD_D);
-        c0.x = fmaf(e0, v0.x, c0.x); c0.y = fmaf(e0, v0.y, c0.y); c0.z = fmaf(e0, v0.z, c0.z); c0.w = fmaf(e0, v0.w, c0.w);
-        c1.x = fmaf(e1, v1.x, c1.x); c1.y = fmaf(e1, v1.y, c1.y); c1.z = fmaf(e1, v1.z, c1.z); c1.w = fmaf(e1, v1.w, c1.w);
+    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = hw; j0 < w_n; j0 += 8 * PD_VB) {
+        float4 vv[PD_VB];
+#pragma unroll
+        for (int q = 0; q < PD_VB; ++q) {
+            const int jj = j0 + 8 * q;
+            vv[q] = *reinterpret_cast<const float4*>(vb + (size_t)(jj < w_n ? jj : w_n - 1) * PD_D);
+        }
+#pragma unroll
+        for (int q = 0; q < PD_VB; ++q) {
+            const int jj = j0 + 8 * q;
+            const float e = jj < w_n ? sc[jj] : 0.f;
+            c0.x = fmaf(e, vv[q].x, c0.x); c0.y = fmaf(e, vv[q].y, c0.y); c0.z = fmaf(e, vv[q].z, c0.z); c0.w = fmaf(e, vv[q].w, c0.w);
+        }
     }
-    if (jj < w_n) {
-        const float e0 = sc[jj];
-        const float4 v0 = *reinterpret_cast<const float4*>(vb + (size_t)jj * PD_D);
-        c0.x = fmaf(e0, v0.x, c0.x); c0.y = fmaf(e0, v0.y, c0.y); c0.z = fmaf(e0, v0.z, c0.z); c0.w = fmaf(e0, v0.w, c0.w);
-    }
-    c0.x += c1.x; c0.y += c1.y; c0.z += c1.z; c0.w += c1.w;
     *reinterpret_cast<float4*>(part + hw * PD_D + 4 * lane) = c0;
     __syncthreads();
     if (t512 < 64) {
