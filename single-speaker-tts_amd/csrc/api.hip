@@ -662,8 +662,10 @@ int run_cbhg(tts_handle_t h, const CbhgWeights& w, const char* tag, const float*
         GemmBatch b;
         std::memset(&b, 0, sizeof(b));
         const int ng = std::min(TTS_GEMM_MAX_GROUPS, NB - k0);
+        // widest bank first: the groups are dispatched in order (blockIdx.z slowest), and a launch that ends with its
+        // cheapest tiles (k = 1: 80 or 128 deep) has a shorter tail than one that ends with the k = 8 / 16 ones
         for (int i = 0; i < ng; ++i) {
-            const int k = k0 + i;
+            const int k = k0 + ng - 1 - i;
             b.g[i] = conv_group(x, w.c_in, k + 1, T, w.bank_wt[k], w.bank_b[k], w.bank_scale[k], w.bank_shift[k], bank,
                                 NB * NF, k * NF, M, NF, ACT_RELU, 0);
         }
