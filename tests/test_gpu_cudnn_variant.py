@@ -33,7 +33,7 @@ def test_manifest_has_cudnn_variables(cudnn_setup):
     assert not any(n.endswith('candidate/kernel') for n in names)
 
 
-@pytest.mark.parametrize('B,Ts,S', [(2, 9, 4), (5, 60, 12)])
+@pytest.mark.parametrize('B,Ts,S', [(2, 9, 4), (3, 11, 3), (5, 60, 12)])   # Ts % 3 = 0, 2, 0; T = 5 S: % 3 = 2, 0, 0
 def test_cudnn_full_network(cudnn_setup, B, Ts, S):
     hp, w, eng = cudnn_setup
     rng = np.random.default_rng(B)

@@ -24,7 +24,8 @@ def make_ids(rng, B, Ts):
     return ids
 
 
-@pytest.mark.parametrize('B,Ts', [(2, 7), (3, 37), (5, 150)])
+# Ts % 3 = 1, 2, 1, 0: the bi-GRU loop is unrolled by three (gru.hip), every remainder is walked
+@pytest.mark.parametrize('B,Ts', [(2, 7), (4, 8), (3, 37), (5, 150)])
 def test_encoder_stages(engine, hparams, weights64, B, Ts):
     rng = np.random.default_rng(100 + B)
     ids = make_ids(rng, B, Ts)
@@ -75,7 +76,7 @@ def test_decoder_graph_matches_eager(engine):
     assert np.array_equal(a0, al1.to_host())
 
 
-@pytest.mark.parametrize('B,T', [(2, 15), (3, 100)])
+@pytest.mark.parametrize('B,T', [(2, 15), (2, 20), (3, 100)])   # T % 3 = 0, 2, 1
 def test_postnet_stages(engine, hparams, weights64, B, T):
     rng = np.random.default_rng(300 + B)
     mel = rng.random((B, T, 80)).astype(np.float32)
