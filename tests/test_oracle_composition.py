@@ -56,11 +56,18 @@ def pre_net(x, w, scope, layers):
 
 
 def gru_cell(x, h, w, scope):
-    """tf.nn.rnn_cell.GRUCell [TF 1.8]: gates on [x ; h] ordered r | u, candidate on [x ; r * h]."""
+    """tf.nn.rnn_cell.GRUCell [TF 1.8]: gates on [x ; h] ordered r | u, candidate on [x ; r * h].  When the weight
+    dictionary holds the CudnnCompatibleGRUCell variables (force_cudnn, reference layers.py:560-577,
+    model.py:226-229,257-262) the candidate is tanh(x W_ci + b_ci + r * (h W_ch + b_ch)) instead."""
     U = h.shape[-1]
     g = torch.sigmoid(F.linear(torch.cat([x, h], -1), t(w[scope + '/gates/kernel']).T, t(w[scope + '/gates/bias'])))
     r, u = g[..., :U], g[..., U:]
-    c = torch.tanh(F.linear(torch.cat([x, r * h], -1), t(w[scope + '/candidate/kernel']).T, t(w[scope + '/candidate/bias'])))
+    if scope + '/candidate/kernel' in w:
+        c = torch.tanh(F.linear(torch.cat([x, r * h], -1), t(w[scope + '/candidate/kernel']).T, t(w[scope + '/candidate/bias'])))
+    else:
+        ci = F.linear(x, t(w[scope + '/candidate/input_projection/kernel']).T, t(w[scope + '/candidate/input_projection/bias']))
+        ch = F.linear(h, t(w[scope + '/candidate/hidden_projection/kernel']).T, t(w[scope + '/candidate/hidden_projection/bias']))
+        c = torch.tanh(ci + r * ch)
     return u * h + (1.0 - u) * c
 
 
@@ -150,9 +157,10 @@ def tacotron_forward(ids, w, hp, n_steps):
     return dict(memory=memory, reduced=reduced, mel=mel, linear=linear, alignments=align)
 
 
-@pytest.mark.parametrize('B,Ts,S,seed', [(2, 7, 3, 0), (3, 12, 4, 5)])
-def test_whole_forward_pass_against_a_torch_restatement(B, Ts, S, seed):
+@pytest.mark.parametrize('B,Ts,S,seed,cudnn', [(2, 7, 3, 0, False), (3, 12, 4, 5, False), (2, 9, 3, 2, True)])
+def test_whole_forward_pass_against_a_torch_restatement(B, Ts, S, seed, cudnn):
     hp = P.ModelParams()
+    hp.force_cudnn = cudnn
     w = O.cast_weights(W.synthetic_weights(seed, hp), np.float64)
     rng = np.random.default_rng(100 + seed)
     ids = rng.integers(2, hp.vocabulary_size, (B, Ts)).astype(np.int32)
