@@ -76,6 +76,8 @@ struct tts_handle_s {
     hipEvent_t ev_front_done = nullptr;
     hipEvent_t ev_post_done[2] = {nullptr, nullptr};   // post-net of the calls of even / odd parity
     bool post_pending[2] = {false, false};
+    hipEvent_t ev_gl_done[2] = {nullptr, nullptr};     // Griffin-Lim of the calls of even / odd parity (its phase buffers are free)
+    bool gl_pending[2] = {false, false};
     bool front_pending = false;     // ev_front_done has been recorded at least once
     unsigned syn_calls = 0;
     int syn_shape[3] = {0, 0, 0};   // (B, Ts, n_steps) of the previous tts_synthesize call
@@ -853,14 +855,22 @@ int gl_prepare(tts_handle_t h, int T, int win, int hop, int n_fft) {
 }
 
 // mag_int: internal [B][T][FP]; init_ft: reference-layout U[0,1) numbers or null.
+// phase_pair: the two phasor-code buffers to iterate in (null: the handle's own pair); phase_ready: phase_pair[0] already
+// holds the initial phasors (written on another stream, ordered by the caller's events).
 int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t seed, int B, int T, int n_iter,
            int win, int hop, int n_fft, float* wav, float* mse, bool peak_normalize = false,
-           bool under_reservation = false) {
+           bool under_reservation = false, float2* const* phase_pair = nullptr, bool phase_ready = false) {
     int rc = gl_prepare(h, T, win, hop, n_fft);
     if (rc) return rc;
     const int F = 1 + n_fft / 2, FP = TTS_GL_FP;
-    WS(h, "gl.phase0", float2, (size_t)B * T * FP, ph0);
-    WS(h, "gl.phase1", float2, (size_t)B * T * FP, ph1);
+    float2 *ph0, *ph1;
+    if (phase_pair) {
+        ph0 = phase_pair[0]; ph1 = phase_pair[1];
+    } else {   // 4 bytes per bin: the state between iterations is a 32-bit phasor code (griffin_lim.hip)
+        WS(h, "gl.phase0", unsigned, (size_t)B * T * FP, own0);
+        WS(h, "gl.phase1", unsigned, (size_t)B * T * FP, own1);
+        ph0 = reinterpret_cast<float2*>(own0); ph1 = reinterpret_cast<float2*>(own1);
+    }
     GlParams p;
     std::memset(&p, 0, sizeof(p));
     p.mag = mag_int;
@@ -884,7 +894,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     // one zeroed work counter per launch (the persistent workgroups draw their item ids from it)
     WS(h, "gl.counters", unsigned, (size_t)n_iter + 1, counters);
     HIPCHK(h, hipMemsetAsync(counters, 0, ((size_t)n_iter + 1) * sizeof(unsigned), h->stream));
-    HIPCHK(h, launch_phase_init(h->stream, init_ft, seed, ph0, B, F, T, FP));
+    if (!phase_ready) HIPCHK(h, launch_phase_init(h->stream, init_ft, seed, ph0, B, F, T, FP));
     float2* cur = ph0;
     float2* nxt = ph1;
     // One launch for all iterations when nothing per-iteration is asked for (gl_iter_kernel, FUSED); `free_cus`
@@ -1085,8 +1095,10 @@ int tts_destroy(tts_handle_t h) {
     if (h->hold_flags) hipFree(h->hold_flags);
     if (h->ev_aux) hipEventDestroy(h->ev_aux);
     if (h->ev_front_done) hipEventDestroy(h->ev_front_done);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
         if (h->ev_post_done[i]) hipEventDestroy(h->ev_post_done[i]);
+        if (h->ev_gl_done[i]) hipEventDestroy(h->ev_gl_done[i]);
+    }
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return TTS_OK;
@@ -1102,6 +1114,7 @@ int tts_set_stream(tts_handle_t h, void* s) {
         if (rc) return rc;
     }
     h->post_pending[0] = h->post_pending[1] = false;
+    h->gl_pending[0] = h->gl_pending[1] = false;
     if (h->dec_graph) {
         hipGraphExecDestroy(h->dec_graph);
         h->dec_graph = nullptr;
@@ -1133,6 +1146,7 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
         int rc = sync_all(h);
         if (rc) return rc;
         h->post_pending[0] = h->post_pending[1] = false;
+        h->gl_pending[0] = h->gl_pending[1] = false;
         h->pipeline = value;
     }
     else return fail(h, TTS_ERR_INVALID, std::string("unknown option ") + key);
@@ -1710,6 +1724,16 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     float* linear = linear_out;   // null: the final Dense emits only the de-normalised magnitude (rows of 1028 floats;
                                   // the 1025-float rows of the linear spectrogram cannot be written in whole cache lines)
     WS(h, "gl.mag", float, (size_t)B * T * FP, magi);
+    // Under the call pipeline the initial phasors of a call are written on the FRONT stream, behind its decoder (that
+    // stream has slack, the main one bounds the step): the phasor-code buffers are then a pair per call parity, so that
+    // the write does not wait for the previous call's Griffin-Lim.  All four are sized here, before anything is enqueued
+    // (a growing workspace synchronises every stream).
+    // (its own buffers, not the pair of the stand-alone tts_griffin_lim: 4 bytes per bin, the state is a phasor code)
+    WS(h, "syn.phase0.even", unsigned, (size_t)B * T * FP, gph0e);
+    WS(h, "syn.phase1.even", unsigned, (size_t)B * T * FP, gph1e);
+    WS(h, "syn.phase0.odd", unsigned, (size_t)B * T * FP, gph0o);
+    WS(h, "syn.phase1.odd", unsigned, (size_t)B * T * FP, gph1o);
+    float2* const phase_pair[2] = {reinterpret_cast<float2*>(parity ? gph0o : gph0e), reinterpret_cast<float2*>(parity ? gph1o : gph1e)};
     // Pipelined only while the library owns its stream (inputs on a borrowed stream may still be in flight) and
     // from the second call of a shape on: the first call of a new (B, Ts, n_steps) grows the workspaces, which
     // synchronises every stream -- under the CU reservation that would park the host on the sleepers' 100 ms bound.
@@ -1730,6 +1754,12 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_front_done, hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_post_done[0], hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_post_done[1], hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_gl_done[0], hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_gl_done[1], hipEventDisableTiming));
+            // calls made before these events existed recorded nothing: the front stream's first work starts behind
+            // everything that is on the main stream now
+            HIPCHK(h, hipEventRecord(h->ev_aux, h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_aux, 0));
         }
     }
     hipStream_t main_stream = h->stream;
@@ -1771,8 +1801,14 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         if (hold_flag) hipMemsetAsync(hold_flag, 1, sizeof(int), h->front);
         return rc;
     }
+    const bool phase_on_front = pipelined && sp->n_iter >= 0;
     if (pipelined) {
         if (hold_flag) HIPCHK(h, hipMemsetAsync(hold_flag, 1, sizeof(int), h->front));   // release the held CUs
+        if (phase_on_front) {
+            // this parity's buffers were last used by the Griffin-Lim of the call two back
+            if (h->gl_pending[parity]) HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_gl_done[parity], 0));
+            HIPCHK(h, launch_phase_init(h->front, init_phase, sp->seed, phase_pair[0], B, F, T, FP));
+        }
         HIPCHK(h, hipEventRecord(h->ev_front_done, h->front));
         h->front_pending = true;
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_front_done, 0));
@@ -1781,12 +1817,17 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     if (denorm_can_assert(sp->ref_db, sp->max_db) && (rc = denorm_flag_arm(h, &db_flag))) return rc;
     if ((rc = postnet_impl(h, mel, B, T, linear, magi, sp->ref_db, sp->max_db, sp->power, db_flag))) return rc;
     if (db_flag && (rc = denorm_flag_read(h))) return rc;   // as the reference: no waveform for such a spectrogram
-    if (pipelined) {
+    if (h->front) {   // (also for an unpipelined call between pipelined ones: its buffers are the same ones)
         HIPCHK(h, hipEventRecord(h->ev_post_done[parity], h->stream));
         h->post_pending[parity] = true;
     }
-    return gl_run(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav, nullptr,
-                  sp->peak_normalize != 0, pipelined);
+    rc = gl_run(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav, nullptr,
+                sp->peak_normalize != 0, pipelined, phase_pair, phase_on_front);
+    if (h->front && !rc) {
+        HIPCHK(h, hipEventRecord(h->ev_gl_done[parity], h->stream));
+        h->gl_pending[parity] = true;
+    }
+    return rc;
 }
 
 int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* bytes) {
