@@ -162,6 +162,45 @@ def test_pipelined_calls_equal_sequential(engine):
         engine.set_option('persistent_decoder', 1)
 
 
+def test_pipelined_calls_with_changing_shapes_equal_sequential(engine):
+    """Shapes change between back-to-back calls, so unpipelined calls (the first of every new shape) alternate with
+    pipelined ones, a stand-alone Griffin-Lim call sits in the middle, and calls of both parities use the phasor and
+    mel buffers from either stream (the initial phasors of a pipelined call are written on the front stream): every
+    waveform and spectrogram must equal the fully serialised run bit for bit."""
+    shapes = [(4, 30, 8), (4, 30, 8), (4, 30, 8), (3, 21, 6), (3, 21, 6), (4, 30, 8), (4, 30, 8), (3, 21, 6), (3, 21, 6), (3, 21, 6)]
+    batches = [bench_ids(B, Ts, 70 + i) for i, (B, Ts, S) in enumerate(shapes)]
+    inits = [np.random.default_rng(90 + i).random((B, 1025, 5 * S)).astype(np.float32) for i, (B, Ts, S) in enumerate(shapes)]
+    gl_mag = (np.random.default_rng(7).random((2, 1025, 30), dtype=np.float32) ** 3) * 4
+    gl_init = np.random.default_rng(8).random((2, 1025, 30), dtype=np.float32)
+
+    def run(pipeline):
+        engine.set_option('pipeline', pipeline)
+        dev_ids = [engine.to_device(b) for b in batches]
+        dev_init = [engine.to_device(x) for x in inits]
+        d_mag, d_gi = engine.to_device(gl_mag), engine.to_device(gl_init)
+        outs, solo = [], None
+        for i, (B, Ts, S) in enumerate(shapes):
+            outs.append(engine.synthesize(dev_ids[i], S, 6.02, 99.89, 1.3, 5, WIN, HOP, init_phase=dev_init[i],
+                                          want_mel=True, want_linear=True))
+            if i == 5:   # between two pipelined calls
+                solo, _ = engine.griffin_lim(d_mag, 4, WIN, HOP, 2048, init_phase=d_gi, want_mse=False)
+        engine.synchronize()
+        return [{k: v.to_host() for k, v in o.items() if v is not None} for o in outs], solo.to_host()
+
+    try:
+        for pd in (0, 2):
+            engine.set_option('persistent_decoder', pd)
+            seq, seq_solo = run(0)
+            pip, pip_solo = run(1)
+            assert np.array_equal(seq_solo, pip_solo), pd
+            for i, (a, b) in enumerate(zip(seq, pip)):
+                for k in a:
+                    assert np.array_equal(a[k], b[k]), (pd, i, k)
+    finally:
+        engine.set_option('pipeline', 1)
+        engine.set_option('persistent_decoder', 1)
+
+
 def test_pipelining_on_an_adopted_stream(engine):
     """tts_set_stream + pipeline = 2: calls on a caller's stream (a plain hipStream_t here, what
     torch.cuda.current_stream().cuda_stream is) overlap like those on the library's own, with identical results;
