@@ -71,3 +71,26 @@ def test_bench_self_launches_n_ranks(tmp_path):
     line = [l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1]
     rec = json.loads(line)
     assert rec['n_gpus'] == 2 and rec['world_size_seen'] == 2 and rec['ok'] is True
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's own launch line for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`): bench.py must take RANK / LOCAL_RANK / WORLD_SIZE
+    from the environment it is given instead of launching ranks of its own."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SSTTS_DIST_BACKEND='gloo')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port),
+                          os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dist-selftest'],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout.decode()
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['world_size_seen'] == 2 and rec['ok'] is True
