@@ -49,31 +49,60 @@ def synthetic_ids(B, Ts, seed):
     return ids
 
 
-def cpu_baseline(weights, hp, n_utts=6):
-    """Times the numpy oracle (a restated CPU path -- NOT TensorFlow, which cannot run here)
-    on a bounded sample: n_utts utterances, network in one process (float32), Griffin-Lim in
-    an n_utts-process pool the way the reference fans it out (tacotron/inference.py:185-188,
-    params/inference.py:34: 6 workers)."""
+def _median_time(fn, repeats):
+    """one untimed warm-up run, then the median wall time of `repeats` runs; returns (seconds, last result)"""
+    out = fn()
+    ts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        out = fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), out
+
+
+def _blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return [{'lib': i.get('internal_api'), 'threads': i.get('num_threads')} for i in threadpool_info()]
+    except Exception:   # noqa: BLE001 -- a report field, never a reason to fail the bench
+        return None
+
+
+def cpu_baseline(weights, hp, n_utts=6, repeats=3):
+    """the numpy oracle (a restated CPU path -- NOT TensorFlow, which cannot run here) on a bounded
+    sample of the bench workload, on this box's host cores: (i) the network on n_utts utterances in one process
+    (float32, the BLAS library's default thread count, reported); (ii) Griffin-Lim the way the reference fans it out
+    -- 6 worker processes, one utterance each (tacotron/inference.py:185-188, params/inference.py:34) -- and also
+    with os.cpu_count() workers on as many utterances.  One warm-up run each, then the median of `repeats`.
+    `value` = frames / (network + Griffin-Lim with the reference's 6 workers)."""
     from multiprocessing import get_context
     from oracle import tacotron_oracle as O
+    cores = os.cpu_count() or 1
     w32 = {k: np.asarray(v, np.float32) for k, v in weights.items()}
     ids = synthetic_ids(n_utts, TS, 4321)
-    t0 = time.perf_counter()
-    out = O.tacotron_predict(ids, w32, hp, n_steps=N_STEPS)
-    t_net = time.perf_counter() - t0
+    t_net, out = _median_time(lambda: O.tacotron_predict(ids, w32, hp, n_steps=N_STEPS), repeats)
     lin = out['linear'].astype(np.float32)
-    jobs = [(lin[b], b) for b in range(n_utts)]
-    t0 = time.perf_counter()
-    with get_context('fork').Pool(n_utts) as pool:
-        wavs = pool.map(_cpu_gl_job, jobs)
-    t_gl = time.perf_counter() - t0
-    assert all(w.shape == (HOP * (N_STEPS * hp.reduction - 1),) for w in wavs)
+    n_samples = HOP * (N_STEPS * hp.reduction - 1)
+
+    def gl(n_workers):
+        jobs = [(lin[b % n_utts], b) for b in range(n_workers)]
+        with get_context('fork').Pool(n_workers) as pool:
+            t, wavs = _median_time(lambda: pool.map(_cpu_gl_job, jobs), repeats)
+        assert all(w.shape == (n_samples,) for w in wavs)
+        return t
+
+    t_gl6 = gl(n_utts)
+    t_glc = gl(cores) if cores != n_utts else t_gl6
     frames = n_utts * N_STEPS * hp.reduction
-    return dict(value=frames / (t_net + t_gl), unit='mel-frames/s', cores=n_utts, kind='port',
-                sample='{} utterances end-to-end (Ts={}, {} decoder steps, {} GL iterations): numpy oracle, '
-                       'network {:.2f} s in 1 process + Griffin-Lim {:.2f} s in a {}-process pool'.format(
-                           n_utts, TS, N_STEPS, N_ITER, t_net, t_gl, n_utts),
-                griffin_lim_rtf=t_gl / (n_utts * HOP * (N_STEPS * hp.reduction - 1) / SR))
+    return dict(value=frames / (t_net + t_gl6), unit='mel-frames/s', cores=cores, kind='port',
+                sample='{} utterances end-to-end (Ts={}, {} decoder steps, {} GL iterations), numpy oracle = a restated CPU '
+                       'path, not TensorFlow; 1 warm-up + median of {}: network {:.2f} s in 1 process (BLAS threads: {}), '
+                       'Griffin-Lim {:.2f} s in the reference\'s {}-process pool; with {} workers on {} utterances {:.2f} s'.format(
+                           n_utts, TS, N_STEPS, N_ITER, repeats, t_net, _blas_threads(), t_gl6, n_utts, cores, cores, t_glc),
+                network_s=t_net, griffin_lim_s_6_workers=t_gl6, griffin_lim_s_all_cores=t_glc, gl_workers_reference=n_utts,
+                blas=_blas_threads(),
+                griffin_lim_rtf=t_gl6 / (n_utts * n_samples / SR),
+                griffin_lim_rtf_all_cores=t_glc / (cores * n_samples / SR))
 
 
 def _cpu_gl_job(args):
@@ -104,12 +133,29 @@ def self_launch(args, argv):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        # only rank 0 prints the result; the others' stdout is dropped (an unread pipe would block a chatty child)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r else None))
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    # the first rank that fails ends the run: its siblings would otherwise sit in a collective until the backend's
+    # timeout (they are the exact processes started above, ended by PID)
     rc = 0
-    for r, pr in enumerate(procs):
-        pr.wait()
-        rc = rc or pr.returncode
+    live = dict(enumerate(procs))
+    while live and rc == 0:
+        for r, pr in list(live.items()):
+            code = pr.poll()
+            if code is not None:
+                del live[r]
+                rc = rc or code
+        if live and rc == 0:
+            time.sleep(0.05)
+    for pr in live.values():
+        pr.terminate()
+    for pr in live.values():
+        try:
+            pr.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            pr.wait()
     return rc
 
 
@@ -148,6 +194,7 @@ def main():
     ap.add_argument('--hold-lds-kb', type=int, default=None)
     ap.add_argument('--persistent-decoder', type=int, default=None, help='override the library default (0 never, 1 pipelined, 2 always)')
     ap.add_argument('--gl-fused', type=int, default=None, help='override the library default (all Griffin-Lim iterations in one launch)')
+    ap.add_argument('--no-aux-outputs', action='store_true', help='A/B: do not write the linear spectrograms and alignments')
     ap.add_argument('--dist-selftest', action='store_true', help='rehearse the N > 1 launch path without GPU work')
     args = ap.parse_args()
 
@@ -194,10 +241,24 @@ def main():
         blob = Wm.pack_blob(weights, hp)
     else:
         blob = np.empty(n_floats, np.float32)
+    broadcast_ms = None
     if world > 1:
+        # the ONE collective of the path (RCCL over xGMI under "nccl"); nothing is exchanged afterwards
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit('process group has {} ranks, --gpus says {}'.format(dist.get_world_size(), args.gpus))
         bdev = 'cuda:{}'.format(local_rank) if dist.get_backend() == 'nccl' else 'cpu'
+        dist.barrier()
+        t0 = time.perf_counter()
         blob = shard.broadcast_blob(blob, src=0, device=bdev)
+        dist.barrier()
+        broadcast_ms = 1e3 * (time.perf_counter() - t0)   # includes the communicator set-up of the first collective
     eng = sstts.Engine(hp, device_id=local_rank)
+    if world > 1 and dist.get_backend() == 'nccl':
+        import torch
+        # one process per GPU: this rank's handle and its RCCL communicator sit on the same device, a different one per rank
+        if eng.device_id != local_rank or torch.cuda.current_device() != local_rank:
+            raise SystemExit('rank {}: handle on device {}, communicator on {}, LOCAL_RANK {}'.format(
+                rank, eng.device_id, torch.cuda.current_device(), local_rank))
     eng.load_weights_blob(blob)
     if args.pipeline is not None:
         eng.set_option('pipeline', args.pipeline)
@@ -219,10 +280,16 @@ def main():
     F = 1 + N_FFT // 2
     init = eng.to_device(np.random.default_rng(42 + rank).random((B, F, T), dtype=np.float32))
     wav = eng.empty((B, HOP * (T - 1)))
+    # every output north_star names is written to HBM in every timed step: the waveforms, the linear spectrograms
+    # (262 MB, an extra store of the final Dense) and the alignments into caller buffers; the mel spectrograms into the
+    # library's own pair of buffers (one per call parity -- a caller's single mel buffer would make the decoder of call
+    # k + 1 wait for the post-net of call k)
+    lin_out = None if args.no_aux_outputs else eng.empty((B, T, F))
+    ali_out = None if args.no_aux_outputs else eng.empty((N_STEPS, B, TS))
 
     def step():
         eng.synthesize(ids, N_STEPS, REF_DB, MAX_DB, POWER, N_ITER, WIN, HOP, init_phase=init,
-                       peak_normalize=True, wav=wav)
+                       peak_normalize=True, wav=wav, want_linear=lin_out, want_alignments=ali_out)
 
     def barrier():
         eng.synchronize()
@@ -306,6 +373,7 @@ def main():
             'unit': 'mel-frames/s',
             'n_gpus': world,
             'world_size_seen': dist.get_world_size() if dist is not None else 1,
+            'weight_broadcast_ms': broadcast_ms,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': ms_per_step,
@@ -321,10 +389,17 @@ def main():
             'end_to_end_rtf': ms_per_step * 1e-3 / audio_s,
             'mel_frames_per_sec_encoder_decoder': B_PER_GPU * T / ((stage_ms['encoder'] + stage_ms['decoder']) * 1e-3),
             'stage_ms': stage_ms,
+            'outputs_per_step': 'wav (peak-normalised)' + ('' if args.no_aux_outputs else ', linear spectrograms, alignments') +
+                                ', mel (library-owned double buffer); all resident in HBM, none copied to the host in the timed region',
             'roofline': {'kernel': 'gl_iter_kernel<0> (one Griffin-Lim iteration, iSTFT+STFT fused)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'launch_ms': gl_launch_ms, 'launch_ms_alone': gl_alone_ms,
                          'algorithmic_bytes_per_launch': alg_bytes,
+                         # the same launch priced on the bytes the kernel really moves (12 B per bin: 4 B phasor code in and
+                         # out, 4 B magnitude in), and on the measured HBM traffic
+                         'achieved_moved': 12.0 * F * T * B_PER_GPU / (gl_launch_ms * 1e-3) / 1e9 if gl_launch_ms > 0 else 0.0,
+                         'frac_moved': 12.0 * F * T * B_PER_GPU / (gl_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if gl_launch_ms > 0 else 0.0,
+                         'frac_traffic': (traffic / (gl_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and gl_launch_ms > 0) else None,
                          'note': 'achieved = algorithmic bytes (20 B per bin and iteration, SURVEY.md 8(d)) / launch time; the kernel '
                                  'itself moves 12 B per bin (32-bit phasor code in and out, 4 B magnitude in), which is what traffic shows'},
             'roofline_mfma': {'kernel': 'gemm_f32_kernel (post-net projection 1: conv1d k=3, 1024 -> 256, max-pool in the loader, M = {})'.format(M),

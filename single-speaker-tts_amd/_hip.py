@@ -215,6 +215,7 @@ class Engine(object):
         if rc != TTS_OK:
             raise TtsError(rc, (self.lib.tts_last_error(None) or b'').decode())
         self.handle = h
+        self.device_id = int(device_id)
         self._staging = {}
         if stream is not None:
             self._check(self.lib.tts_set_stream(self.handle, c_void_p(stream)))
@@ -381,9 +382,18 @@ class Engine(object):
         p_ids, _k1 = self._in(ids, np.int32, 'ids')
         p_init, _k2 = self._in(init_phase, np.float32, 'init_phase')
         wav = wav if wav is not None else self.empty((B, hop_length * (T - 1)))
-        mel = self.empty((B, T, self.cfg.n_mels)) if want_mel else None
-        ali = self.empty((n_steps, B, Ts)) if want_alignments else None
-        lin = self.empty((B, T, F)) if want_linear else None
+        # want_*: False, True (a fresh buffer) or a device array of the right size to write into (no allocation in the call)
+        def _out(want, shape):
+            if want is None or want is False:
+                return None
+            if want is True:
+                return self.empty(shape)
+            if int(np.prod(want.shape)) != int(np.prod(shape)):
+                raise ValueError('synthesize: output buffer of shape {} given, {} needed'.format(want.shape, shape))
+            return want
+        mel = _out(want_mel, (B, T, self.cfg.n_mels))
+        ali = _out(want_alignments, (n_steps, B, Ts))
+        lin = _out(want_linear, (B, T, F))
         self._check(self.lib.tts_synthesize(self.handle, p_ids, B, Ts, byref(sp), p_init, wav.data_ptr(),
                                             mel.data_ptr() if mel is not None else None,
                                             ali.data_ptr() if ali is not None else None,

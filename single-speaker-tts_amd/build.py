@@ -4,6 +4,7 @@
 
 hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -20,11 +21,30 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-val
 EXTRA_FLAGS = {'griffin_lim.hip': ['-fno-slp-vectorize']}
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra=()):
+    """sha256 over the CONTENT of the inputs (and the command line): what decides whether an object is rebuilt.
+    Modification times say nothing in a fresh checkout or on a box the tree was copied to."""
+    h = hashlib.sha256()
+    for e in extra:
+        h.update(e.encode() + b'\0')
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b'\0')
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stamp_ok(target, digest):
+    stamp = target + '.sha256'
+    if not (os.path.exists(target) and os.path.exists(stamp)):
+        return False
+    with open(stamp) as f:
+        return f.read().strip() == digest
+
+
+def _write_stamp(target, digest):
+    with open(target + '.sha256', 'w') as f:
+        f.write(digest + '\n')
 
 
 def build(force=False, verbose=True):
@@ -34,25 +54,37 @@ def build(force=False, verbose=True):
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     procs = []
+    digests = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace('.hip', '.o'))
+        flags = FLAGS + EXTRA_FLAGS.get(src, [])
+        d = _digest([s] + hdrs, flags)
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', s, '-o', o]
+        digests.append(d)
+        if force or not _stamp_ok(o, d):
+            cmd = [hipcc] + flags + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, p in procs:
+            procs.append((src, o, d, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, o, d, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             sys.stderr.write(out.decode(errors='replace'))
             raise RuntimeError('hipcc failed on ' + src)
-    if force or procs or _stale(LIB, objs):
+        _write_stamp(o, d)
+    # objects nobody lists any more (renamed / removed sources) must not travel to the GPU box
+    keep = {os.path.basename(o) for o in objs} | {os.path.basename(o) + '.sha256' for o in objs}
+    for f in os.listdir(objdir):
+        if f not in keep:
+            os.remove(os.path.join(objdir, f))
+    lib_digest = hashlib.sha256('\n'.join(digests).encode()).hexdigest()
+    if force or procs or not _stamp_ok(LIB, lib_digest):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+        _write_stamp(LIB, lib_digest)
     return LIB
 
 

@@ -511,21 +511,23 @@ GruOffsets pack_dec_gru(tts_handle_t h, Packer& p, const std::string& scope, int
 }
 
 // ------------------------------------------------------------------------------------ workspace
-int sync_all(tts_handle_t h) {
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->front && h->front != h->stream) HIPCHK(h, hipStreamSynchronize(h->front));
-    if (h->aux) HIPCHK(h, hipStreamSynchronize(h->aux));
+// Did every bounded wait of the persistent kernels enqueued so far end by arrival?  Both status words are STICKY on the
+// device (no launch clears them): a timeout in call j is still there when call j + 1 has been queued behind it; the
+// host clears a word when it has read it.  The caller has synchronised the streams the kernels ran on.
+int check_status(tts_handle_t h) {
     if (h->gl_fused_used) {
         h->gl_fused_used = false;
         int status = 0;
         HIPCHK(h, hipMemcpy(&status, h->gl_status, sizeof(int), hipMemcpyDeviceToHost));
-        if (status)
+        if (status) {
+            HIPCHK(h, hipMemset(h->gl_status, 0, sizeof(int)));
             return fail(h, TTS_ERR_HIP,
                         "fused Griffin-Lim: a workgroup waited for a neighbour run longer than the bound (not all "
                         "workgroups were co-resident); the waveforms of that call are invalid -- "
                         "tts_set_option(h, \"gl_fused\", 0) selects one launch per iteration");
+        }
     }
-    if (h->pd_used) {   // did every wait of the persistent decoder's last launch end by arrival?
+    if (h->pd_used) {
         h->pd_used = false;
         int status = 0;
         HIPCHK(h, hipMemcpy(&status, h->pd_sync + 64 * h->pd_clusters + 1, sizeof(int), hipMemcpyDeviceToHost));
@@ -537,6 +539,13 @@ int sync_all(tts_handle_t h) {
                         "tts_set_option(h, \"persistent_decoder\", 0) selects the launch-per-layer path");
     }
     return TTS_OK;
+}
+
+int sync_all(tts_handle_t h) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->front && h->front != h->stream) HIPCHK(h, hipStreamSynchronize(h->front));
+    if (h->aux) HIPCHK(h, hipStreamSynchronize(h->aux));
+    return check_status(h);
 }
 
 int ws_get(tts_handle_t h, const char* name, size_t bytes, void** out) {
@@ -908,11 +917,14 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
         p.n_fused = n_iter;
         p.buf[0] = ph0; p.buf[1] = ph1;
         p.done = done;
-        p.status = reinterpret_cast<int*>(done + p.n_items);
+        if (!h->gl_status) {   // sticky status word of the fused launches (check_status)
+            HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->gl_status), sizeof(int)));
+            HIPCHK(h, hipMemsetAsync(h->gl_status, 0, sizeof(int), h->stream));
+        }
+        p.status = h->gl_status;
         p.work_counter = counters;
         HIPCHK(h, launch_gl_fused(h->stream, p, free_cus));
         if (n_iter & 1) std::swap(cur, nxt);
-        h->gl_status = p.status;
         h->gl_fused_used = true;
     } else {
         ProfScope ps(h, ST_GL_ITER, n_iter);
@@ -1093,6 +1105,7 @@ int tts_destroy(tts_handle_t h) {
         hipStreamDestroy(h->aux);
     }
     if (h->hold_flags) hipFree(h->hold_flags);
+    if (h->gl_status) hipFree(h->gl_status);
     if (h->ev_aux) hipEventDestroy(h->ev_aux);
     if (h->ev_front_done) hipEventDestroy(h->ev_front_done);
     for (int i = 0; i < 2; ++i) {
@@ -1137,6 +1150,7 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     else if (!std::strcmp(key, "profile")) h->profile = value;
     else if (!std::strcmp(key, "persistent_decoder")) h->persistent_decoder = value;
     else if (!std::strcmp(key, "gl_fused")) h->gl_fused = value;
+    else if (!std::strcmp(key, "pd_debug_delay")) pd_debug_delay = value;   // tests only (decoder_persistent.hip)
     else if (!std::strcmp(key, "reserve_cus")) {
         h->reserve_cus = value;
     } else if (!std::strcmp(key, "hold_lds_kb")) {
@@ -1361,7 +1375,8 @@ int tts_memcpy_d2h(tts_handle_t h, void* dst, const void* src, size_t bytes) {
     if (h->front) HIPCHK(h, hipStreamSynchronize(h->front));   // optional outputs of a pipelined synthesize
     HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return TTS_OK;
+    // the bytes are host-visible from here on: a timed-out persistent kernel must not pass for a result
+    return check_status(h);
 }
 int tts_memset(tts_handle_t h, void* dst, int value, size_t bytes) {
     DeviceScope dev_scope(h);
@@ -1413,7 +1428,7 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
     const int A = c.n_attention_units, U = c.n_decoder_gru_units, mem = 2 * c.n_gru_units;
     const int NL = c.n_decoder_gru_layers;
     WS(h, "dec.keys", float, (size_t)B * Ts * A, keys);
-    const size_t state_floats = (size_t)B * (A + A + (size_t)NL * U);
+    const size_t state_floats = (size_t)B * (A + 2 * ((size_t)A + (size_t)NL * U));   // att | h_att, h_dec[] | their second copies
     WS(h, "dec.state", float, state_floats, state);
     WS(h, "dec.tmp", float, (size_t)B * (c.dec_prenet_units[0] + c.dec_prenet_units[1] + 6 * (size_t)U), tmp);
     WS(h, "dec.ctx_parts", float, (size_t)TTS_ATT_PARTS * B * mem, ctx_parts);
@@ -1427,6 +1442,11 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
     sc.att = state;
     sc.h_att = state + (size_t)B * A;
     for (int l = 0; l < NL; ++l) sc.h_dec[l] = state + (size_t)B * (2 * A + (size_t)l * U);
+    {
+        float* alt = state + (size_t)B * (2 * A + (size_t)NL * U);
+        sc.h_att_alt = alt;
+        for (int l = 0; l < NL; ++l) sc.h_dec_alt[l] = alt + (size_t)B * (A + (size_t)l * U);
+    }
     float* t = tmp;
     sc.p1 = t; t += (size_t)B * c.dec_prenet_units[0];
     sc.p2 = t; t += (size_t)B * c.dec_prenet_units[1];

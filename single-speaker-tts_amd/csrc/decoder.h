@@ -57,6 +57,7 @@ struct DecoderScratch {
     float* state;        // att | h_att | h_dec[0..n_layers) contiguous, zeroed per call
     size_t state_bytes;
     float* att; float* h_att; float* h_dec[4];
+    float* h_att_alt; float* h_dec_alt[4];   // second copies of the states (persistent decoder: double-buffered by step parity)
     float* p1; float* p2; float* rh; float* u; float* hh; float* xi; float* y0; float* y1;
     float* ctx_parts;    // [TTS_ATT_PARTS][B][mem]
     float* att_stats;    // [n_steps][B][TTS_ATT_PARTS][2]
@@ -81,7 +82,9 @@ struct PdParams {
     const float* al_w;                            // attention layer
     const float *g_gw[2], *g_gb[2], *g_cw[2], *g_cb[2];
     const float *memory, *keys;                   // [B][Ts][256]
-    float *att, *h_att, *h_dec[2], *p1, *p2, *rh, *ctx, *y0, *yhist;   // hand-off buffers [B][.] (state zeroed per call)
+    float *att, *p1, *p2, *rh, *ctx, *y0, *yhist;   // hand-off buffers [B][.] (state zeroed per call)
+    float *h_att2[2], *h_dec2[2][2];              // recurrent states, double-buffered by step parity (zeroed per call)
+    int dbg_delay;                                // tests only: workgroup 3 of every cluster sleeps this long before it stages
     float* align;                                 // [n_steps][B][Ts] or null
     unsigned* counters;                           // [clusters][64]: one arrival counter per cluster, zeroed per call
     unsigned* resident;                           // workgroups that have started
@@ -97,6 +100,7 @@ struct PdParams {
 bool decoder_persistent_supports(const DecoderWeights& w, int cudnn, int B, int Ts);
 int decoder_persistent_workgroups(int B);         // compute units the launch needs all to itself
 hipError_t decoder_persistent_configure();        // per device
+extern int pd_debug_delay;                        // tests only (tts_set_option "pd_debug_delay"): see PdParams::dbg_delay
 // `sync`: 64 * ceil(B / 16) + 2 unsigned words
 hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, const DecoderScratch& sc, const float* memory,
                                       const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync,

@@ -44,6 +44,8 @@ namespace tts {
 #define PD_VB 4
 #endif
 
+int pd_debug_delay = 0;
+
 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned pd_u32x4;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t pd_rsrc(const void* p) {
@@ -85,6 +87,7 @@ struct PdPhase {
     int more;                            // a `cont` phase follows: nothing to publish yet
     int ub;                              // units of this layer owned per workgroup (32 or 16)
     int epi, act, layer;
+    int delay;                           // tests only: workgroup 3 sleeps delay x ~3.4 us between the wait and the staging
     float* out; int ldo;                 // PD_ACT: activations; PD_GATES: r*h; PD_CAND: new state h
     float* yout; int ldy;                // PD_CAND with residual: y = x + h'
 };
@@ -186,6 +189,8 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, int j, i
     PD_STAMP(0)
     if (!ph.cont) pd_wait(cnt, target, status, ctrl);
     PD_STAMP(1)
+    if (ph.delay && !ph.cont && j == 3)   // a late stager: what a workgroup that clears its poll late looks like to its peers
+        for (int i = 0; i < ph.delay; ++i) __builtin_amdgcn_s_sleep(127);
 
     // ---- stage the cluster's A tile (16 rows x K) in LDS: sc1 loads of the handed-off activations.  K <= 512: at most
     // two float4 per thread, BOTH requested before either is written to LDS (written as a loop of load-then-store the
@@ -514,6 +519,12 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
     const int yld = p.n_steps * PD_D;
     unsigned g = 0;   // phases completed by the cluster
     for (int t = 0; t < p.n_steps; ++t) {
+        // The recurrent states are double-buffered by step parity: step t reads h[t & 1] and writes h[(t + 1) & 1].
+        // In the CudnnCompatibleGRUCell form the candidate phase continues on the staged tile without a wait, so a
+        // workgroup stores its slice of h' while a peer that left the previous wait a little later may still be staging
+        // the full previous h: with one buffer that peer would read a mix of h_{t-1} and h_t.
+        const float* h_att_old = p.h_att2[t & 1];
+        float* h_att_new = p.h_att2[(t + 1) & 1];
         // ONE instance of the phase body in a loop over the step's ten phases (ten inlined copies spill)
 #pragma nounroll
         for (int k = 0; k < 10; ++k) {
@@ -526,14 +537,15 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
                 lc.wp = p.local_wp; lc.vp = p.local_vp; lc.p_hist_t = p.p_hist ? p.p_hist + (size_t)t * p.B : nullptr;
                 lc.err_flag = p.err_flag;
                 float* align_t = p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr;
-                if (p.local_d > 0) pd_attention_local(p.h_att, p.keys, p.memory, p.ctx, align_t, p.Ts, lds, j, b0, p.B, cnt, PD_W * g, p.status, lc);
-                else pd_attention_body<false>(p.h_att, p.keys, p.memory, p.ctx, align_t, p.Ts, lds, j, b0, p.B, cnt, PD_W * g, p.status, lc);
+                if (p.local_d > 0) pd_attention_local(h_att_new, p.keys, p.memory, p.ctx, align_t, p.Ts, lds, j, b0, p.B, cnt, PD_W * g, p.status, lc);
+                else pd_attention_body<false>(h_att_new, p.keys, p.memory, p.ctx, align_t, p.Ts, lds, j, b0, p.B, cnt, PD_W * g, p.status, lc);
                 ++g;
                 continue;
             }
             PdPhase ph;
             ph.lda0 = PD_D; ph.k0 = PD_D; ph.lda1 = PD_D; ph.K = 2 * PD_D; ph.ub = 32; ph.act = ACT_NONE; ph.layer = 0;
             ph.ldo = PD_D; ph.yout = nullptr; ph.ldy = PD_D; ph.bias = nullptr; ph.row0 = 0; ph.cont = 0; ph.more = 0;
+            ph.delay = p.dbg_delay;
             switch (k) {
                 case 0:
                     // PrenetWrapper on concat([x_t, attention_{t-1}]) (wrappers.py:122-124); x_0 = GO frame = zeros
@@ -548,21 +560,21 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
                     ph.epi = PD_ACT; ph.act = ACT_RELU; ph.out = p.p2; ph.ldo = PD_P2;
                     break;
                 case 2:   // attention GRU (model.py:226-229): gates on [p2 ; h_att]
-                    ph.a0 = p.p2; ph.lda0 = PD_P2; ph.k0 = PD_P2; ph.a1 = p.h_att; ph.K = PD_P2 + PD_D;
+                    ph.a0 = p.p2; ph.lda0 = PD_P2; ph.k0 = PD_P2; ph.a1 = h_att_old; ph.K = PD_P2 + PD_D;
                     ph.Wt = p.ag_w; ph.bias = p.ag_b; ph.epi = p.cudnn ? PD_CUDNN_RU : PD_GATES; ph.out = p.rh; ph.more = p.cudnn;
                     break;
                 case 3:   // ... candidate (GRUCell: on [p2 ; r*h_att], after a hop); the new state is the attention query
                     ph.a0 = p.p2; ph.lda0 = PD_P2; ph.k0 = PD_P2; ph.a1 = p.rh; ph.K = PD_P2 + PD_D;
-                    ph.Wt = p.cudnn ? p.ag_w : p.ac_w; ph.bias = p.cudnn ? p.ag_b : p.ac_b; ph.out = p.h_att;
+                    ph.Wt = p.cudnn ? p.ag_w : p.ac_w; ph.bias = p.cudnn ? p.ag_b : p.ac_b; ph.out = h_att_new;
                     ph.epi = p.cudnn ? PD_CUDNN_HX : PD_CAND; ph.row0 = p.cudnn ? 2 * PD_D : 0; ph.cont = p.cudnn;
                     break;
                 case 5:   // attention_layer(concat([cell_output, context])), no bias
-                    ph.a0 = p.h_att; ph.a1 = p.ctx; ph.Wt = p.al_w; ph.epi = PD_ACT; ph.out = p.att;
+                    ph.a0 = h_att_new; ph.a1 = p.ctx; ph.Wt = p.al_w; ph.epi = PD_ACT; ph.out = p.att;
                     break;
                 default: {   // 6..9: two ResidualWrapper(GRU cell) layers (model.py:254-269); the top one writes the y history
                     const int l = (k - 6) >> 1;
                     const bool second = (k - 6) & 1;
-                    ph.a0 = l == 0 ? p.att : p.y0; ph.a1 = (second && !p.cudnn) ? p.rh : p.h_dec[l];
+                    ph.a0 = l == 0 ? p.att : p.y0; ph.a1 = (second && !p.cudnn) ? p.rh : p.h_dec2[l][t & 1];
                     ph.layer = 1 + l;
                     if (p.cudnn) {
                         ph.Wt = p.g_gw[l]; ph.bias = p.g_gb[l];
@@ -572,7 +584,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
                         ph.Wt = second ? p.g_cw[l] : p.g_gw[l]; ph.bias = second ? p.g_cb[l] : p.g_gb[l];
                         ph.epi = second ? PD_CAND : PD_GATES;
                     }
-                    ph.out = second ? p.h_dec[l] : p.rh;
+                    ph.out = second ? p.h_dec2[l][(t + 1) & 1] : p.rh;
                     if (second) { ph.yout = l == 0 ? p.y0 : p.yhist + (size_t)t * PD_D; ph.ldy = l == 0 ? PD_D : yld; }
                 } break;
             }
@@ -618,10 +630,12 @@ hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, co
     p.al_w = w.attn_layer_wt;
     for (int l = 0; l < 2; ++l) {
         p.g_gw[l] = w.gru[l].gates_wt; p.g_gb[l] = w.gru[l].gates_b; p.g_cw[l] = w.gru[l].cand_wt; p.g_cb[l] = w.gru[l].cand_b;
-        p.h_dec[l] = sc.h_dec[l];
+        p.h_dec2[l][0] = sc.h_dec[l]; p.h_dec2[l][1] = sc.h_dec_alt[l];
     }
+    p.h_att2[0] = sc.h_att; p.h_att2[1] = sc.h_att_alt;
+    p.dbg_delay = pd_debug_delay;
     p.memory = memory; p.keys = keys;
-    p.att = sc.att; p.h_att = sc.h_att; p.p1 = sc.p1; p.p2 = sc.p2; p.rh = sc.rh; p.ctx = sc.ctx_parts; p.y0 = sc.y0;
+    p.att = sc.att; p.p1 = sc.p1; p.p2 = sc.p2; p.rh = sc.rh; p.ctx = sc.ctx_parts; p.y0 = sc.y0;
     p.yhist = sc.yhist; p.align = align;
     p.counters = sync; p.resident = sync + 64 * clusters; p.status = reinterpret_cast<int*>(sync + 64 * clusters + 1);
     p.hold_flag = hold_flag;

@@ -11,7 +11,10 @@ where ``checkpoint_file`` is either an explicit prefix or ``tf.train.latest_chec
   ``checkpoint``                     a text CheckpointState: ``model_checkpoint_path: "<prefix>"``
 
 This module parses those three files with the standard library + numpy and maps the variables onto
-the manifest of :mod:`.weights`.  No checkpoint ships with the reference (README.md:357-361), so the
+the manifest of :mod:`.weights`.  Like ``Saver.restore`` it VERIFIES what it reads: the masked CRC-32C of
+every table block (LevelDB block trailer, TF table/format.cc ReadBlock) and of every tensor's bytes
+(BundleEntryProto.crc32c, TF tensor_bundle.cc BundleReader::GetValue); a mismatch raises
+:class:`ChecksumError` -- a corrupt checkpoint must not load silently.  No checkpoint ships with the reference (README.md:357-361), so the
 parser is validated against a writer of the same published format in the tests, not against a file
 produced by TensorFlow.
 """
@@ -26,6 +29,88 @@ from .weights import manifest
 
 TABLE_MAGIC = 0xdb4775248b80fb57
 _DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64}   # tensorflow/core/framework/types.proto
+
+
+class ChecksumError(ValueError):
+    """A stored CRC-32C does not match the bytes read (TensorFlow: DataLoss 'Checksum does not match')."""
+
+
+# ------------------------------------------------------------------------------------------ CRC-32C (Castagnoli)
+def _crc_table():
+    t = np.arange(256, dtype=np.uint32)
+    for _ in range(8):
+        t = np.where(t & 1, (t >> 1) ^ np.uint32(0x82F63B78), t >> 1).astype(np.uint32)
+    return t
+
+
+_CRC_TAB = _crc_table()
+_CRC_TAB_LIST = [int(v) for v in _CRC_TAB]
+
+
+def _crc_raw(data, reg):
+    """The CRC register after `data` (bytes-like), starting from `reg`; no pre- / post-conditioning."""
+    tab = _CRC_TAB_LIST
+    for b in data:
+        reg = tab[(reg ^ b) & 0xFF] ^ (reg >> 8)
+    return reg
+
+
+def _gf2_times(mat, vec):
+    out = 0
+    i = 0
+    while vec:
+        if vec & 1:
+            out ^= mat[i]
+        vec >>= 1
+        i += 1
+    return out
+
+
+def _zero_shift_matrix(n_bytes):
+    """32x32 GF(2) matrix (as 32 column words) that advances the CRC register through n_bytes zero bytes."""
+    m = [_crc_raw(b'\0', 1 << i) for i in range(32)]           # one zero byte
+    result = [1 << i for i in range(32)]                       # identity
+    while n_bytes:
+        if n_bytes & 1:
+            result = [_gf2_times(m, c) for c in result]
+        m = [_gf2_times(m, c) for c in m]
+        n_bytes >>= 1
+    return result
+
+
+def crc32c(data):
+    """CRC-32C of a bytes-like object (RFC 3720 check value: crc32c(b'123456789') == 0xE3069283).
+
+    A checkpoint's tensors are tens of megabytes and the register recurrence is byte-serial, so long inputs are cut
+    into K equal segments whose registers advance in lockstep as one numpy vector (the CRC is linear over GF(2):
+    register(A || B, r) = register(B, 0) xor shift_{|B|}(register(A, r))), and the K partial registers are folded
+    with the zero-shift matrix of one segment length."""
+    buf = np.frombuffer(bytes(data) if not isinstance(data, (bytes, bytearray, memoryview, np.ndarray)) else data, dtype=np.uint8)
+    n = buf.size
+    if n < 1 << 14:
+        return _crc_raw(buf.tolist(), 0xFFFFFFFF) ^ 0xFFFFFFFF
+    # init 0xFFFFFFFF == init 0 on the message with its first four bytes inverted; leading zero bytes leave a zero
+    # register untouched, so the message may be padded IN FRONT to a whole number of segments
+    K = 4096 if n >= 1 << 20 else 256
+    seg = -(-n // K)
+    m = np.zeros(K * seg, dtype=np.uint8)
+    m[K * seg - n:] = buf
+    m[K * seg - n:K * seg - n + 4] ^= 0xFF
+    cols = m.reshape(K, seg).T.astype(np.uint32)               # cols[i] = byte i of every segment
+    reg = np.zeros(K, dtype=np.uint32)
+    for i in range(seg):
+        reg = _CRC_TAB[(reg ^ cols[i]) & 0xFF] ^ (reg >> 8)
+    shift = _zero_shift_matrix(seg)
+    r = 0
+    for part in reg.tolist():
+        r = _gf2_times(shift, r) ^ part
+    return r ^ 0xFFFFFFFF
+
+
+def unmask_crc(masked):
+    """Inverse of TF / LevelDB crc32c::Mask: rotate right by 15 bits and add 0xa282ead8."""
+    rot = (masked - 0xa282ead8) & 0xFFFFFFFF
+    return ((rot >> 17) | (rot << 15)) & 0xFFFFFFFF
 
 
 # ------------------------------------------------------------------------------------------ varints / protobuf
@@ -102,9 +187,14 @@ def _block_handle(buf, pos):
     return off, size, pos
 
 
-def _read_block(data, off, size):
+def _read_block(data, off, size, path='table'):
+    if off + size + 5 > len(data):
+        raise ValueError('{}: block [{}, +{}) runs past the end of the file'.format(path, off, size))
     block = data[off:off + size]
     ctype = data[off + size]
+    stored = unmask_crc(struct.unpack('<I', data[off + size + 1:off + size + 5])[0])
+    if crc32c(data[off:off + size + 1]) != stored:            # contents + type byte (table_format.md, block trailer)
+        raise ChecksumError('{}: block checksum mismatch at offset {}'.format(path, off))
     if ctype != 0:
         raise NotImplementedError('compressed SSTable blocks are not supported (TF writes the bundle index uncompressed)')
     n_restarts = struct.unpack('<I', block[-4:])[0]
@@ -133,15 +223,16 @@ def read_table(path):
     _mo, _ms, pos = _block_handle(footer, 0)
     io, isz, _ = _block_handle(footer, pos)
     out = []
-    for _key, handle in _read_block(data, io, isz):
+    for _key, handle in _read_block(data, io, isz, path):
         bo, bs, _ = _block_handle(handle, 0)
-        out.extend(_read_block(data, bo, bs))
+        out.extend(_read_block(data, bo, bs, path))
     return out
 
 
 # ------------------------------------------------------------------------------------------ tensor bundle
-def read_tensor_bundle(prefix):
-    """{variable name: ndarray} of a TF V2 checkpoint ``prefix`` (no TensorFlow needed)."""
+def read_tensor_bundle(prefix, verify=True):
+    """{variable name: ndarray} of a TF V2 checkpoint ``prefix`` (no TensorFlow needed).  ``verify``: check every
+    tensor's bytes against the masked CRC-32C its index entry stores (always on in load_checkpoint)."""
     entries = read_table(prefix + '.index')
     num_shards = 1
     tensors = {}
@@ -165,8 +256,12 @@ def read_tensor_bundle(prefix):
         if sid not in shards:
             shards[sid] = np.memmap('{}.data-{:05d}-of-{:05d}'.format(prefix, sid, num_shards), dtype=np.uint8, mode='r')
         dt = np.dtype(_DTYPES[e['dtype']]).newbyteorder('<')
-        raw = shards[sid][e['offset']:e['offset'] + e['size']]
-        arr = np.frombuffer(raw.tobytes(), dtype=dt).reshape(e['shape'])
+        if e['offset'] + e['size'] > shards[sid].size:
+            raise ValueError('{}: tensor {} runs past the end of its data shard'.format(prefix, name))
+        raw = shards[sid][e['offset']:e['offset'] + e['size']].tobytes()
+        if verify and e['crc32c'] is not None and crc32c(raw) != unmask_crc(e['crc32c']):
+            raise ChecksumError('{}: checksum of tensor {} does not match its bytes'.format(prefix, name))
+        arr = np.frombuffer(raw, dtype=dt).reshape(e['shape'])
         tensors[name] = arr
     return tensors
 
@@ -220,8 +315,8 @@ def cudnn_gru_opaque_to_canonical(opaque, input_size, num_units, bidirectional=T
     n_w = 3 * num_units * input_size + 3 * num_units * num_units
     n_b = 6 * num_units
     need = len(dirs) * (n_w + n_b)
-    if opaque.size < need:
-        raise ValueError('opaque CudnnGRU buffer has {} floats, a {}-directional {}->{} layer needs {}'.format(
+    if opaque.size != need:   # a buffer of other dimensions would be sliced into wrong matrices without any error
+        raise ValueError('opaque CudnnGRU buffer has {} floats, a {}-directional {}->{} layer has {}'.format(
             opaque.size, len(dirs), input_size, num_units, need))
     out = {}
     for di, d in enumerate(dirs):
@@ -252,8 +347,11 @@ def expand_cudnn_gru(tensors, hparams=None):
             continue
         m = _CUDNN_OPAQUE.match(name)
         if m:
-            # input of the bi-GRU = the highway width, units = n_gru_units (reference layers.py:555-566)
-            canon = cudnn_gru_opaque_to_canonical(arr, hp.encoder.n_highway_units, hp.encoder.n_gru_units, True)
+            # input of the bi-GRU = the highway width, units = n_gru_units (reference layers.py:555-566) -- of the
+            # CBHG the buffer belongs to: the post-processing net has its own sizes (model.py:336-352)
+            scope = m.group('scope')
+            cb = hp.post if (scope.startswith('post') or '/post' in scope) else hp.encoder
+            canon = cudnn_gru_opaque_to_canonical(arr, cb.n_highway_units, cb.n_gru_units, True)
             for d, parts in canon.items():
                 for suffix, v in parts.items():
                     out['{}/gru/{}/gru_cell_{}/{}'.format(m.group('scope'), d, d, suffix)] = v

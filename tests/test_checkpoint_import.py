@@ -6,11 +6,62 @@ import numpy as np
 import pytest
 
 from conftest import pkg
-from tf_bundle_writer import crc32c, write_tensor_bundle
+from tf_bundle_writer import crc32c, masked_crc, write_tensor_bundle
 
 
 def test_crc32c_known_answer():
-    assert crc32c(b'123456789') == 0xE3069283        # RFC 3720 check value
+    """Both CRC-32C implementations (the writer's byte loop, the importer's segment-parallel one) against the
+    published vectors of RFC 3720 (B.4) and against each other across the importer's size thresholds."""
+    C = pkg('tacotron.checkpoint')
+    vectors = [(b'123456789', 0xE3069283), (bytes(32), 0x8A9136AA), (b'\xff' * 32, 0x62A8AB43),
+               (bytes(range(32)), 0x46DD794E), (bytes(range(31, -1, -1)), 0x113FDB5C)]
+    for data, want in vectors:
+        assert crc32c(data) == want and C.crc32c(data) == want
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 3, 4, 5, 1000, (1 << 14) - 1, 1 << 14, (1 << 14) + 1, 70001, (1 << 20) + 13):
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert C.crc32c(d) == crc32c(d), n
+        assert C.unmask_crc(masked_crc(d)) == crc32c(d)
+
+
+def test_corrupt_checkpoints_are_refused(tmp_path):
+    """What Saver.restore does with a damaged file (tacotron/inference.py:55,71 -> DataLoss): one flipped bit in a
+    tensor's bytes or in an index block must raise, in whichever data shard it sits; restart arrays with several
+    entries and several data shards parse."""
+    C = pkg('tacotron.checkpoint')
+    rng = np.random.default_rng(1)
+    tensors = {'scope/v{:02d}/kernel'.format(i): rng.standard_normal((5, 3 + i)).astype(np.float32) for i in range(23)}
+    tensors['global_step'] = np.array(7, dtype=np.int64)
+    prefix = str(tmp_path / 'm')
+    write_tensor_bundle(prefix, tensors, block_entries=9, num_shards=3, restart_interval=2)
+    assert sorted(f.name for f in tmp_path.iterdir()) == ['m.data-00000-of-00003', 'm.data-00001-of-00003',
+                                                          'm.data-00002-of-00003', 'm.index']
+    got = C.read_tensor_bundle(prefix)
+    assert set(got) == set(tensors) and all(np.array_equal(got[k], tensors[k]) for k in tensors)
+    # a flipped bit in the second data shard
+    shard = tmp_path / 'm.data-00001-of-00003'
+    raw = bytearray(shard.read_bytes())
+    raw[len(raw) // 2] ^= 0x10
+    shard.write_bytes(bytes(raw))
+    with pytest.raises(C.ChecksumError, match='tensor'):
+        C.read_tensor_bundle(prefix)
+    assert set(C.read_tensor_bundle(prefix, verify=False)) == set(tensors)      # (the escape hatch reads the damaged bytes)
+    raw[len(raw) // 2] ^= 0x10
+    shard.write_bytes(bytes(raw))
+    C.read_tensor_bundle(prefix)
+    # a flipped bit inside an index block (here: in a key of the first data block)
+    index = tmp_path / 'm.index'
+    good = index.read_bytes()
+    bad = bytearray(good)
+    bad[40] ^= 0x01
+    index.write_bytes(bytes(bad))
+    with pytest.raises(C.ChecksumError, match='block'):
+        C.read_tensor_bundle(prefix)
+    # a wrong stored tensor checksum with intact bytes
+    index.write_bytes(good)
+    entries = dict(C.read_table(prefix + '.index'))
+    e = C._parse_bundle_entry(entries[b'scope/v03/kernel'])
+    assert C.unmask_crc(e['crc32c']) == crc32c(tensors['scope/v03/kernel'].tobytes())
 
 
 def test_bundle_round_trip(tmp_path):
@@ -43,7 +94,7 @@ def test_latest_checkpoint_and_model_variable_selection(tmp_path, weights, hpara
     ck['beta1_power'] = np.array(0.1, dtype=np.float32)
     ck['dense/kernel/Adam'] = np.zeros_like(weights['dense/kernel'])
     ck['dense/kernel/Adam_1'] = np.zeros_like(weights['dense/kernel'])
-    write_tensor_bundle(str(run / 'model.ckpt-215000'), ck, block_entries=16)
+    write_tensor_bundle(str(run / 'model.ckpt-215000'), ck, block_entries=16, num_shards=2, crc_fn=C.crc32c)
     (run / 'checkpoint').write_text('model_checkpoint_path: "model.ckpt-215000"\n'
                                     'all_model_checkpoint_paths: "model.ckpt-210000"\n'
                                     'all_model_checkpoint_paths: "model.ckpt-215000"\n')
@@ -53,14 +104,14 @@ def test_latest_checkpoint_and_model_variable_selection(tmp_path, weights, hpara
     assert all(np.array_equal(got[k], weights[k]) for k in weights)
     # a scope spelled differently in the checkpoint can be aliased; a missing variable is an error
     renamed = {('decoder/memory_layer/kernel' if k == 'decoder2/memory_layer/kernel' else k): v for k, v in weights.items()}
-    write_tensor_bundle(str(tmp_path / 'other'), renamed, block_entries=16)
+    write_tensor_bundle(str(tmp_path / 'other'), renamed, block_entries=16, crc_fn=C.crc32c)
     with pytest.raises(KeyError):
         C.load_checkpoint(str(tmp_path / 'other'), hparams)
     ok = C.load_checkpoint(str(tmp_path / 'other'), hparams, aliases={'decoder/memory_layer/kernel': 'decoder2/memory_layer/kernel'})
     assert np.array_equal(ok['decoder2/memory_layer/kernel'], weights['decoder2/memory_layer/kernel'])
     bad = dict(weights)
     bad['dense/bias'] = np.zeros(7, np.float32)
-    write_tensor_bundle(str(tmp_path / 'bad'), bad, block_entries=16)
+    write_tensor_bundle(str(tmp_path / 'bad'), bad, block_entries=16, crc_fn=C.crc32c)
     with pytest.raises(ValueError):
         C.load_checkpoint(str(tmp_path / 'bad'), hparams)
 
@@ -120,7 +171,7 @@ def test_cudnn_checkpoints_load_in_both_saved_forms(tmp_path):
                         scope, d, k[len(pre):])
         canon[k] = v
     assert not any('/gru_cell_fw/' in k and k.startswith('encoder/gru') for k in canon)
-    write_tensor_bundle(str(tmp_path / 'canon'), canon, block_entries=16)
+    write_tensor_bundle(str(tmp_path / 'canon'), canon, block_entries=16, crc_fn=C.crc32c)
     got = C.load_checkpoint(str(tmp_path / 'canon'), hp)
     assert set(got) == set(weights) and all(np.array_equal(got[k], weights[k]) for k in weights)
     # (2) opaque buffers, built by inverting the documented layout
@@ -138,7 +189,7 @@ def test_cudnn_checkpoints_load_in_both_saved_forms(tmp_path):
             bs += [np.concatenate([gb[:H], gb[H:], weights[pre + 'candidate/input_projection/bias']]),
                    np.concatenate([np.zeros(2 * H, np.float32), weights[pre + 'candidate/hidden_projection/bias']])]
         opaque['{}/gru/cudnn_gru/opaque_kernel'.format(scope)] = np.concatenate(ws + bs).astype(np.float32)
-    write_tensor_bundle(str(tmp_path / 'opaque'), opaque, block_entries=16)
+    write_tensor_bundle(str(tmp_path / 'opaque'), opaque, block_entries=16, crc_fn=C.crc32c)
     got = C.load_checkpoint(str(tmp_path / 'opaque'), hp)
     assert set(got) == set(weights) and all(np.array_equal(got[k], weights[k]) for k in weights)
     # the GRUCell configuration cannot take such a checkpoint: the error says why

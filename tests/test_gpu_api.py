@@ -197,46 +197,71 @@ def test_serve_helpers(weights, tmp_path):
     assert len(first) == 2 and len(second) == 1 and first[0].shape == (275 * 19,) and np.isfinite(first[1]).all()
 
 
-@pytest.mark.parametrize('cudnn', [False, True])
-def test_weights_through_the_checkpoint_importer_equal_the_dict_path(tmp_path, cudnn):
-    """load_checkpoint -> tts_set_weight gives bit-identical results to handing the same tensors over directly,
-    for the GRUCell layout and for a force_cudnn checkpoint that stores the CBHG bi-GRUs the way CudnnGRUSaveable
-    does (reference tacotron/inference.py:44-55,71; layers.py:560-577)."""
+@pytest.mark.parametrize('form', ['grucell', 'cudnn_canonical', 'cudnn_opaque'])
+def test_weights_through_the_checkpoint_importer_match_the_oracle(tmp_path, form):
+    """bundle on disk -> load_checkpoint (checksums verified) -> tts_set_weight -> HIP forward pass, compared with the
+    ORACLE run on the original weight dictionary (not with a second HIP run): the GRUCell layout, and force_cudnn
+    checkpoints that store the CBHG bi-GRUs the way CudnnGRUSaveable does or as the raw opaque cuDNN buffer
+    (reference tacotron/inference.py:44-55,71; layers.py:560-577).  Two data shards, several restarts per block."""
     import copy
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from tf_bundle_writer import write_tensor_bundle
+    from oracle import tacotron_oracle as O
+    from conftest import rel_l2
     C = pkg('tacotron.checkpoint')
     W = pkg('tacotron.weights')
     hp = copy.deepcopy(pkg('tacotron.params').ModelParams())
+    cudnn = form != 'grucell'
     hp.force_cudnn = cudnn
     weights = W.synthetic_weights(5, hp)
+    U, H = hp.encoder.n_highway_units, hp.encoder.n_gru_units
     ck = {}
     for k, v in weights.items():
-        if cudnn:
-            for scope in ('encoder', 'post_process'):
-                for d in ('fw', 'bw'):
-                    pre = '{}/gru/{}/gru_cell_{}/'.format(scope, d, d)
-                    if k.startswith(pre):
-                        k = '{}/gru/cudnn_gru/stack_bidirectional_rnn/cell_0/bidirectional_rnn/{}/cudnn_compatible_gru_cell/{}'.format(
-                            scope, d, k[len(pre):])
+        cb_gru = None
+        for scope in ('encoder', 'post_process'):
+            for d in ('fw', 'bw'):
+                pre = '{}/gru/{}/gru_cell_{}/'.format(scope, d, d)
+                if cudnn and k.startswith(pre):
+                    cb_gru = (scope, d, k[len(pre):])
+        if cb_gru and form == 'cudnn_canonical':
+            k = '{}/gru/cudnn_gru/stack_bidirectional_rnn/cell_0/bidirectional_rnn/{}/cudnn_compatible_gru_cell/{}'.format(*cb_gru)
+        elif cb_gru:
+            continue                                   # goes into the opaque buffer below
         ck[k] = v
+    if form == 'cudnn_opaque':
+        for scope in ('encoder', 'post_process'):
+            ws, bs = [], []
+            for d in ('fw', 'bw'):
+                pre = '{}/gru/{}/gru_cell_{}/'.format(scope, d, d)
+                gk, gb = weights[pre + 'gates/kernel'], weights[pre + 'gates/bias']
+                wi = [gk[:U, :H].T, gk[:U, H:].T, weights[pre + 'candidate/input_projection/kernel'].T]
+                wr = [gk[U:, :H].T, gk[U:, H:].T, weights[pre + 'candidate/hidden_projection/kernel'].T]
+                ws += [np.concatenate([m.reshape(-1) for m in wi]), np.concatenate([m.reshape(-1) for m in wr])]
+                bs += [np.concatenate([gb[:H], gb[H:], weights[pre + 'candidate/input_projection/bias']]),
+                       np.concatenate([np.zeros(2 * H, np.float32), weights[pre + 'candidate/hidden_projection/bias']])]
+            ck['{}/gru/cudnn_gru/opaque_kernel'.format(scope)] = np.concatenate(ws + bs).astype(np.float32)
     ck['global_step'] = np.array(215000, dtype=np.int64)
+    ck['dense/kernel/Adam'] = np.zeros_like(weights['dense/kernel'])
     run = tmp_path / 'run'
     run.mkdir()
-    write_tensor_bundle(str(run / 'model.ckpt-215000'), ck, block_entries=16)
+    write_tensor_bundle(str(run / 'model.ckpt-215000'), ck, block_entries=16, num_shards=2, restart_interval=4, crc_fn=C.crc32c)
     (run / 'checkpoint').write_text('model_checkpoint_path: "model.ckpt-215000"\n')
     loaded = C.load_checkpoint(str(run), hp)
-    ids = np.random.default_rng(0).integers(2, 39, (2, 11)).astype(np.int32)
+    B, Ts, S = 2, 11, 6
+    ids = np.random.default_rng(0).integers(2, 39, (B, Ts)).astype(np.int32)
     ids[:, -1] = 1
-    outs = []
-    for w in (weights, loaded):
-        eng = pkg().Engine(hp)
-        eng.load_weights(w)
-        mem = eng.encoder_forward(ids)
-        mel, al = eng.decoder_forward(mem, 6)
-        lin = eng.postnet_forward(mel.to_host().reshape(2, 30, 80))
-        outs.append((mem.to_host(), mel.to_host(), al.to_host(), lin.to_host()))
-        eng.close()
-    for a, b in zip(*outs):
-        assert np.array_equal(a, b)
+    w64 = {k: v.astype(np.float64) for k, v in weights.items()}
+    ref_mem = O.encoder(ids, w64, hp)
+    ref_mel, ref_al = O.decoder(ref_mem, w64, hp, n_steps=S)
+    ref_lin = O.post_process(ref_mel.reshape(B, -1, hp.n_mels), w64, hp)
+    eng = pkg().Engine(hp)
+    eng.load_weights(loaded)
+    mem = eng.encoder_forward(ids)
+    mel, al = eng.decoder_forward(mem, S)
+    lin = eng.postnet_forward(mel.to_host().reshape(B, S * hp.reduction, hp.n_mels))
+    errs = dict(memory=rel_l2(mem.to_host().reshape(-1), ref_mem.reshape(-1)), mel=rel_l2(mel.to_host().reshape(-1), ref_mel.reshape(-1)),
+                align=float(np.abs(al.to_host().reshape(-1) - ref_al.reshape(-1)).max()), linear=rel_l2(lin.to_host().reshape(-1), ref_lin.reshape(-1)))
+    eng.close()
+    print('importer ({}) vs oracle: {}'.format(form, errs))
+    assert errs['memory'] < 1e-4 and errs['mel'] < 1e-3 and errs['align'] < 1e-4 and errs['linear'] < 1e-3, errs

@@ -39,7 +39,7 @@ def test_griffin_lim_few_iterations(engine, B, T, n_iter):
         e = rel_l2(wav[b], ref_wav)
         print('GL B={} T={} it={} b={}: wav rel-L2 {:.3e} mse {} vs {}'.format(B, T, n_iter, b, e, mse[b], ref_mse))
         assert wav[b].shape == ref_wav.shape
-        assert e < 1e-4 * max(1, n_iter) * 3
+        assert e < 1e-4 * max(1, n_iter)   # one iteration from identical phases <= 1e-4
         if n_iter > 0:
             assert abs(mse[b] - ref_mse) <= 1e-3 * abs(ref_mse) + 1e-9
 
