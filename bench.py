@@ -92,17 +92,22 @@ def cpu_baseline(weights, hp, n_utts=6, repeats=3):
         return t
 
     t_gl6 = gl(n_utts)
-    t_glc = gl(cores) if cores != n_utts else t_gl6
+    # "all cores": one GPU's share of the host (16 worker processes on the GPU boxes, which report 256 logical CPUs for
+    # eight GPUs), never more than the host has
+    share = min(cores, 16)
+    t_glc = gl(share) if share != n_utts else t_gl6
     frames = n_utts * N_STEPS * hp.reduction
     return dict(value=frames / (t_net + t_gl6), unit='mel-frames/s', cores=cores, kind='port',
                 sample='{} utterances end-to-end (Ts={}, {} decoder steps, {} GL iterations), numpy oracle = a restated CPU '
                        'path, not TensorFlow; 1 warm-up + median of {}: network {:.2f} s in 1 process (BLAS threads: {}), '
-                       'Griffin-Lim {:.2f} s in the reference\'s {}-process pool; with {} workers on {} utterances {:.2f} s'.format(
-                           n_utts, TS, N_STEPS, N_ITER, repeats, t_net, _blas_threads(), t_gl6, n_utts, cores, cores, t_glc),
-                network_s=t_net, griffin_lim_s_6_workers=t_gl6, griffin_lim_s_all_cores=t_glc, gl_workers_reference=n_utts,
+                       'Griffin-Lim {:.2f} s in the reference\'s {}-process pool; with {} workers (one GPU\'s share of the {} host CPUs) on {} '
+                       'utterances {:.2f} s'.format(
+                           n_utts, TS, N_STEPS, N_ITER, repeats, t_net, _blas_threads(), t_gl6, n_utts, share, cores, share, t_glc),
+                network_s=t_net, griffin_lim_s_6_workers=t_gl6, griffin_lim_s_cpu_share=t_glc, gl_workers_reference=n_utts,
+                gl_workers_cpu_share=share,
                 blas=_blas_threads(),
                 griffin_lim_rtf=t_gl6 / (n_utts * n_samples / SR),
-                griffin_lim_rtf_all_cores=t_glc / (cores * n_samples / SR))
+                griffin_lim_rtf_cpu_share=t_glc / (share * n_samples / SR))
 
 
 def _cpu_gl_job(args):

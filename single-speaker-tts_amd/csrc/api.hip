@@ -89,6 +89,7 @@ struct tts_handle_s {
     // at B = 64; tools/pipeline_sweep.py: 16.0 against 19.6 ms per call at B = 32), so it stays.  2: whenever the
     // configuration allows it.  0: never.
     int persistent_decoder = 1;
+    int gl_stream = 1;               // Griffin-Lim iterations by gl_stream_kernel (a run = one stream through an LDS ring)
     int gl_fused = 0;                // all Griffin-Lim iterations of a call in one launch (gl_iter_kernel, FUSED): same
                                      // waveforms, measured no faster, so off unless asked for
     bool gl_fused_used = false;      // a fused launch has been enqueued since the last status check
@@ -892,12 +893,15 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     p.T = T; p.FP = FP; p.win = win; p.hop = hop;
     p.ncol = (win + hop - 1) / hop;
     p.B = B;
-    if (gl_max_item_frames(win, hop) < 1) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: window does not fit in LDS");
+    if (gl_max_item_frames(win, hop) < 1 && gl_stream_ring_frames(win, hop) < 1)
+        return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: window does not fit in LDS");
     const int n_cus = device_cus(h);
     // workgroups that really run side by side: the pipelined tts_synthesize keeps `reserve_cus` compute units
     // free of Griffin-Lim for its second stream
     const int held = (under_reservation && h->reserve_cus > 0) ? h->reserve_cus : 0;
-    gl_plan_items(p, n_cus - held > 16 ? n_cus - held : n_cus);
+    const bool stream = h->gl_stream != 0 && gl_stream_ring_frames(win, hop) > 0;
+    if (stream) gl_plan_stream(p, n_cus - held > 16 ? n_cus - held : n_cus);
+    else gl_plan_items(p, n_cus - held > 16 ? n_cus - held : n_cus);
     const int nchunks = p.slots_per_utt;
     WS(h, "gl.mse_partial", float, (size_t)B * nchunks, msep);
     // one zeroed work counter per launch (the persistent workgroups draw their item ids from it)
@@ -909,7 +913,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     // One launch for all iterations when nothing per-iteration is asked for (gl_iter_kernel, FUSED); `free_cus`
     // workgroups must all be resident, so under the call pipeline it is only used on the compute units the plan counts
     const int free_cus = n_cus - held > 16 ? n_cus - held : n_cus;
-    const bool fused = h->gl_fused != 0 && !mse && n_iter > 1 && gl_fused_supported(p);
+    const bool fused = !stream && h->gl_fused != 0 && !mse && n_iter > 1 && gl_fused_supported(p);
     if (fused) {
         ProfScope ps(h, ST_GL_ITER, n_iter);   // counted in iterations, like the separate launches
         WS(h, "gl.done", unsigned, (size_t)p.n_items + 1, done);
@@ -943,7 +947,8 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
             // no more workgroups than the plan counts on: one that finds its compute unit taken (the call pipeline's other
             // stream) would start when the first of the others leaves, load its tables, find no item and only
             // lengthen the launch
-            HIPCHK(h, launch_gl_iter(h->stream, p, free_cus, 0));
+            if (stream) HIPCHK(h, launch_gl_stream(h->stream, p, free_cus, 0));
+            else HIPCHK(h, launch_gl_iter(h->stream, p, free_cus, 0));
             std::swap(cur, nxt);
         }
 #ifdef GL_TIMELINE
@@ -995,7 +1000,8 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
         p.wav = wav;
         p.peak_partial = peak_normalize ? msep : nullptr;   // the mse partials are consumed by now
         p.work_counter = counters + n_iter;
-        HIPCHK(h, launch_gl_iter(h->stream, p, free_cus, 1));
+        if (stream) HIPCHK(h, launch_gl_stream(h->stream, p, free_cus, 1));
+        else HIPCHK(h, launch_gl_iter(h->stream, p, free_cus, 1));
     }
     if (peak_normalize) HIPCHK(h, launch_peak_scale(h->stream, wav, B, hop * (T - 1), msep, nchunks));
     return TTS_OK;
@@ -1150,6 +1156,7 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     else if (!std::strcmp(key, "profile")) h->profile = value;
     else if (!std::strcmp(key, "persistent_decoder")) h->persistent_decoder = value;
     else if (!std::strcmp(key, "gl_fused")) h->gl_fused = value;
+    else if (!std::strcmp(key, "gl_stream")) h->gl_stream = value;
     else if (!std::strcmp(key, "pd_debug_delay")) pd_debug_delay = value;   // tests only (decoder_persistent.hip)
     else if (!std::strcmp(key, "reserve_cus")) {
         h->reserve_cus = value;

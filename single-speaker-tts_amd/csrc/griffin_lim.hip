@@ -90,6 +90,12 @@ __device__ __forceinline__ cf cconj_add_pi(cf a, cf b) {
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// conj(a - b) = (a.x - b.x, -a.y + b.y)
+__device__ __forceinline__ cf cconj_sub(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // a + conj(b), a - conj(b)
 __device__ __forceinline__ cf cadd_conj(cf a, cf b) {
     cf r;
@@ -381,6 +387,20 @@ __device__ __forceinline__ void gl_c_store(unsigned* p, unsigned v, bool shared_
 }
 #define GL_FUSED_SPIN_LIMIT 4000000u
 
+// tools-only ablations (garbage results, timing only): -DGL_ABL_NOBAR drops the chunk loop's workgroup barriers,
+// -DGL_ABL_NOSTORE the spectrum stores of phase B, -DGL_ABL_NOLOAD the spectrum loads of phase A, -DGL_ABL_NOFLAG the
+// overlap-add progress waits
+#ifdef GL_ABL_NOLOAD
+#define GL_ABL_LD(load, fake) (fake)
+#else
+#define GL_ABL_LD(load, fake) (load)
+#endif
+#ifdef GL_ABL_NOBAR
+#define GL_CHUNK_BARRIER() asm volatile("" ::: "memory")
+#else
+#define GL_CHUNK_BARRIER() __syncthreads()
+#endif
+
 // LDS control words behind the exchange buffers
 enum { CT_FLAGS = 0 /* GL_NW overlap-add progress flags */, CT_BNEXT = 8, CT_NEXT_ITEM = 9, CT_ABORT = 10 /* fused launch: a wait timed out */, CT_WORDS = 16 };
 
@@ -554,8 +574,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                  \
         const unsigned* prow_ = phb + (size_t)tf_ * p.FP + lane;                           \
         const float* srow_ = magb + (size_t)tf_ * p.FP + lane;                             \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = gl_c_load<FUSED>(prow_ + 64 * j_); \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_STREAM_LOAD(srow_ + 64 * j_);   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = GL_ABL_LD(gl_c_load<FUSED>(prow_ + 64 * j_), (unsigned)(tf_ * 64 + j_) * 0x9E3779B9u); \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_ABL_LD(GL_STREAM_LOAD(srow_ + 64 * j_), (float)(tf_ + j_ + lane));   \
         nyq_c = gl_c_load<FUSED>(phb + (size_t)tf_ * p.FP + MH);                           \
         nyq_s = magb[(size_t)tf_ * p.FP + MH];                                             \
     }
@@ -625,9 +645,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                 }
             }
             const int need = r - (R - ncol);
+#ifndef GL_ABL_NOFLAG
             if (need > 0 && wave + 1 < GL_NW) {
                 while (gl_flag_load(ctrl + CT_FLAGS + wave + 1) < need) __builtin_amdgcn_s_sleep(1);
             }
+#endif
             asm volatile("" ::: "memory");
             float* sf = sig + fa * hop;
             if (r == 0) {
@@ -674,7 +696,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
         // registers now, so that the loads fly while the wave waits for the others at the barrier
         if (MODE == 0) GL_LOAD_WINDOW(0)
         if (tid == 0 && cq == 0) ctrl[CT_NEXT_ITEM] = (int)next_item_reg;
-        __syncthreads();   // all overlap-adds done (the signal is final), next item published
+        if (cq == 0) __syncthreads(); else GL_CHUNK_BARRIER();   // all overlap-adds done (the signal is final), next item published
         if (cq == 0) next_item = __builtin_amdgcn_readfirstlane(ctrl[CT_NEXT_ITEM]);
         if (tid < GL_NW) ctrl[CT_FLAGS + tid] = 0;   // nobody looks at the phase-A flags before the next item
         const int ybase = (t0 - halo) * hop + wpad - MH;   // trimmed-signal index of sig[0]
@@ -781,7 +803,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
                     const cf e = cadd_conj(zk, zmr[c]);
                     const cf o = cmul(csub_conj(zk, zmr[c]), twr[c]);
                     const cf x = cadd_mi(e, o);
+#ifdef GL_ABL_NOSTORE
+                    if (__float_as_uint(x.x) == 0x12345678u) gl_c_store<FUSED>(orow + k, gl_pack_phasor(x), shared_frame);
+#else
                     gl_c_store<FUSED>(orow + k, gl_pack_phasor(x), shared_frame);
+#endif
                     if (MSE) {
                         const float d = mg[c] - (float)MH * sqrtf(fmaf(x.x, x.x, x.y * x.y));   // x = X / MH
                         mse_acc += d * d;
@@ -847,7 +873,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             }
         }
 #endif
-        __syncthreads();   // everyone is done with the signal buffer
+        GL_CHUNK_BARRIER();   // everyone is done with the signal buffer
         if (more) {
             // shift the signal of the frames shared with the next chunk to the front of the buffer
             // (source [C hop, C hop + carry_len) and destination [0, carry_len) do not overlap: the host
@@ -855,7 +881,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
             const int src = C * hop;
 #pragma unroll 1
             for (int i = tid; i < carry_len; i += GL_THREADS) sig[i] = sig[src + i];
-            __syncthreads();
+            GL_CHUNK_BARRIER();
         }
         t0 += C;
       }   // chunks of the run
@@ -879,11 +905,518 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
 #undef GL_LOAD_WINDOW
 }
 
+
+// ====================================================================================== streaming form
+// One Griffin-Lim iteration (MODE 0) or the final iSTFT (MODE 1) WITHOUT phases: a run of consecutive frames of one
+// utterance is a stream.  Frame index i of the run (frame t = run_t0 - halo + i, halo = ncol - 1) belongs to wave
+// i mod 8, and a wave's iteration for index i is
+//     decode + split + inverse FFT + synthesis window of frame i            (registers, the wave's exchange buffer)
+//     overlap-add into a RING of R frames in LDS                            (in index order: a chain, see below)
+//     forward FFT + merge + phasor code of frame i - halo                   (final once index i has been added)
+// so loads of spectrum rows, arithmetic and stores of new rows interleave all the time instead of taking turns, no
+// wave waits at a workgroup barrier inside a run (there is one per run), nothing is copied when the window moves on,
+// and both windows stay in registers.  The eight waves drift apart by themselves (the chain staggers them), so the
+// two waves of a SIMD are usually in different parts of the iteration.
+//
+// Ring.  A frame's SPAN is the 128-sample slots of its 2048 padded samples that the window touches (slots c_lo ..
+// c_hi of the lane layout f = 2 (lane + 64 c) + e; 10 slots = 1280 samples for 1102): span sample q of index k lives
+// at ring position hop (k mod R) + q.  The window is zero on the rest of the two outer slots, so whole slots are
+// added (adding zeros) and no lane predicate is needed except in ONE slot: index k ACCUMULATES into span samples
+// q < S - hop (what indices < k have written) and STORES the last hop samples (nobody has), so the ring is never
+// cleared.  Spans that run past the end of the ring continue linearly into a GUARD of S - hop samples; the first
+// index of the next lap (k mod R == 0) reads its accumulate part from the guard and writes it to the start of the
+// ring (the guard is zeroed when a run starts: index 0 is such a fold, too).  Overlap-adds happen in index order --
+// index i waits for the LDS word `ola_done` to reach i and sets it to i + 1 afterwards (LDS executes a wave's
+// operations in order: the flag store follows the data stores) -- which fixes the summation order of every sample
+// (bit-reproducible) and is the only synchronisation inside a run: once index i has been added, every frame <= i - halo
+// has its final signal, and what the forward FFT of frame i - halo reads is not written again before the ring comes
+// round (R >= 9 + halo + ceil(S / hop) + 1: by the time an index may overwrite a position, every wave has finished the
+// iteration that read it; gl_stream_ring_frames).  Frames whose window leaves the signal (reflect padding) or whose
+// span crosses the lap end (the final values of the wrapped part are at the ring's start, not in the guard) take an
+// index-mapped read path: 4 + (halo + ceil(S / hop)) / R of the frames.
+// MODE 1 writes out, straight from the overlap-add's registers, the hop samples that index i makes final.
+enum { CT_OLA = 0, CT_SNEXT = 1, CT_SWORDS = 16 };
+
+template <int MODE, int WIN_CT, int HOP_CT, bool MSE>
+__global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int win = WIN_CT ? WIN_CT : p.win;
+    const int hop = HOP_CT ? HOP_CT : p.hop;
+    const int ncol = (WIN_CT && HOP_CT) ? (WIN_CT + HOP_CT - 1) / (HOP_CT ? HOP_CT : 1) : p.ncol;
+    const int halo = ncol - 1;
+    const int wpad = (NFFT - win) >> 1;
+    const int c_lo = wpad >> 7;                        // first / last 128-sample slot the window touches
+    const int c_hi = (wpad + win - 1) >> 7;
+    const int n_sl = c_hi - c_lo + 1;
+    const int S = 128 * n_sl;                          // span of a frame in the ring
+    const int fs = 128 * c_lo;                         // padded sample of span sample 0
+    const int acc_len = S - hop;                       // span samples that earlier indices have written
+    // A frame's forward FFT runs `lag` indices behind its overlap-add: halo, or one more when the reflect padding of the
+    // signal's first frame reaches exactly as far as halo frames make final (windows with ncol * hop == win)
+    const int lag = (halo + 1) * hop > 2 * (MH - wpad) ? halo : halo + 1;
+    const int R = p.ring_frames;
+    const int ring_len = hop * R;
+    const int L = hop * (p.T - 1);                     // samples of the (trimmed) signal
+    // carve: [exchange: GL_NW * EX_CPLX cf][control][ring: ring_len + acc_len + 128 floats]
+    cf* ex_all = reinterpret_cast<cf*>(smem_raw);
+    int* ctrl = reinterpret_cast<int*>(ex_all + GL_NW * EX_CPLX);
+    float* ring = reinterpret_cast<float*>(ctrl + CT_SWORDS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    cf* ex = ex_all + wave * EX_CPLX;
+
+    // ---------------- one-time setup: twiddles and BOTH windows in registers
+    if (tid == 0) ctrl[CT_SNEXT] = (int)atomicAdd(p.work_counter, 1u);
+    // twr[j] = W2048^{lane + 64 j} for j < 8; W2048^{512} = -i, so slot j + 8 uses -i twr[j] (folded into the adds)
+    cf twr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) twr[j] = reinterpret_cast<const cf*>(p.tw2048)[lane + 64 * j];
+    FftTwReg tw;
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) tw.a[k2 - 1] = reinterpret_cast<const cf*>(p.tables)[1024 + (k2 - 1) * 64 + lane];
+#pragma unroll
+    for (int d = 1; d < 4; ++d) tw.b[d - 1] = reinterpret_cast<const cf*>(p.tw1024)[16 * (lane & 15) * d];
+    // p.wlane: [set][lane][c][e], set 0 = analysis window w[n] / (2 MH), set 1 = set 0 / window-sum-square at an
+    // interior frame (gl_build_wlane); zero outside the window, statically so for the slots outside the span
+    float wana[16][2], wsyn[16][2];
+    {
+        const float4* wa = reinterpret_cast<const float4*>(p.wlane + (0 * 64 + lane) * 32);
+        const float4* ws = reinterpret_cast<const float4*>(p.wlane + (1 * 64 + lane) * 32);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 a4 = wa[q], s4 = ws[q];
+            wana[2 * q][0] = a4.x; wana[2 * q][1] = a4.y; wana[2 * q + 1][0] = a4.z; wana[2 * q + 1][1] = a4.w;
+            wsyn[2 * q][0] = s4.x; wsyn[2 * q][1] = s4.y; wsyn[2 * q + 1][0] = s4.z; wsyn[2 * q + 1][1] = s4.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (WIN_CT && (c < c_lo || c > c_hi)) { wana[c][0] = wana[c][1] = wsyn[c][0] = wsyn[c][1] = 0.f; }
+    }
+    __syncthreads();
+    int item = __builtin_amdgcn_readfirstlane(ctrl[CT_SNEXT]);
+
+    // ---------------- work item -> (utterance, first frame, frames, slot of its partial results); wave-uniform
+    auto decode_item = [&](int it, int& b, int& t0, int& len, int& slot) {
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < GL_MAX_CLASSES; ++q)
+            if (q < p.n_classes && it >= p.cls_first[q]) k = q;
+        const int rel = it - p.cls_first[k];
+        b = rel % p.B;
+        const int jc = rel / p.B;
+        len = p.cls_C[k];
+        t0 = p.cls_t0[k] + jc * len;
+        slot = p.cls_slot0[k] + jc;
+    };
+
+    // prefetch registers of one spectrum row: phasor codes and magnitudes of bins lane + 64 j, and the Nyquist bin
+    unsigned gc[16];
+    float gs[16];
+    unsigned nyq_c;
+    float nyq_s;
+#define GLS_LOAD_ROW(BASE_C, BASE_M, TF)                                                        \
+    {                                                                                           \
+        int tf_ = (TF);                                                                         \
+        tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                       \
+        const unsigned* prow_ = (BASE_C) + (size_t)tf_ * p.FP + lane;                           \
+        const float* srow_ = (BASE_M) + (size_t)tf_ * p.FP + lane;                              \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = prow_[64 * j_];              \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_STREAM_LOAD(srow_ + 64 * j_); \
+        nyq_c = prow_[MH - lane];                                                               \
+        nyq_s = srow_[MH - lane];                                                               \
+    }
+    const unsigned* x_in = reinterpret_cast<const unsigned*>(p.phase_in);
+    unsigned* x_out = reinterpret_cast<unsigned*>(p.phase_out);
+
+    bool have_row = false;   // (per wave) the first row of this run was requested in the last iteration of the previous one
+    while (item < p.n_items) {
+        int b, run_t0, run_len, slot;
+        decode_item(item, b, run_t0, run_len, slot);
+        const float* magb = p.mag + (size_t)b * p.T * p.FP;
+        const unsigned* phb = x_in + (size_t)b * p.T * p.FP;
+        unsigned next_item_reg = 0;
+        if (tid == 0) next_item_reg = atomicAdd(p.work_counter, 1u);
+        if (!have_row) GLS_LOAD_ROW(phb, magb, run_t0 - halo + wave)
+        have_row = false;
+        // run start: the guard reads as zero for index 0, the chain starts at 0
+        for (int q = tid; q < acc_len + 128; q += GL_THREADS) ring[ring_len + q] = 0.f;
+        if (tid == 0) { ctrl[CT_OLA] = 0; ctrl[CT_SNEXT] = (int)next_item_reg; }
+        __syncthreads();
+        const int next_item = __builtin_amdgcn_readfirstlane(ctrl[CT_SNEXT]);
+        int nb = b, nt0 = 0, nlen = 0, nslot = 0;
+        if (next_item < p.n_items) decode_item(next_item, nb, nt0, nlen, nslot);
+
+        const int n_idx = run_len + halo + lag;
+        const int y_base = (run_t0 - halo) * hop - MH + fs;   // trimmed-signal index of ring coordinate 0 (lap 0)
+        float mse_acc = 0.f, pk = 0.f;
+        int s = wave % R;                                     // ring slot of this wave's index (wave < 8 <= R)
+        for (int i = wave; i < n_idx; i += GL_NW) {
+            const int t = run_t0 - halo + i;
+            const bool valid = t >= 0 && t < p.T;             // wave-uniform
+            cf v[16];
+            if (valid) {
+                cf gk[16], gm[16];   // X[k] = |S[k]| * phasor[k] and the mirrored bins X[MH - k]
+#pragma unroll
+                for (int j = 0; j < 16; ++j) gk[j] = gl_unpack_phasor(gc[j], gs[j]);
+                const cf nyq = cmk(gl_unpack_phasor(nyq_c, nyq_s).x, 0.f);
+                mirror_bins(gk, gm, ex, lane, nyq);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    cf xk = gk[j];
+                    cf xr = gm[j];                                         // xm = conj(xr)
+                    if (j == 0 && lane == 0) { xk.y = 0.f; xr.y = 0.f; }   // DC and Nyquist bins are real
+                    // Zin = E + i O, E = (xk + xm)/2, O = conj(tw) (xk - xm)/2; the transform is fed conj(Zin), the
+                    // two 1/2 are in the window.  For j >= 8, conj(tw) = i conj(twr[j - 8]): conj(E + i i O') = conj(E - O')
+                    const cf e = cadd_conj(xk, xr);
+                    const cf o = cmul_conj(csub_conj(xk, xr), twr[j & 7]);
+                    v[j] = j < 8 ? cconj_add_pi(e, o) : cconj_sub(e, o);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = cmk(0.f, 0.f);
+            }
+            // the row is consumed: request this wave's next one (of this run, or the first of the next item)
+            if (i + GL_NW < n_idx) {
+                GLS_LOAD_ROW(phb, magb, t + GL_NW)
+            } else if (next_item < p.n_items) {
+                GLS_LOAD_ROW(x_in + (size_t)nb * p.T * p.FP, p.mag + (size_t)nb * p.T * p.FP, nt0 - halo + wave)
+                have_row = true;
+            }
+            if (valid) {
+                fft1024(v, ex, tw, lane);
+                // z[m] = conj(v) / MH, m = lane + 64 c: x[2m] = Re, x[2m+1] = Im; synthesis window (with 1 / wss)
+                if (t >= halo && t + halo < p.T) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) v[c] = v[c] * cmk(wsyn[c][0], -wsyn[c][1]);
+                } else {
+                    // frame near an utterance end: fewer overlapping neighbours, 1 / wss per sample (rare)
+                    const float* rwp = p.rwss + (size_t)t * hop + wpad;
+#pragma unroll
+                    for (int c0 = 0; c0 < 16; c0 += 4) {
+#pragma unroll
+                        for (int c = c0; c < c0 + 4; ++c) {
+                            const int nw0 = 2 * (lane + 64 * c) - wpad;
+                            const bool i0 = nw0 >= 0 && nw0 < win, i1 = nw0 + 1 >= 0 && nw0 + 1 < win;
+                            const float r0 = rwp[i0 ? nw0 : 0], r1 = rwp[i1 ? nw0 + 1 : 0];
+                            v[c] = cmk(i0 ? v[c].x * wana[c][0] * r0 : 0.f, i1 ? -v[c].y * wana[c][1] * r1 : 0.f);
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+                }
+            }
+            // ---------------- overlap-add, in index order
+            while (gl_flag_load(ctrl + CT_OLA) < i) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            {
+                float* wr = ring + hop * s + 2 * lane;
+                const float* rd = wr + (s == 0 ? ring_len : 0);       // first index of a lap: fold the guard in
+                // MODE 1: span samples [q_fin, q_fin + hop) of this index are final now; y of span sample 0
+                const int q_fin = wpad - fs;
+                const int y0 = t * hop + fs - MH;
+                const bool emit = MODE == 1 && (t >= run_t0 || run_t0 == 0) && (t < run_t0 + run_len || run_t0 + run_len == p.T);
+                float* wb = MODE == 1 ? p.wav + (size_t)b * L : nullptr;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int j = c - c_lo;
+                    if (j < 0 || j >= n_sl) continue;                  // wave-uniform (static for the reference window)
+                    const int qb = 128 * j;
+                    float a0, a1;
+                    if (qb + 127 < acc_len) {
+                        a0 = rd[qb] + v[c].x;
+                        a1 = rd[qb + 1] + v[c].y;
+                    } else if (qb >= acc_len) {
+                        a0 = v[c].x;
+                        a1 = v[c].y;
+                    } else {
+                        float o0 = rd[qb], o1 = rd[qb + 1];
+                        o0 = qb + 2 * lane < acc_len ? o0 : 0.f;
+                        o1 = qb + 2 * lane + 1 < acc_len ? o1 : 0.f;
+                        a0 = o0 + v[c].x;
+                        a1 = o1 + v[c].y;
+                    }
+                    wr[qb] = a0;
+                    wr[qb + 1] = a1;
+                    if (MODE == 1 && qb + 127 >= q_fin && qb < q_fin + hop) {   // slot holds final samples (wave-uniform)
+                        const int q = qb + 2 * lane;
+                        const int y = y0 + q;
+                        if (emit && q >= q_fin && q < q_fin + hop && y >= 0 && y < L) { wb[y] = a0; pk = fmaxf(pk, fabsf(a0)); }
+                        if (emit && q + 1 >= q_fin && q + 1 < q_fin + hop && y + 1 >= 0 && y + 1 < L) { wb[y + 1] = a1; pk = fmaxf(pk, fabsf(a1)); }
+                    }
+                }
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) gl_flag_store(ctrl + CT_OLA, i + 1);
+
+            // ---------------- forward FFT of frame t - lag: its signal is final
+            if (MODE == 0 && i >= halo + lag && i < halo + lag + run_len) {
+                const int tm = t - lag;                                  // in [run_t0, run_t0 + run_len), < T
+                int sm = s - lag;
+                sm += sm < 0 ? R : 0;
+                const float* mrow = magb + (size_t)tm * p.FP;
+                float mg[16];
+                if (MSE) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) mg[c] = fabsf(GL_STREAM_LOAD(mrow + lane + 64 * c));
+                }
+                const int ylo = tm * hop + wpad - MH;                    // y index of window sample 0
+                const bool edge = ylo < 0 || ylo + win > L;              // reflect padding needed
+                // The span is read linearly when it does not cross the end of the lap, or when the next lap's fold (index
+                // m + R - sm) has not happened yet: what it will fold is still in the guard, behind the ring.
+                if (!edge && (hop * sm + S <= ring_len || R - sm > lag)) {
+                    const float* sf = ring + hop * sm + 2 * lane;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const int j = c - c_lo;
+                        if (j < 0 || j >= n_sl) v[c] = cmk(0.f, 0.f);
+                        else v[c] = cmk(wana[c][0] * sf[128 * j], wana[c][1] * sf[128 * j + 1]);
+                    }
+                } else {
+                    // index-mapped reads: reflect at the signal's ends; run coordinate u = lap * ring_len + off lives at
+                    // ring position off -- unless off < acc_len and that lap's fold (index lap * R) is still to come:
+                    // then it is in the guard
+                    const int lap0 = (i - lag) / R;
+                    const int ub = y_base + lap0 * ring_len;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        float x[2] = {0.f, 0.f};
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int f = 2 * (lane + 64 * c) + e;
+                            const int nw = f - wpad;
+                            if (nw >= 0 && nw < win) {
+                                int y = ylo + nw;
+                                y = y < 0 ? -y : y;
+                                y = y >= L ? 2 * (L - 1) - y : y;
+                                int off = y - ub, lap = lap0;
+                                if (off >= ring_len) { off -= ring_len; ++lap; }
+                                else if (off < 0) { off += ring_len; --lap; }
+                                const int pos = (off < acc_len && lap * R > i) ? ring_len + off : off;
+                                x[e] = wana[c][e] * ring[pos];
+                            }
+                        }
+                        v[c] = cmk(x[0], x[1]);
+                    }
+                }
+                fft1024(v, ex, tw, lane);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
+                wave_lds_sync();
+                unsigned* orow = x_out + ((size_t)b * p.T + tm) * p.FP;
+                cf zmr[16];   // all mirrored bins first: one LDS latency for the pass instead of one per bin
+#pragma unroll
+                for (int c = 0; c < 16; ++c) zmr[c] = ex[(MH - (lane + 64 * c)) & (MH - 1)];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int k = lane + 64 * c;
+                    const cf zk = v[c];
+                    // zm = conj(zmr); 2 X[k] = (zk + zm) - i tw (zk - zm); for c >= 8, tw = -i twr[c - 8]: X = E - O'
+                    const cf e = cadd_conj(zk, zmr[c]);
+                    const cf o = cmul(csub_conj(zk, zmr[c]), twr[c & 7]);
+                    const cf x = c < 8 ? cadd_mi(e, o) : csub(e, o);
+                    __builtin_nontemporal_store(gl_pack_phasor(x), orow + k);
+                    if (MSE) {
+                        const float d = mg[c] - (float)MH * sqrtf(fmaf(x.x, x.x, x.y * x.y));   // x = X / MH
+                        mse_acc += d * d;
+                    }
+                }
+                if (lane == 0) {
+                    const cf z0 = v[0];
+                    const float xn = z0.x - z0.y;   // Nyquist bin, real
+                    __builtin_nontemporal_store(xn < 0.f ? 1u : 0u, orow + MH);   // phasor (-1, 0) / (1, 0)
+                    if (MSE) {
+                        const float d = fabsf(mrow[MH]) - (2.0f * MH) * fabsf(xn);   // xn = X[MH] / (2 MH)
+                        mse_acc += d * d;
+                    }
+                }
+                wave_lds_sync();
+            }
+            s += GL_NW;
+            s -= s >= R ? R : 0;
+        }
+        // ---------------- run end: per-run partial results (fixed order), then everyone is done with the ring
+        if ((MODE == 0 && MSE) || (MODE == 1 && p.peak_partial)) {
+            float r = MODE == 0 ? mse_acc : pk;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) r = MODE == 0 ? r + __shfl_xor(r, o) : fmaxf(r, __shfl_xor(r, o));
+            __syncthreads();   // all waves are done with their exchange buffers
+            float* red = reinterpret_cast<float*>(ex_all);
+            if (lane == 0) red[wave] = r;
+            __syncthreads();
+            if (tid == 0) {
+                float a = MODE == 0 ? 0.f : 0.f;
+                for (int w = 0; w < GL_NW; ++w) a = MODE == 0 ? a + red[w] : fmaxf(a, red[w]);
+                (MODE == 0 ? p.mse_partial : p.peak_partial)[(size_t)b * p.slots_per_utt + slot] = a;
+            }
+        }
+        __syncthreads();
+        item = next_item;
+    }
+#undef GLS_LOAD_ROW
+}
+
 size_t gl_lds_bytes(const GlParams& p) {
     const int halo = p.ncol - 1;
     const int nA = p.C + 2 * halo;
     const int span = (nA - 1) * p.hop + p.win;
     return (size_t)(GL_NW * EX_CPLX) * sizeof(cf) + CT_WORDS * sizeof(int) + (size_t)((span + 3) & ~3) * sizeof(float);
+}
+
+
+// ---- streaming form: geometry, plan, launch
+namespace {
+struct GlStreamGeom { int c_lo, n_sl, S, acc_len, halo; };
+GlStreamGeom gl_stream_geom(int win, int hop) {
+    GlStreamGeom g;
+    const int wpad = (NFFT - win) >> 1;
+    g.c_lo = wpad >> 7;
+    g.n_sl = ((wpad + win - 1) >> 7) - g.c_lo + 1;
+    g.S = 128 * g.n_sl;
+    g.acc_len = g.S - hop;
+    g.halo = (win + hop - 1) / hop - 1;
+    return g;
+}
+}  // namespace
+
+// Frames the ring holds (0: the window / hop pair does not fit).  Lower bound: what keeps an index from overwriting ring
+// positions that a slower wave may still read (see gl_stream_kernel), and the reflect-padded frames' reach; upper
+// bound: LDS.  More frames only make the lap-end read path rarer.
+int gl_stream_ring_frames(int win, int hop) {
+    const GlStreamGeom g = gl_stream_geom(win, hop);
+    if (g.acc_len < 0) return 0;   // hop > span: frames do not even touch (ncol = 1 with a hop beyond the padded slots)
+    const int wpad = (NFFT - win) >> 1;
+    const int lag = (g.halo + 1) * hop > 2 * (MH - wpad) ? g.halo : g.halo + 1;
+    const int budget = (160 * 1024 - (int)(GL_NW * EX_CPLX * sizeof(cf)) - CT_SWORDS * (int)sizeof(int)) / (int)sizeof(float) - g.acc_len - 128;
+    int need = 9 + lag + (g.S + hop - 1) / hop + 1;
+    const int reach = (g.S + win + 2 * hop + hop - 1) / hop;   // what a reflect-padded frame reads is still in the ring, within one lap
+    need = std::max(need, std::max(reach, GL_NW));
+    const int R = std::min(budget / hop, std::max(64, need));
+    return R >= need ? R : 0;
+}
+
+size_t gl_stream_lds_bytes(const GlParams& p) {
+    const GlStreamGeom g = gl_stream_geom(p.win, p.hop);
+    return (size_t)(GL_NW * EX_CPLX) * sizeof(cf) + CT_SWORDS * sizeof(int) +
+           (size_t)((p.hop * p.ring_frames + g.acc_len + 128 + 3) & ~3) * sizeof(float);
+}
+
+// Work items of the streaming form: every utterance is cut into nr runs of (almost) equal length, a multiple of the
+// eight waves; a run costs its frames plus the 2 halo indices that are only inverse-transformed plus a constant for
+// filling and draining the stream.  nr is chosen by simulating the list schedule on the workgroups that really run.
+void gl_plan_stream(GlParams& p, int n_workers) {
+    const int halo = p.ncol - 1;
+    p.ring_frames = gl_stream_ring_frames(p.win, p.hop);
+    struct Cut { int L, n_full, rem; };
+    Cut best{p.T, 1, 0};
+    bool forced = false;
+    if (const char* ov = getenv("SSTTS_GL_RUNS")) {   // experiments: runs per utterance
+        const int nr = atoi(ov);
+        if (nr >= 1 && nr <= p.T) {
+            const int L = ((p.T + nr - 1) / nr + GL_NW - 1) / GL_NW * GL_NW;
+            best = Cut{L, p.T / L, p.T - (p.T / L) * L};
+            forced = true;
+        }
+    }
+    if (!forced) {
+        static std::map<std::vector<int>, Cut> cache;
+        static std::mutex cache_mutex;
+        std::lock_guard<std::mutex> lock(cache_mutex);
+        const std::vector<int> key = {p.T, p.B, p.win, p.hop, n_workers};
+        auto it = cache.find(key);
+        if (it != cache.end()) {
+            best = it->second;
+        } else {
+            double best_t = 1e300;
+            const double fill = 6.0;   // frames' worth of time to fill and drain the stream of a run
+            for (int nr = 1; nr <= p.T; ++nr) {
+                const int L = ((p.T + nr - 1) / nr + GL_NW - 1) / GL_NW * GL_NW;
+                if (nr > 1 && L == ((p.T + nr - 2) / (nr - 1) + GL_NW - 1) / GL_NW * GL_NW) continue;   // same cut as nr - 1
+                const int n_full = p.T / L, rem = p.T - n_full * L;
+                // list schedule, longest runs first: n_full * B items of cost cL, then B items of cost cR
+                const double cL = L + 2 * halo + fill, cR = rem > 0 ? rem + 2 * halo + fill : 0.0;   // (lag - halo <= 1: in `fill`)
+                std::vector<double> heap((size_t)n_workers, 0.0);
+                auto cmp = [](double a, double b) { return a > b; };
+                auto deal = [&](long long items, double cost) {
+                    for (long long i = 0; i < items; ++i) {
+                        std::pop_heap(heap.begin(), heap.end(), cmp);
+                        heap.back() += cost;
+                        std::push_heap(heap.begin(), heap.end(), cmp);
+                    }
+                };
+                deal((long long)n_full * p.B, cL);
+                if (rem > 0) deal(p.B, cR);
+                const double t = *std::max_element(heap.begin(), heap.end());
+                if (t < best_t - 1e-9) { best_t = t; best = Cut{L, n_full, rem}; }
+                if (L <= GL_NW) break;
+            }
+            cache[key] = best;
+        }
+    }
+    for (int k = 0; k < GL_MAX_CLASSES; ++k) {
+        p.cls_C[k] = p.cls_n[k] = p.cls_t0[k] = p.cls_slot0[k] = p.cls_first[k] = p.cls_chunks[k] = 0;
+    }
+    int nc = 0, t = 0, slot = 0, first = 0;
+    auto add = [&](int len, int n) {
+        p.cls_C[nc] = len; p.cls_n[nc] = n; p.cls_chunks[nc] = 1;
+        p.cls_t0[nc] = t; p.cls_slot0[nc] = slot; p.cls_first[nc] = first;
+        t += len * n; slot += n; first += n * p.B;
+        ++nc;
+    };
+    if (best.n_full > 0) add(best.L, best.n_full);
+    if (best.rem > 0) add(best.rem, 1);
+    p.n_classes = nc;
+    p.n_items = first;
+    p.slots_per_utt = slot;
+    p.chunk = p.C = best.L;
+}
+
+template <int MODE, int W, int H, bool MSE>
+static hipError_t gl_stream_set_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_stream_kernel<MODE, W, H, MSE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+// p.work_counter must point at a zeroed counter that no other launch uses; p planned by gl_plan_stream.
+hipError_t launch_gl_stream(hipStream_t s, const GlParams& p, int n_cus, int final_istft) {
+    if (p.ring_frames < GL_NW) return hipErrorInvalidValue;
+    const size_t lds = gl_stream_lds_bytes(p);
+    const int nwg = p.n_items < n_cus ? p.n_items : n_cus;   // one workgroup per compute unit (256 registers x 8 waves)
+    dim3 grid(nwg);
+    const bool ref_cfg = p.win == 1102 && p.hop == 275;
+    const bool mse = p.mse_partial != nullptr;
+#define GLS_LAUNCH(MODE, W, H, M) hipLaunchKernelGGL((gl_stream_kernel<MODE, W, H, M>), grid, dim3(GL_THREADS), lds, s, p)
+#ifdef GL_FAST_BUILD
+    if (!ref_cfg || mse) return hipErrorInvalidValue;
+    if (final_istft) GLS_LAUNCH(1, 1102, 275, false);
+    else GLS_LAUNCH(0, 1102, 275, false);
+#else
+    if (final_istft) {
+        if (ref_cfg) GLS_LAUNCH(1, 1102, 275, false);
+        else GLS_LAUNCH(1, 0, 0, false);
+    } else if (mse) {
+        if (ref_cfg) GLS_LAUNCH(0, 1102, 275, true);
+        else GLS_LAUNCH(0, 0, 0, true);
+    } else {
+        if (ref_cfg) GLS_LAUNCH(0, 1102, 275, false);
+        else GLS_LAUNCH(0, 0, 0, false);
+    }
+#endif
+#undef GLS_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t gl_stream_configure() {
+    hipError_t e;
+#ifndef GL_FAST_BUILD
+    if ((e = gl_stream_set_attr<0, 0, 0, false>()) != hipSuccess) return e;
+    if ((e = gl_stream_set_attr<0, 0, 0, true>()) != hipSuccess) return e;
+    if ((e = gl_stream_set_attr<1, 0, 0, false>()) != hipSuccess) return e;
+    if ((e = gl_stream_set_attr<0, 1102, 275, true>()) != hipSuccess) return e;
+#endif
+    if ((e = gl_stream_set_attr<0, 1102, 275, false>()) != hipSuccess) return e;
+    if ((e = gl_stream_set_attr<1, 1102, 275, false>()) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 void gl_build_wlane(const float* window, const float* rwss, int win, int hop, int T, float* out) {
@@ -1070,6 +1603,7 @@ hipError_t gl_configure() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_iter_kernel<0, 0, 0, false, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
 #endif
+    if ((e = gl_stream_configure()) != hipSuccess) return e;
     return stft_configure();
 }
 

@@ -82,3 +82,35 @@ def test_cudnn_persistent_decoder(cudnn_setup, B, Ts, S):
         B, Ts, S, e_mel, e_al, rel_l2(mel, mel0)))
     assert e_mel < 1e-3 and e_al < 1e-4
     assert rel_l2(mel, mel0) < 1e-5 and np.abs(al - al0).max() < 1e-4
+
+
+@pytest.mark.parametrize('B,Ts,S,delay', [(20, 50, 40, 1), (64, 150, 60, 2)])
+def test_persistent_cudnn_decoder_with_a_late_stager(cudnn_setup, B, Ts, S, delay):
+    """CudnnCompatibleGRUCell form in the persistent kernel: the candidate phase continues on the staged tile without
+    a wait, so a workgroup stores its slice of h' while a peer may still be STAGING the previous h.  With one state
+    buffer that peer read a mix of h_{t-1} and h_t (round-2 advisory); the states are double-buffered by step parity
+    now.  `pd_debug_delay` makes workgroup 3 of every cluster sleep ~3.4 us x delay between each wait and its staging
+    loads -- the late stager -- and the result must still equal the launch-per-layer path (1e-5: other summation
+    order) and be bit-identical to the undelayed persistent run."""
+    hp, w, eng = cudnn_setup
+    rng = np.random.default_rng(40 + B)
+    memory = eng.to_device((rng.standard_normal((B, Ts, 256)) * 0.7).astype(np.float32))
+    try:
+        eng.set_option('persistent_decoder', 0)
+        mel0, al0 = eng.decoder_forward(memory, S)
+        mel0, al0 = mel0.to_host(), al0.to_host()
+        eng.set_option('persistent_decoder', 2)
+        mel1, al1 = eng.decoder_forward(memory, S)
+        eng.synchronize()
+        mel1, al1 = mel1.to_host(), al1.to_host()
+        eng.set_option('pd_debug_delay', delay)
+        mel2, al2 = eng.decoder_forward(memory, S)
+        eng.synchronize()
+        mel2, al2 = mel2.to_host(), al2.to_host()
+    finally:
+        eng.set_option('pd_debug_delay', 0)
+        eng.set_option('persistent_decoder', 1)
+    print('cudnn persistent vs launch path: mel rel-L2 {:.3e}; late stager vs undelayed: equal = {}'.format(
+        rel_l2(mel1, mel0), np.array_equal(mel1, mel2)))
+    assert rel_l2(mel1, mel0) < 1e-5 and np.abs(al1 - al0).max() < 1e-5
+    assert np.array_equal(mel1, mel2) and np.array_equal(al1, al2)

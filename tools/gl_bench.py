@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--nocheck', action='store_true', help='ablation builds produce garbage')
     ap.add_argument('--fused', type=int, default=None, help='override the library default (all iterations in one launch)')
+    ap.add_argument('--stream', type=int, default=None, help='override the library default (streaming kernel)')
     ap.add_argument('--compare', action='store_true', help='fused against separate launches: waveforms must be identical')
     a = ap.parse_args()
     sstts = importlib.import_module('single-speaker-tts_amd')
@@ -41,6 +42,8 @@ def main():
         return
     if a.fused is not None:
         eng.set_option('gl_fused', a.fused)
+    if a.stream is not None:
+        eng.set_option('gl_stream', a.stream)
     eng.griffin_lim(mag, 2, 1102, 275, 2048, init_phase=init, want_mse=False)
     eng.set_option('profile', 1)
     eng.profile_reset()
