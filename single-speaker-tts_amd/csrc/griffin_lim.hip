@@ -964,7 +964,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // the wave index as a SCALAR: everything derived from it (frame index, ring slot, the branches on them) then lives
+    // in SGPRs and branches without exec masks -- as `tid >> 6` it is a vector value to the compiler
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     cf* ex = ex_all + wave * EX_CPLX;
 
     // ---------------- one-time setup: twiddles and BOTH windows in registers
@@ -1022,14 +1024,35 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                       \
         const unsigned* prow_ = (BASE_C) + (size_t)tf_ * p.FP + lane;                           \
         const float* srow_ = (BASE_M) + (size_t)tf_ * p.FP + lane;                              \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = prow_[64 * j_];              \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_STREAM_LOAD(srow_ + 64 * j_); \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = GL_ABL_LD(prow_[64 * j_], (unsigned)(tf_ * 64 + j_) * 0x9E3779B9u);              \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_ABL_LD(GL_STREAM_LOAD(srow_ + 64 * j_), (float)(tf_ + j_ + lane)); \
         nyq_c = prow_[MH - lane];                                                               \
         nyq_s = srow_[MH - lane];                                                               \
     }
+    // vmcnt counts loads and stores together, in issue order.  The row for the next iteration is requested early in
+    // this one and the new row is stored at its end, so at the top of the loop the loads are OLDER than 17 stores: the
+    // compiler's wait for "the last load" there (it does not carry the stores round the loop) is a wait for every store
+    // of the previous iteration to reach memory -- a full write latency per iteration.  Touching the row registers just
+    // before the stores makes the compiler wait for the loads there, where they are the youngest operations and some
+    // microseconds old; at the top of the loop nothing is left to wait for (every path into the loop settles them).
+#define GLS_TOUCH_ROW()                                                                                              \
+    asm volatile("" : "+v"(gc[0]), "+v"(gc[1]), "+v"(gc[2]), "+v"(gc[3]), "+v"(gc[4]), "+v"(gc[5]), "+v"(gc[6]),       \
+                      "+v"(gc[7]), "+v"(gc[8]), "+v"(gc[9]), "+v"(gc[10]), "+v"(gc[11]), "+v"(gc[12]), "+v"(gc[13]), \
+                      "+v"(gc[14]), "+v"(gc[15]), "+v"(nyq_c));                                                      \
+    asm volatile("" : "+v"(gs[0]), "+v"(gs[1]), "+v"(gs[2]), "+v"(gs[3]), "+v"(gs[4]), "+v"(gs[5]), "+v"(gs[6]),       \
+                      "+v"(gs[7]), "+v"(gs[8]), "+v"(gs[9]), "+v"(gs[10]), "+v"(gs[11]), "+v"(gs[12]), "+v"(gs[13]), \
+                      "+v"(gs[14]), "+v"(gs[15]), "+v"(nyq_s));
     const unsigned* x_in = reinterpret_cast<const unsigned*>(p.phase_in);
     unsigned* x_out = reinterpret_cast<unsigned*>(p.phase_out);
 
+#ifdef GL_TIMELINE   // tools only: 100 MHz stamps of workgroup 0's waves, [wave][64], from the tenth iteration of a run on
+    int stamp_n = 0;
+#define GLS_STAMP()                                                                                       \
+    if (p.dbg && blockIdx.x == 0 && lane == 0 && stamp_n < 64 && i >= 10 * GL_NW)                         \
+        p.dbg[1024 + wave * 64 + stamp_n++] = __builtin_amdgcn_s_memrealtime();
+#else
+#define GLS_STAMP()
+#endif
     bool have_row = false;   // (per wave) the first row of this run was requested in the last iteration of the previous one
     while (item < p.n_items) {
         int b, run_t0, run_len, slot;
@@ -1052,9 +1075,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         const int y_base = (run_t0 - halo) * hop - MH + fs;   // trimmed-signal index of ring coordinate 0 (lap 0)
         float mse_acc = 0.f, pk = 0.f;
         int s = wave % R;                                     // ring slot of this wave's index (wave < 8 <= R)
+        GLS_TOUCH_ROW()
         for (int i = wave; i < n_idx; i += GL_NW) {
             const int t = run_t0 - halo + i;
             const bool valid = t >= 0 && t < p.T;             // wave-uniform
+            GLS_STAMP()   // 0: iteration start
             cf v[16];
             if (valid) {
                 cf gk[16], gm[16];   // X[k] = |S[k]| * phasor[k] and the mirrored bins X[MH - k]
@@ -1077,6 +1102,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) v[j] = cmk(0.f, 0.f);
             }
+            GLS_STAMP()   // 1: decoded, split
             // the row is consumed: request this wave's next one (of this run, or the first of the next item)
             if (i + GL_NW < n_idx) {
                 GLS_LOAD_ROW(phb, magb, t + GL_NW)
@@ -1106,9 +1132,13 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     }
                 }
             }
+            GLS_STAMP()   // 2: inverse FFT + window done
             // ---------------- overlap-add, in index order
+#ifndef GL_ABL_NOFLAG
             while (gl_flag_load(ctrl + CT_OLA) < i) __builtin_amdgcn_s_sleep(1);
+#endif
             asm volatile("" ::: "memory");
+            GLS_STAMP()   // 3: my turn in the chain
             {
                 float* wr = ring + hop * s + 2 * lane;
                 const float* rd = wr + (s == 0 ? ring_len : 0);       // first index of a lap: fold the guard in
@@ -1117,25 +1147,31 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                 const int y0 = t * hop + fs - MH;
                 const bool emit = MODE == 1 && (t >= run_t0 || run_t0 == 0) && (t < run_t0 + run_len || run_t0 + run_len == p.T);
                 float* wb = MODE == 1 ? p.wav + (size_t)b * L : nullptr;
+                // All reads first, then the adds, then the writes: written slot by slot, every read waits for the
+                // previous slot's write (the compiler cannot tell that they do not alias) and the critical section of
+                // the chain is eight LDS round trips instead of one.
+                float o[16][2];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
                     const int j = c - c_lo;
+                    o[c][0] = o[c][1] = 0.f;
                     if (j < 0 || j >= n_sl) continue;                  // wave-uniform (static for the reference window)
                     const int qb = 128 * j;
-                    float a0, a1;
-                    if (qb + 127 < acc_len) {
-                        a0 = rd[qb] + v[c].x;
-                        a1 = rd[qb + 1] + v[c].y;
-                    } else if (qb >= acc_len) {
-                        a0 = v[c].x;
-                        a1 = v[c].y;
-                    } else {
-                        float o0 = rd[qb], o1 = rd[qb + 1];
-                        o0 = qb + 2 * lane < acc_len ? o0 : 0.f;
-                        o1 = qb + 2 * lane + 1 < acc_len ? o1 : 0.f;
-                        a0 = o0 + v[c].x;
-                        a1 = o1 + v[c].y;
+                    if (qb < acc_len) { o[c][0] = rd[qb]; o[c][1] = rd[qb + 1]; }
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int j = c - c_lo;
+                    if (j < 0 || j >= n_sl) continue;
+                    const int qb = 128 * j;
+                    float a0 = o[c][0], a1 = o[c][1];
+                    if (qb < acc_len && qb + 127 >= acc_len) {         // the slot where accumulate turns into store
+                        a0 = qb + 2 * lane < acc_len ? a0 : 0.f;
+                        a1 = qb + 2 * lane + 1 < acc_len ? a1 : 0.f;
                     }
+                    a0 += v[c].x;
+                    a1 += v[c].y;
                     wr[qb] = a0;
                     wr[qb + 1] = a1;
                     if (MODE == 1 && qb + 127 >= q_fin && qb < q_fin + hop) {   // slot holds final samples (wave-uniform)
@@ -1148,6 +1184,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
             }
             asm volatile("" ::: "memory");
             if (lane == 0) gl_flag_store(ctrl + CT_OLA, i + 1);
+            // the next row has arrived (requested before the inverse FFT) -- settled on every path round the loop, at the
+            // point of the iteration where the fewest registers are live, before this iteration's stores are issued
+            GLS_STAMP()   // 4: overlap-add issued, flag passed on
+            GLS_TOUCH_ROW()
+            GLS_STAMP()   // 5: next row has arrived
 
             // ---------------- forward FFT of frame t - lag: its signal is final
             if (MODE == 0 && i >= halo + lag && i < halo + lag + run_len) {
@@ -1200,6 +1241,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     }
                 }
                 fft1024(v, ex, tw, lane);
+                GLS_STAMP()   // 6: forward FFT done
 #pragma unroll
                 for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
                 wave_lds_sync();
@@ -1215,7 +1257,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     const cf e = cadd_conj(zk, zmr[c]);
                     const cf o = cmul(csub_conj(zk, zmr[c]), twr[c & 7]);
                     const cf x = c < 8 ? cadd_mi(e, o) : csub(e, o);
+#ifdef GL_ABL_NOSTORE
+                    if (__float_as_uint(x.x) == 0x12345678u) __builtin_nontemporal_store(gl_pack_phasor(x), orow + k);
+#else
                     __builtin_nontemporal_store(gl_pack_phasor(x), orow + k);
+#endif
                     if (MSE) {
                         const float d = mg[c] - (float)MH * sqrtf(fmaf(x.x, x.x, x.y * x.y));   // x = X / MH
                         mse_acc += d * d;
@@ -1231,6 +1277,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     }
                 }
                 wave_lds_sync();
+                GLS_STAMP()   // 7: merged, encoded, stores issued
             }
             s += GL_NW;
             s -= s >= R ? R : 0;
@@ -1254,6 +1301,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         item = next_item;
     }
 #undef GLS_LOAD_ROW
+#undef GLS_TOUCH_ROW
+#undef GLS_STAMP
 }
 
 size_t gl_lds_bytes(const GlParams& p) {
