@@ -4,7 +4,7 @@
 
 namespace tts {
 
-#define TTS_GL_FP 1028      // padded row length of the frame-major spectra (F = 1025)
+#define TTS_GL_FP 1056      // padded row length of the frame-major spectra (F = 1025): rows start on 128-byte lines
 #define TTS_GL_NFFT 2048
 #define GL_MAX_CLASSES 4
 

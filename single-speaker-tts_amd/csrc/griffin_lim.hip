@@ -11,7 +11,7 @@
 //
 // Internal layout: frame-major.  mag [B][T][FP] float and a ping-pong pair of 32-bit unit-phasor codes
 // e^{i phi} [B][T][FP] (gl_pack_phasor; the estimate X = |S| e^{i phi} is rebuilt from mag where it is
-// consumed), FP = 1028 (F = 1025 padded so that every row is 16-byte aligned).  One frame's spectrum is a
+// consumed), FP = 1056 (F = 1025 padded so that every row starts on a 128-byte line: -2.5 % per launch).  One frame's spectrum is a
 // contiguous row, which is also how the network produces it (B,T,F): the reference's (F,T) transpose
 // exists only at the C ABI.
 //
@@ -332,7 +332,11 @@ __device__ __forceinline__ cf unit_phasor(cf z) {
 // The spectra are streamed once per iteration (1.3 GB per launch at the bench size): non-temporal accesses
 // keep them from evicting the decoder's weights and attention memory, which the second stream re-reads
 // every step while this kernel runs.
+#ifdef GL_PLAIN_LOAD
+__device__ __forceinline__ float gl_stream_load(const float* p) { return *p; }
+#else
 __device__ __forceinline__ float gl_stream_load(const float* p) { return __builtin_nontemporal_load(p); }
+#endif
 __device__ __forceinline__ void gl_stream_store(cf* p, cf v) { __builtin_nontemporal_store(v, p); }
 #define GL_STREAM_LOAD(ptr) gl_stream_load(ptr)
 #define GL_STREAM_STORE(ptr, val) gl_stream_store((ptr), (val))
@@ -1024,8 +1028,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                       \
         const unsigned* prow_ = (BASE_C) + (size_t)tf_ * p.FP + lane;                           \
         const float* srow_ = (BASE_M) + (size_t)tf_ * p.FP + lane;                              \
+        GLS_WIDE_LOADS(prow_, srow_) {                                                          \
         _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = GL_ABL_LD(prow_[64 * j_], (unsigned)(tf_ * 64 + j_) * 0x9E3779B9u);              \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_ABL_LD(GL_STREAM_LOAD(srow_ + 64 * j_), (float)(tf_ + j_ + lane)); \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_ABL_LD(GL_STREAM_LOAD(srow_ + 64 * j_), (float)(tf_ + j_ + lane)); }\
         nyq_c = prow_[MH - lane];                                                               \
         nyq_s = srow_[MH - lane];                                                               \
     }
@@ -1042,6 +1047,19 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
     asm volatile("" : "+v"(gs[0]), "+v"(gs[1]), "+v"(gs[2]), "+v"(gs[3]), "+v"(gs[4]), "+v"(gs[5]), "+v"(gs[6]),       \
                       "+v"(gs[7]), "+v"(gs[8]), "+v"(gs[9]), "+v"(gs[10]), "+v"(gs[11]), "+v"(gs[12]), "+v"(gs[13]), \
                       "+v"(gs[14]), "+v"(gs[15]), "+v"(nyq_s));
+#ifdef GL_ABL_WIDE   // tools only: the same bytes with a quarter of the memory instructions (wrong layout: garbage results)
+#define GLS_WIDE_LOADS(PR, SR)                                                                                 \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                        \
+        const uint4 c4_ = reinterpret_cast<const uint4*>((PR) - lane)[lane + 64 * q_];                         \
+        typedef float gl_f4_ __attribute__((ext_vector_type(4)));                                              \
+        const gl_f4_ m4_ = __builtin_nontemporal_load(reinterpret_cast<const gl_f4_*>((SR) - lane) + lane + 64 * q_); \
+        gc[4 * q_] = c4_.x; gc[4 * q_ + 1] = c4_.y; gc[4 * q_ + 2] = c4_.z; gc[4 * q_ + 3] = c4_.w;            \
+        gs[4 * q_] = m4_.x; gs[4 * q_ + 1] = m4_.y; gs[4 * q_ + 2] = m4_.z; gs[4 * q_ + 3] = m4_.w;            \
+    }                                                                                                          \
+    if (false)
+#else
+#define GLS_WIDE_LOADS(PR, SR)
+#endif
     const unsigned* x_in = reinterpret_cast<const unsigned*>(p.phase_in);
     unsigned* x_out = reinterpret_cast<unsigned*>(p.phase_out);
 
@@ -1052,6 +1070,24 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         p.dbg[1024 + wave * 64 + stamp_n++] = __builtin_amdgcn_s_memrealtime();
 #else
 #define GLS_STAMP()
+#endif
+    // Issue priority by lateness.  The overlap-add chain makes every wave do one index per round; the hardware
+    // arbitrates the two waves of a SIMD by age, so waves 0-3 run ahead, then sleep at the chain while their partners
+    // (4-7) run alone -- and a wave alone on a SIMD fills fewer issue slots than two (the timeline showed 2.4 us of
+    // waiting per 7.5 us iteration for the older half, none for the younger).  A wave whose next overlap-add is what the
+    // chain will ask for next raises its priority, one that is far ahead lowers it: the waves then arrive at the chain
+    // about when it is their turn.
+#ifndef GL_NO_LATEPRIO
+#define GLS_URGENCY(NEXT_INDEX)                                                                    \
+    {                                                                                              \
+        const int d_ = __builtin_amdgcn_readfirstlane((NEXT_INDEX) - gl_flag_load(ctrl + CT_OLA)); \
+        if (d_ <= 1) __builtin_amdgcn_s_setprio(3);                                                \
+        else if (d_ <= 3) __builtin_amdgcn_s_setprio(2);                                           \
+        else if (d_ <= 5) __builtin_amdgcn_s_setprio(1);                                           \
+        else __builtin_amdgcn_s_setprio(0);                                                        \
+    }
+#else
+#define GLS_URGENCY(NEXT_INDEX)
 #endif
     bool have_row = false;   // (per wave) the first row of this run was requested in the last iteration of the previous one
     while (item < p.n_items) {
@@ -1080,6 +1116,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
             const int t = run_t0 - halo + i;
             const bool valid = t >= 0 && t < p.T;             // wave-uniform
             GLS_STAMP()   // 0: iteration start
+            GLS_URGENCY(i)
             cf v[16];
             if (valid) {
                 cf gk[16], gm[16];   // X[k] = |S[k]| * phasor[k] and the mirrored bins X[MH - k]
@@ -1103,6 +1140,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                 for (int j = 0; j < 16; ++j) v[j] = cmk(0.f, 0.f);
             }
             GLS_STAMP()   // 1: decoded, split
+            GLS_URGENCY(i)
             // the row is consumed: request this wave's next one (of this run, or the first of the next item)
             if (i + GL_NW < n_idx) {
                 GLS_LOAD_ROW(phb, magb, t + GL_NW)
@@ -1189,6 +1227,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
             GLS_STAMP()   // 4: overlap-add issued, flag passed on
             GLS_TOUCH_ROW()
             GLS_STAMP()   // 5: next row has arrived
+            GLS_URGENCY(i + GL_NW)
 
             // ---------------- forward FFT of frame t - lag: its signal is final
             if (MODE == 0 && i >= halo + lag && i < halo + lag + run_len) {
@@ -1242,10 +1281,14 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                 }
                 fft1024(v, ex, tw, lane);
                 GLS_STAMP()   // 6: forward FFT done
+                GLS_URGENCY(i + GL_NW)
 #pragma unroll
                 for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
                 wave_lds_sync();
                 unsigned* orow = x_out + ((size_t)b * p.T + tm) * p.FP;
+#ifdef GL_ABL_WIDE
+                unsigned wide_[4];
+#endif
                 cf zmr[16];   // all mirrored bins first: one LDS latency for the pass instead of one per bin
 #pragma unroll
                 for (int c = 0; c < 16; ++c) zmr[c] = ex[(MH - (lane + 64 * c)) & (MH - 1)];
@@ -1259,6 +1302,14 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     const cf x = c < 8 ? cadd_mi(e, o) : csub(e, o);
 #ifdef GL_ABL_NOSTORE
                     if (__float_as_uint(x.x) == 0x12345678u) __builtin_nontemporal_store(gl_pack_phasor(x), orow + k);
+#elif defined(GL_ABL_WIDE)
+                    wide_[c & 3] = gl_pack_phasor(x);
+                    if ((c & 3) == 3) {
+                        typedef unsigned gl_u4_ __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store((gl_u4_){wide_[0], wide_[1], wide_[2], wide_[3]}, reinterpret_cast<gl_u4_*>(orow) + lane + 64 * (c >> 2));
+                    }
+#elif defined(GL_PLAIN_STORE)
+                    orow[k] = gl_pack_phasor(x);
 #else
                     __builtin_nontemporal_store(gl_pack_phasor(x), orow + k);
 #endif
@@ -1282,6 +1333,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
             s += GL_NW;
             s -= s >= R ? R : 0;
         }
+        __builtin_amdgcn_s_setprio(0);
         // ---------------- run end: per-run partial results (fixed order), then everyone is done with the ring
         if ((MODE == 0 && MSE) || (MODE == 1 && p.peak_partial)) {
             float r = MODE == 0 ? mse_acc : pk;
@@ -1303,6 +1355,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
 #undef GLS_LOAD_ROW
 #undef GLS_TOUCH_ROW
 #undef GLS_STAMP
+#undef GLS_URGENCY
 }
 
 size_t gl_lds_bytes(const GlParams& p) {

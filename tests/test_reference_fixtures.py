@@ -79,9 +79,9 @@ def test_host_mirror_equals_the_reference(fx):
 def test_hip_db_convert_against_the_reference(engine, fx):
     arrays, meta = fx
     # mode 0: 20 log10(max(1e-5, x)): the kernel rounds the float64 result once; the reference computes in float32 (one
-    # rounding in log10, one in the product): <= 2 ulp of 100 dB apart
+    # rounding in log10, one in the product): <= 2 ulp of the value apart (the inputs reach 3e38 = 770 dB)
     got = engine.db_convert(arrays['m2d_in'], 0)
-    assert np.abs(got - arrays['m2d_out']).max() <= 2e-5
+    assert (np.abs(got - arrays['m2d_out']) <= 2.4e-7 * np.maximum(np.abs(arrays['m2d_out']), 64.0)).all()
     # mode 1: 10 ** (x / 20) as exp2: relative error of an fp32 exp2 with a 7-bit exponent argument
     got = engine.db_convert(arrays['d2m_in'], 1)
     assert np.abs(got / arrays['d2m_out'] - 1.0).max() <= 4e-6
