@@ -199,6 +199,9 @@ def main():
     ap.add_argument('--hold-lds-kb', type=int, default=None)
     ap.add_argument('--persistent-decoder', type=int, default=None, help='override the library default (0 never, 1 pipelined, 2 always)')
     ap.add_argument('--gl-fused', type=int, default=None, help='override the library default (all Griffin-Lim iterations in one launch)')
+    ap.add_argument('--through-facade', action='store_true',
+                    help='also time the reference-shaped host API (tacotron.inference.synthesize_stream: host ids in, host '
+                         'waveforms out, upload and download inside the timed region) and report facade_ms_per_step')
     ap.add_argument('--no-aux-outputs', action='store_true', help='A/B: do not write the linear spectrograms and alignments')
     ap.add_argument('--dist-selftest', action='store_true', help='rehearse the N > 1 launch path without GPU work')
     args = ap.parse_args()
@@ -355,6 +358,27 @@ def main():
     for d in (ga, gw, gc):
         d.free()
 
+    facade_ms = None
+    if args.through_facade:
+        # the same batch through the reference-shaped functions: ids from host memory, waveforms back in host memory
+        # (pinned buffers of the library), two calls in flight; initial phases from the seed as the reference draws them
+        Tm = importlib.import_module('single-speaker-tts_amd.tacotron.model')
+        Inf = importlib.import_module('single-speaker-tts_amd.tacotron.inference')
+        model = Tm.Tacotron(inputs=Tm.Tacotron.model_placeholders(), mode=Tm.Mode.PREDICT, engine=eng, hparams=hp)
+        ids_host = ids_all[lo:hi]
+        n_f = args.steps
+        for _ in Inf.synthesize_stream(model, (ids_host for _ in range(max(2, args.warmup))), n_steps=N_STEPS, n_iter=N_ITER,
+                                       peak_normalize=True):
+            pass
+        barrier()
+        t0 = time.perf_counter()
+        checksum = 0.0
+        for wavs in Inf.synthesize_stream(model, (ids_host for _ in range(n_f)), n_steps=N_STEPS, n_iter=N_ITER, peak_normalize=True):
+            checksum += float(wavs[0, 1000])   # the host really reads what came back
+        barrier()
+        facade_ms = 1e3 * (time.perf_counter() - t0) / n_f
+        assert np.isfinite(checksum)
+
     if rank == 0:
         frames_total = world * B_PER_GPU * T
         ms_per_step = 1e3 * elapsed / args.steps
@@ -394,6 +418,7 @@ def main():
             'end_to_end_rtf': ms_per_step * 1e-3 / audio_s,
             'mel_frames_per_sec_encoder_decoder': B_PER_GPU * T / ((stage_ms['encoder'] + stage_ms['decoder']) * 1e-3),
             'stage_ms': stage_ms,
+            'facade_ms_per_step': facade_ms,
             'outputs_per_step': 'wav (peak-normalised)' + ('' if args.no_aux_outputs else ', linear spectrograms, alignments') +
                                 ', mel (library-owned double buffer); all resident in HBM, none copied to the host in the timed region',
             'roofline': {'kernel': 'gl_iter_kernel<0> (one Griffin-Lim iteration, iSTFT+STFT fused)', 'bound': 'hbm',

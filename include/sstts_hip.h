@@ -208,6 +208,19 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
                    const float* init_phase /* [B*F*T] or NULL */, float* wav, float* mel,
                    float* alignments, float* linear);
 
+/* The same call for a caller that lives in HOST memory -- what the reference's inference() / serve() are
+ * (tacotron/inference.py:75-101,185-200, serve.py:89-126: host id arrays in, host waveforms out) -- without giving up the
+ * call pipeline: the ids are copied to a pinned staging buffer of the handle and uploaded on a copy stream, the
+ * call is enqueued behind that upload (the initial phases are drawn on the device from p->seed, as the reference
+ * draws them with np.random), and the waveforms are downloaded into pinned memory of the handle on a second copy
+ * stream as soon as they are complete.  The call returns at once with a ticket; tts_wait_host blocks until that
+ * call's waveforms have arrived and hands out the pinned buffer, [B * hop*(T-1)] floats, valid until the second
+ * tts_synthesize_host call after the one that produced it (two buffers alternate).  Keep at most two calls in
+ * flight: submit k + 1, then wait for k.  Bit-identical to tts_synthesize + tts_memcpy_d2h. */
+int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, const tts_synth_params_t* p,
+                        int* ticket);
+int tts_wait_host(tts_handle_t h, int ticket, const float** wav_host, size_t* n_floats);
+
 /* ---- profiling -------------------------------------------------------------------------- */
 /* With option "profile"=1 the library brackets its stages with HIP events on the handle's
  * stream.  Stages: "encoder", "decoder", "postnet", "denorm", "gl_iter", "gl_final", "debug_gemm"

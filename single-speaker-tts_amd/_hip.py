@@ -90,6 +90,8 @@ _PROTOTYPES = {
                                     c_void_p]),
     'tts_synthesize': (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(TtsSynthParams), c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p]),
+    'tts_synthesize_host': (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(TtsSynthParams), POINTER(c_int)]),
+    'tts_wait_host': (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_size_t)]),
     'tts_profile_reset': (c_int, [c_void_p]),
     'tts_profile_get': (c_int, [c_void_p, c_char_p, POINTER(c_float), POINTER(c_int64)]),
     'tts_debug_workspace': (c_int, [c_void_p, c_char_p, POINTER(c_void_p), POINTER(c_size_t)]),
@@ -399,6 +401,31 @@ class Engine(object):
                                             ali.data_ptr() if ali is not None else None,
                                             lin.data_ptr() if lin is not None else None))
         return dict(wav=wav, mel=mel, alignments=ali, linear=lin)
+
+    def synthesize_host(self, ids, n_steps, ref_db, max_db, power, n_iter, win_length, hop_length, seed=0,
+                        peak_normalize=True):
+        """Asynchronous end-to-end call on HOST ids (int32 (B, T_sent)): returns a ticket at once; the upload, the
+        network, Griffin-Lim and the download of the waveforms into pinned memory overlap with the neighbouring
+        calls.  Keep at most two calls in flight: submit k + 1, then ``wait_host(ticket_k)``."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        self._check_ids(ids)
+        B, Ts = ids.shape
+        sp = TtsSynthParams(n_steps, ref_db, max_db, power, n_iter, win_length, hop_length, seed, 1 if peak_normalize else 0)
+        t = c_int(-1)
+        self._check(self.lib.tts_synthesize_host(self.handle, ids.ctypes.data, B, Ts, byref(sp), byref(t)))
+        self._host_shapes = getattr(self, '_host_shapes', {})
+        self._host_shapes[t.value] = (B, hop_length * (n_steps * self.cfg.reduction - 1))
+        return t.value
+
+    def wait_host(self, ticket, copy=True):
+        """Waveforms (B, hop*(T-1)) float32 of a ``synthesize_host`` call.  ``copy=False`` returns a view of the library's
+        pinned buffer, valid until the second ``synthesize_host`` call after the one that produced it."""
+        p = c_void_p()
+        n = c_size_t(0)
+        self._check(self.lib.tts_wait_host(self.handle, int(ticket), byref(p), byref(n)))
+        shape = self._host_shapes.pop(ticket, (n.value,))
+        view = np.ctypeslib.as_array(ctypes.cast(p, POINTER(c_float)), shape=(n.value,)).reshape(shape)
+        return view.copy() if copy else view
 
     def stft(self, wav, n_fft, win_length, hop_length):
         """complex64 (B, F, n_frames) = librosa.stft per utterance."""

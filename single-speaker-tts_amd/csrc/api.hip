@@ -79,6 +79,8 @@ struct tts_handle_s {
     hipEvent_t ev_gl_done[2] = {nullptr, nullptr};     // Griffin-Lim of the calls of even / odd parity (its phase buffers are free)
     bool gl_pending[2] = {false, false};
     bool front_pending = false;     // ev_front_done has been recorded at least once
+    hipEvent_t ev_serial_done = nullptr;   // encoder + decoder of an UNPIPELINED call (they ran on the main stream)
+    bool serial_pending = false;           // ... has been recorded since the front stream last waited for it
     unsigned syn_calls = 0;
     int syn_shape[3] = {0, 0, 0};   // (B, Ts, n_steps) of the previous tts_synthesize call
     // persistent decoder (decoder_persistent.hip).  1 (default): under the call pipeline AND with more than 48
@@ -101,6 +103,29 @@ struct tts_handle_s {
     int pd_clusters = 0;
     int* cur_hold_flag = nullptr;    // set by tts_synthesize around its decoder call: the sleepers' flag
     int cur_cu_budget = 0;           // ... and the compute units the front stream may count on (0 = the whole chip)
+
+    // host-memory calls (tts_synthesize_host): pinned staging of the ids, device copies, pinned waveform buffers and the
+    // device buffers they are copied from, all per call parity; two copy streams
+    struct {
+        hipStream_t in = nullptr, out = nullptr;
+        int32_t* ids_pinned[2] = {nullptr, nullptr};
+        int32_t* ids_dev[2] = {nullptr, nullptr};
+        size_t ids_bytes = 0;
+        float* wav_dev[2] = {nullptr, nullptr};
+        float* wav_pinned[2] = {nullptr, nullptr};
+        size_t wav_bytes = 0;
+        hipEvent_t ev_h2d[2] = {nullptr, nullptr};      // upload of the ids done
+        hipEvent_t ev_enc[2] = {nullptr, nullptr};      // encoder done with the ids buffer
+        hipEvent_t ev_ready[2] = {nullptr, nullptr};    // waveforms complete on the device
+        hipEvent_t ev_d2h[2] = {nullptr, nullptr};      // waveforms have arrived in pinned memory
+        bool d2h_pending[2] = {false, false}, enc_pending[2] = {false, false};
+        size_t n_floats[2] = {0, 0};
+        int* status_pinned = nullptr;   // [2][2]: the sticky status words (fused Griffin-Lim, persistent decoder) as they
+                                        // stood behind each call's download
+        int tickets = 0;
+    } hio;
+    hipEvent_t input_event = nullptr;   // set around a tts_synthesize call: its first kernel waits for this event
+    hipEvent_t enc_done_event = nullptr;   // ... and this one is recorded behind its encoder
 
     std::vector<ManifestEntry> manifest;
     std::map<std::string, std::vector<float>> host_w;
@@ -546,6 +571,8 @@ int sync_all(tts_handle_t h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->front && h->front != h->stream) HIPCHK(h, hipStreamSynchronize(h->front));
     if (h->aux) HIPCHK(h, hipStreamSynchronize(h->aux));
+    if (h->hio.in) HIPCHK(h, hipStreamSynchronize(h->hio.in));
+    if (h->hio.out) HIPCHK(h, hipStreamSynchronize(h->hio.out));
     return check_status(h);
 }
 
@@ -1112,8 +1139,22 @@ int tts_destroy(tts_handle_t h) {
     }
     if (h->hold_flags) hipFree(h->hold_flags);
     if (h->gl_status) hipFree(h->gl_status);
+    for (int i = 0; i < 2; ++i) {
+        if (h->hio.ids_pinned[i]) hipHostFree(h->hio.ids_pinned[i]);
+        if (h->hio.ids_dev[i]) hipFree(h->hio.ids_dev[i]);
+        if (h->hio.wav_pinned[i]) hipHostFree(h->hio.wav_pinned[i]);
+        if (h->hio.wav_dev[i]) hipFree(h->hio.wav_dev[i]);
+        if (h->hio.ev_h2d[i]) hipEventDestroy(h->hio.ev_h2d[i]);
+        if (h->hio.ev_enc[i]) hipEventDestroy(h->hio.ev_enc[i]);
+        if (h->hio.ev_ready[i]) hipEventDestroy(h->hio.ev_ready[i]);
+        if (h->hio.ev_d2h[i]) hipEventDestroy(h->hio.ev_d2h[i]);
+    }
+    if (h->hio.status_pinned) hipHostFree(h->hio.status_pinned);
+    if (h->hio.in) hipStreamDestroy(h->hio.in);
+    if (h->hio.out) hipStreamDestroy(h->hio.out);
     if (h->ev_aux) hipEventDestroy(h->ev_aux);
     if (h->ev_front_done) hipEventDestroy(h->ev_front_done);
+    if (h->ev_serial_done) hipEventDestroy(h->ev_serial_done);
     for (int i = 0; i < 2; ++i) {
         if (h->ev_post_done[i]) hipEventDestroy(h->ev_post_done[i]);
         if (h->ev_gl_done[i]) hipEventDestroy(h->ev_gl_done[i]);
@@ -1795,6 +1836,12 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         // the post-net of the call two back read the mel buffer this call's decoder writes; with a caller's
         // mel buffer (possibly the same one every call) the previous call's post-net has to finish as well
         if (h->post_pending[parity]) HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_post_done[parity], 0));
+        // an unpipelined call in between ran its encoder and decoder on the MAIN stream, in the scratch buffers this
+        // call's encoder and decoder are about to use on the front stream
+        if (h->serial_pending) {
+            HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_serial_done, 0));
+            h->serial_pending = false;
+        }
         if (mel_out && h->post_pending[parity ^ 1])
             HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_post_done[parity ^ 1], 0));
         // The persistent decoder keeps its compute units by being resident (Griffin-Lim is planned and launched for
@@ -1817,13 +1864,20 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         }
         h->stream = h->front;
     }
+    if (h->input_event) HIPCHK(h, hipStreamWaitEvent(h->stream, h->input_event, 0));   // (tts_synthesize_host: the ids' upload)
     rc = tts_encoder_forward(h, ids, B, Ts, memory);
+    if (!rc && h->enc_done_event) HIPCHK(h, hipEventRecord(h->enc_done_event, h->stream));
     h->cur_hold_flag = hold_flag;
     h->cur_cu_budget = (pipelined && h->reserve_cus > 0) ? h->reserve_cus : 0;
     if (!rc) rc = tts_decoder_forward(h, memory, B, Ts, sp->n_steps, mel, align_out);
     h->cur_hold_flag = nullptr;
     h->cur_cu_budget = 0;
     h->stream = main_stream;
+    if (!rc && !pipelined && h->front) {
+        if (!h->ev_serial_done) HIPCHK(h, hipEventCreateWithFlags(&h->ev_serial_done, hipEventDisableTiming));
+        HIPCHK(h, hipEventRecord(h->ev_serial_done, h->stream));
+        h->serial_pending = true;
+    }
     if (rc) {
         if (hold_flag) hipMemsetAsync(hold_flag, 1, sizeof(int), h->front);
         return rc;
@@ -1855,6 +1909,107 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         h->gl_pending[parity] = true;
     }
     return rc;
+}
+
+
+// Host-memory form of tts_synthesize (see sstts_hip.h): uploads and downloads on copy streams, ordered by events, so that
+// consecutive calls overlap exactly like calls on device-resident buffers.
+int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, const tts_synth_params_t* sp, int* ticket) {
+    DeviceScope dev_scope(h);
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!ids_host || !sp || !ticket || B < 1 || Ts < 1 || sp->n_steps < 1)
+        return fail(h, TTS_ERR_INVALID, "synthesize_host: bad arguments");
+    auto& io = h->hio;
+    const int T = sp->n_steps * h->cfg.reduction;
+    const size_t ids_bytes = (size_t)B * Ts * sizeof(int32_t);
+    const size_t n_wav = (size_t)B * sp->hop_length * (size_t)(T - 1);
+    if (!io.in) {
+        HIPCHK(h, hipStreamCreateWithFlags(&io.in, hipStreamNonBlocking));
+        HIPCHK(h, hipStreamCreateWithFlags(&io.out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(h, hipEventCreateWithFlags(&io.ev_h2d[i], hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&io.ev_enc[i], hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&io.ev_ready[i], hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&io.ev_d2h[i], hipEventDisableTiming));
+        }
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&io.status_pinned), 4 * sizeof(int), hipHostMallocDefault));
+    }
+    if (ids_bytes > io.ids_bytes || n_wav * sizeof(float) > io.wav_bytes) {
+        // growing the buffers: nothing of an earlier call may be in flight
+        if ((rc = sync_all(h))) return rc;
+        HIPCHK(h, hipStreamSynchronize(io.in));
+        HIPCHK(h, hipStreamSynchronize(io.out));
+        for (int i = 0; i < 2; ++i) {
+            if (ids_bytes > io.ids_bytes) {
+                if (io.ids_pinned[i]) HIPCHK(h, hipHostFree(io.ids_pinned[i]));
+                if (io.ids_dev[i]) HIPCHK(h, hipFree(io.ids_dev[i]));
+                HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&io.ids_pinned[i]), ids_bytes, hipHostMallocDefault));
+                HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&io.ids_dev[i]), ids_bytes));
+            }
+            if (n_wav * sizeof(float) > io.wav_bytes) {
+                if (io.wav_pinned[i]) HIPCHK(h, hipHostFree(io.wav_pinned[i]));
+                if (io.wav_dev[i]) HIPCHK(h, hipFree(io.wav_dev[i]));
+                HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&io.wav_pinned[i]), n_wav * sizeof(float), hipHostMallocDefault));
+                HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&io.wav_dev[i]), n_wav * sizeof(float)));
+            }
+            io.d2h_pending[i] = io.enc_pending[i] = false;
+        }
+        io.ids_bytes = std::max(io.ids_bytes, ids_bytes);
+        io.wav_bytes = std::max(io.wav_bytes, n_wav * sizeof(float));
+    }
+    const int t = io.tickets++;
+    const int par = t & 1;
+    // the pinned staging buffer and the device copy of the ids were last used by the call two back
+    if (io.d2h_pending[par]) HIPCHK(h, hipEventSynchronize(io.ev_h2d[par]));
+    std::memcpy(io.ids_pinned[par], ids_host, ids_bytes);
+    if (io.enc_pending[par]) HIPCHK(h, hipStreamWaitEvent(io.in, io.ev_enc[par], 0));
+    HIPCHK(h, hipMemcpyAsync(io.ids_dev[par], io.ids_pinned[par], ids_bytes, hipMemcpyHostToDevice, io.in));
+    HIPCHK(h, hipEventRecord(io.ev_h2d[par], io.in));
+    // the waveform buffer of this parity is free once the download of the call two back has left it
+    if (io.d2h_pending[par]) HIPCHK(h, hipStreamWaitEvent(h->stream, io.ev_d2h[par], 0));
+    h->input_event = io.ev_h2d[par];
+    h->enc_done_event = io.ev_enc[par];
+    rc = tts_synthesize(h, io.ids_dev[par], B, Ts, sp, nullptr, io.wav_dev[par], nullptr, nullptr, nullptr);
+    h->input_event = nullptr;
+    h->enc_done_event = nullptr;
+    if (rc) return rc;
+    io.enc_pending[par] = true;
+    HIPCHK(h, hipEventRecord(io.ev_ready[par], h->stream));
+    HIPCHK(h, hipStreamWaitEvent(io.out, io.ev_ready[par], 0));
+    HIPCHK(h, hipMemcpyAsync(io.wav_pinned[par], io.wav_dev[par], n_wav * sizeof(float), hipMemcpyDeviceToHost, io.out));
+    // the sticky status words of the persistent kernels travel with the waveforms (tts_wait_host must not wait for
+    // anything but this call: a stream synchronisation there would wait for the NEXT call's download as well)
+    io.status_pinned[2 * par] = io.status_pinned[2 * par + 1] = 0;
+    if (h->gl_fused_used && h->gl_status)
+        HIPCHK(h, hipMemcpyAsync(&io.status_pinned[2 * par], h->gl_status, sizeof(int), hipMemcpyDeviceToHost, io.out));
+    if (h->pd_used && h->pd_sync)
+        HIPCHK(h, hipMemcpyAsync(&io.status_pinned[2 * par + 1], h->pd_sync + 64 * h->pd_clusters + 1, sizeof(int),
+                                 hipMemcpyDeviceToHost, io.out));
+    HIPCHK(h, hipEventRecord(io.ev_d2h[par], io.out));
+    io.d2h_pending[par] = true;
+    io.n_floats[par] = n_wav;
+    *ticket = t;
+    return TTS_OK;
+}
+
+int tts_wait_host(tts_handle_t h, int ticket, const float** wav_host, size_t* n_floats) {
+    DeviceScope dev_scope(h);
+    if (!h || !wav_host) return TTS_ERR_INVALID;
+    auto& io = h->hio;
+    if (ticket < 0 || ticket >= io.tickets || ticket < io.tickets - 2)
+        return fail(h, TTS_ERR_INVALID, "wait_host: this ticket's buffer has been handed to a later call (at most two calls in flight)");
+    const int par = ticket & 1;
+    HIPCHK(h, hipEventSynchronize(io.ev_d2h[par]));
+    // the download is behind everything the call launched: a timed-out persistent kernel must not pass for a result
+    if (io.status_pinned[2 * par])
+        return fail(h, TTS_ERR_HIP, "fused Griffin-Lim: a wait for a neighbour run timed out; the waveforms of that call are invalid");
+    if (io.status_pinned[2 * par + 1])
+        return fail(h, TTS_ERR_HIP, "persistent decoder: a wait for the cluster timed out; the outputs of that call are invalid -- "
+                                     "tts_set_option(h, \"persistent_decoder\", 0) selects the launch-per-layer path");
+    *wav_host = io.wav_pinned[par];
+    if (n_floats) *n_floats = io.n_floats[par];
+    return TTS_OK;
 }
 
 int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* bytes) {

@@ -973,6 +973,12 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     cf* ex = ex_all + wave * EX_CPLX;
 
+#ifdef GL_CLOCK   // tools only: shader clock held during the launch (s_memtime ticks per 100 MHz s_memrealtime tick)
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef GL_TIMELINE
+    if (p.dbg && tid == 0) p.dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---------------- one-time setup: twiddles and BOTH windows in registers
     if (tid == 0) ctrl[CT_SNEXT] = (int)atomicAdd(p.work_counter, 1u);
     // twr[j] = W2048^{lane + 64 j} for j < 8; W2048^{512} = -i, so slot j + 8 uses -i twr[j] (folded into the adds)
@@ -1352,6 +1358,18 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         __syncthreads();
         item = next_item;
     }
+#ifdef GL_TIMELINE
+    if (p.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+#ifdef GL_CLOCK
+    if (tid == 0 && (blockIdx.x & 63) == 0 && MODE == 0) {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        printf("wg %3d: %.1f us, shader clock %.0f MHz\n", (int)blockIdx.x, (double)dr * 0.01, (double)dt * 100.0 / (double)dr);
+    }
+#endif
 #undef GLS_LOAD_ROW
 #undef GLS_TOUCH_ROW
 #undef GLS_STAMP

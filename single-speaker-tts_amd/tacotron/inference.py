@@ -65,6 +65,30 @@ def synthesize_batch(model, sentences, n_steps=None, n_iter=None, init_phase=Non
     return out['wav'].to_host()
 
 
+def synthesize_stream(model, batches, n_steps=None, n_iter=None, seed=0, peak_normalize=False, copy=False):
+    """Generator over batches of padded id sequences (each (B, T_sent) int32, HOST arrays) -> per batch the waveforms
+    (B, hop*(T-1)) float32 in host memory, with TWO batches in flight: batch k + 1 is uploaded and its encoder /
+    decoder run while batch k is in its post-net / Griffin-Lim and batch k - 1 is being downloaded (the reference
+    runs the batches one after the other, tacotron/inference.py:75-101,185-200).  The arrays yielded are views of the
+    library's pinned buffers unless ``copy``: valid until the next-but-one batch has been requested."""
+    hp = model.hparams
+    loader = dataset_params.dataset_loader
+    win_len = ms_to_samples(hp.win_len, hp.sampling_rate)
+    win_hop = ms_to_samples(hp.win_hop, hp.sampling_rate)
+    S = n_steps or model.n_steps()
+    it = hp.reconstruction_iterations if n_iter is None else n_iter
+    eng = model.engine
+    pending = None
+    for k, ids in enumerate(batches):
+        t = eng.synthesize_host(ids, S, loader.mel_mag_ref_db, loader.mel_mag_max_db, hp.magnitude_power, it, win_len,
+                                win_hop, seed=seed + k, peak_normalize=peak_normalize)
+        if pending is not None:
+            yield eng.wait_host(pending, copy=copy)
+        pending = t
+    if pending is not None:
+        yield eng.wait_host(pending, copy=copy)
+
+
 def synthesize_sentences(raw_sentences, weights, dataset=None, out_dir=None, device_id=0, seed=0):
     """The reference's ``__main__`` (tacotron/inference.py:130-200) as a function.
 

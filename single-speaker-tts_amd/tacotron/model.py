@@ -53,7 +53,7 @@ class Tacotron(object):
     tacotron/inference.py:55,71)."""
 
     def __init__(self, inputs, mode, training_summary=True, weights=None, hparams=None, device_id=0,
-                 stream=None):
+                 stream=None, engine=None):
         if mode != Mode.PREDICT:
             raise NotImplementedError('only Mode.PREDICT is implemented on the MI355X path '
                                       '(training / evaluation are out of scope)')
@@ -71,8 +71,9 @@ class Tacotron(object):
         self.output_linear_spec = Fetch('output_linear_spec')
         self.alignment_history = Fetch('alignment_history')
         self._summary = Fetch('summary')
-        self.engine = Engine(self.hparams, device_id=device_id, stream=stream)
-        self._loaded = False
+        # `engine`: an Engine that already holds the weights (a second view of one handle, e.g. bench.py)
+        self.engine = engine if engine is not None else Engine(self.hparams, device_id=device_id, stream=stream)
+        self._loaded = engine is not None
         if weights is not None:
             self.restore(weights)
 

@@ -38,14 +38,21 @@ def post_process_spectrograms(_spectrograms, engine, init_phase=None, seed=0):
     return [wav[b] for b in range(wav.shape[0])]
 
 
-def serve(sentence_generator, weights, dataset=None, device_id=0):
+def serve(sentence_generator, weights, dataset=None, device_id=0, pipelined=True):
     """Generator: for each batch of raw sentences yield the list of synthesized waveforms
     (reference tacotron/serve.py:89-126, with the SavedModel session replaced by the engine)."""
     from ..datasets.lj_speech import LJSpeechDatasetHelper
     dataset = dataset or LJSpeechDatasetHelper(dataset_folder=dataset_params.dataset_folder,
                                                 char_dict=dataset_params.vocabulary_dict, fill_dict=False)
     model = Tacotron(inputs=Tacotron.model_placeholders(), mode=Mode.PREDICT, weights=weights, device_id=device_id)
-    for sentences in sentence_generator:
-        ids = pre_process_sentences(sentences, dataset)
-        spectrograms = model.run(model.output_linear_spec, {model.inp_sentences: ids})
-        yield post_process_spectrograms(spectrograms, model.engine)
+    if not pipelined:   # the reference's loop as it stands: one batch at a time, spectrograms through host memory
+        for sentences in sentence_generator:
+            ids = pre_process_sentences(sentences, dataset)
+            spectrograms = model.run(model.output_linear_spec, {model.inp_sentences: ids})
+            yield post_process_spectrograms(spectrograms, model.engine)
+        return
+    # two batches in flight, nothing but ids and waveforms crosses the host boundary (inference.synthesize_stream)
+    from .inference import synthesize_stream
+    batches = (pre_process_sentences(sentences, dataset) for sentences in sentence_generator)
+    for wavs in synthesize_stream(model, batches, peak_normalize=False, copy=True):
+        yield [wavs[b] for b in range(wavs.shape[0])]

@@ -265,3 +265,40 @@ def test_weights_through_the_checkpoint_importer_match_the_oracle(tmp_path, form
     eng.close()
     print('importer ({}) vs oracle: {}'.format(form, errs))
     assert errs['memory'] < 1e-4 and errs['mel'] < 1e-3 and errs['align'] < 1e-4 and errs['linear'] < 1e-3, errs
+
+
+def test_host_facade_two_calls_in_flight_equals_serial_calls(engine, hparams):
+    """tacotron.inference.synthesize_stream (host ids in, host waveforms out, two batches in flight: the upload of batch
+    k + 1 and the download of batch k - 1 overlap batch k) gives, bit for bit, what one serialised device call per batch
+    gives -- for batches of changing content and a changing sentence length (the second shape is new: unpipelined once)."""
+    Inf = pkg('tacotron.inference')
+    Tm = pkg('tacotron.model')
+    P = pkg('tacotron.params')
+    model = Tm.Tacotron(inputs=Tm.Tacotron.model_placeholders(), mode=Tm.Mode.PREDICT, engine=engine, hparams=hparams)
+    rng = np.random.default_rng(12)
+    shapes = [(5, 17), (5, 17), (5, 17), (3, 9), (3, 9), (5, 17)]
+    batches = []
+    for B, Ts in shapes:
+        ids = rng.integers(2, 39, (B, Ts)).astype(np.int32)
+        ids[:, -1] = 1
+        batches.append(ids)
+    S, n_iter = 8, 4
+    loader = P.dataset_params.dataset_loader
+    args = (S, loader.mel_mag_ref_db, loader.mel_mag_max_db, hparams.magnitude_power, n_iter, 1102, 275)
+    reset = np.full((2, 5), 2, np.int32)   # a call of another shape: both sequences then start unpipelined
+
+    engine.synthesize(reset, *args, seed=1)
+    got = [w.copy() for w in Inf.synthesize_stream(model, iter(batches), n_steps=S, n_iter=n_iter, seed=100, peak_normalize=True)]
+    assert len(got) == len(batches)
+    # the same calls on device-resident ids, each waited for before the next is made
+    engine.synthesize(reset, *args, seed=1)
+    for k, ids in enumerate(batches):
+        ref = engine.synthesize(engine.to_device(ids), *args, seed=100 + k, peak_normalize=True)
+        want = ref['wav'].to_host()
+        assert got[k].shape == want.shape == (ids.shape[0], 275 * (S * hparams.reduction - 1))
+        assert np.isfinite(got[k]).all() and np.abs(got[k]).max() > 0
+        assert np.array_equal(got[k], want), k
+    # tickets of calls whose buffers have been handed on are refused
+    sstts = pkg()
+    with pytest.raises(sstts.TtsError):
+        engine.wait_host(0)
