@@ -92,6 +92,7 @@ struct tts_handle_s {
     // configuration allows it.  0: never.
     int persistent_decoder = 1;
     int gl_stream = 1;               // Griffin-Lim iterations by gl_stream_kernel (a run = one stream through an LDS ring)
+    int gl_pair = 1;                 // ... two iterations per launch where nothing per-iteration is asked for
     int gl_fused = 0;                // all Griffin-Lim iterations of a call in one launch (gl_iter_kernel, FUSED): same
                                      // waveforms, measured no faster, so off unless asked for
     bool gl_fused_used = false;      // a fused launch has been enqueued since the last status check
@@ -959,14 +960,19 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
         h->gl_fused_used = true;
     } else {
         ProfScope ps(h, ST_GL_ITER, n_iter);
-        for (int it = 0; it < n_iter; ++it) {
+        // the streaming kernel runs two iterations per launch (gl_stream_kernel, NST = 2) wherever no per-iteration result
+        // is asked for: all of them, or all but the last (the mse is the last iteration's)
+        const bool pair_ok = stream && h->gl_pair != 0 && gl_stream_ring_frames(win, hop, 2) > 0;
+        for (int it = 0; it < n_iter;) {
+            const bool want_mse = mse && it == n_iter - 1;
+            const int n_stage = (pair_ok && it + 2 <= n_iter - (mse ? 1 : 0)) ? 2 : 1;
             p.phase_in = cur;
             p.phase_out = nxt;
-            p.mse_partial = (mse && it == n_iter - 1) ? msep : nullptr;
+            p.mse_partial = want_mse ? msep : nullptr;
             p.work_counter = counters + it;
-#ifdef GL_TIMELINE   // tools only: stamps of workgroup 0 during the last iteration
+#ifdef GL_TIMELINE   // tools only: stamps of workgroup 0 during the last launch
             WS(h, "gl.timeline", unsigned long long, 1024 + 64 * 16, tl);
-            if (it == n_iter - 1) {
+            if (it + n_stage >= n_iter) {
                 HIPCHK(h, hipMemsetAsync(tl, 0, (1024 + 64 * 16) * sizeof(unsigned long long), h->stream));
                 p.dbg = tl;
             }
@@ -974,9 +980,10 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
             // no more workgroups than the plan counts on: one that finds its compute unit taken (the call pipeline's other
             // stream) would start when the first of the others leaves, load its tables, find no item and only
             // lengthen the launch
-            if (stream) HIPCHK(h, launch_gl_stream(h->stream, p, free_cus, 0));
+            if (stream) HIPCHK(h, launch_gl_stream(h->stream, p, free_cus, 0, n_stage));
             else HIPCHK(h, launch_gl_iter(h->stream, p, free_cus, 0));
             std::swap(cur, nxt);
+            it += n_stage;
         }
 #ifdef GL_TIMELINE
         if (n_iter > 0) {
@@ -1027,7 +1034,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
         p.wav = wav;
         p.peak_partial = peak_normalize ? msep : nullptr;   // the mse partials are consumed by now
         p.work_counter = counters + n_iter;
-        if (stream) HIPCHK(h, launch_gl_stream(h->stream, p, free_cus, 1));
+        if (stream) HIPCHK(h, launch_gl_stream(h->stream, p, free_cus, 1, 1));
         else HIPCHK(h, launch_gl_iter(h->stream, p, free_cus, 1));
     }
     if (peak_normalize) HIPCHK(h, launch_peak_scale(h->stream, wav, B, hop * (T - 1), msep, nchunks));
@@ -1198,6 +1205,7 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     else if (!std::strcmp(key, "persistent_decoder")) h->persistent_decoder = value;
     else if (!std::strcmp(key, "gl_fused")) h->gl_fused = value;
     else if (!std::strcmp(key, "gl_stream")) h->gl_stream = value;
+    else if (!std::strcmp(key, "gl_pair")) h->gl_pair = value;
     else if (!std::strcmp(key, "pd_debug_delay")) pd_debug_delay = value;   // tests only (decoder_persistent.hip)
     else if (!std::strcmp(key, "reserve_cus")) {
         h->reserve_cus = value;

@@ -34,7 +34,8 @@ struct GlParams {
     int n_classes, n_items, slots_per_utt;
     int cls_C[GL_MAX_CLASSES], cls_n[GL_MAX_CLASSES], cls_t0[GL_MAX_CLASSES], cls_slot0[GL_MAX_CLASSES],
         cls_first[GL_MAX_CLASSES], cls_chunks[GL_MAX_CLASSES];
-    int ring_frames;         // streaming form (gl_stream_kernel): frames the LDS ring holds
+    int ring_frames;         // streaming form (gl_stream_kernel): frames an LDS ring holds
+    int n_stage;             // ... iterations per launch (1 or 2), set by launch_gl_stream
     unsigned* work_counter;  // zeroed counter of THIS launch: the persistent workgroups draw item ids from it
     // fused launch (launch_gl_fused): n_fused iterations, iteration i reads buf[i & 1] and writes buf[(i + 1) & 1]
     int n_fused;
@@ -50,9 +51,9 @@ int gl_max_item_frames(int win, int hop);
 void gl_build_wlane(const float* window, const float* rwss, int win, int hop, int T, float* out);
 void gl_plan_items(GlParams& p, int n_workers);   // needs T, B, win, hop, ncol; sets C and the item classes
 // streaming form of the iteration / final iSTFT (gl_stream_kernel): no chunks, a run is one stream through an LDS ring
-int gl_stream_ring_frames(int win, int hop);      // 0: the window / hop pair does not fit
-void gl_plan_stream(GlParams& p, int n_workers);  // needs T, B, win, hop, ncol; sets ring_frames and the item classes
-hipError_t launch_gl_stream(hipStream_t s, const GlParams& p, int n_cus, int final_istft);
+int gl_stream_ring_frames(int win, int hop, int n_stage = 1);   // 0: the window / hop pair does not fit
+void gl_plan_stream(GlParams& p, int n_workers);  // needs T, B, win, hop, ncol; sets the item classes
+hipError_t launch_gl_stream(hipStream_t s, const GlParams& p, int n_cus, int final_istft, int n_stage = 1);
 hipError_t gl_configure();
 hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int n_cus, int final_istft);
 hipError_t launch_gl_fused(hipStream_t s, const GlParams& p, int n_cus);

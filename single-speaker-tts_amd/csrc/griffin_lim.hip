@@ -910,6 +910,10 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
 }
 
 
+#ifdef GL_CLOCK   // tools only: shader clock held during every launch (workgroup 0), read back by gl_clock_dump()
+__device__ unsigned long long gl_clock_log[4096][2];
+__device__ unsigned gl_clock_n;
+#endif
 // ====================================================================================== streaming form
 // One Griffin-Lim iteration (MODE 0) or the final iSTFT (MODE 1) WITHOUT phases: a run of consecutive frames of one
 // utterance is a stream.  Frame index i of the run (frame t = run_t0 - halo + i, halo = ncol - 1) belongs to wave
@@ -939,10 +943,19 @@ __global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
 // span crosses the lap end (the final values of the wrapped part are at the ring's start, not in the guard) take an
 // index-mapped read path: 4 + (halo + ceil(S / hop)) / R of the frames.
 // MODE 1 writes out, straight from the overlap-add's registers, the hop samples that index i makes final.
-enum { CT_OLA = 0, CT_SNEXT = 1, CT_SWORDS = 16 };
+enum { CT_OLA = 0, CT_SNEXT = 1, CT_OLB = 2, CT_SWORDS = 16 };
 
-template <int MODE, int WIN_CT, int HOP_CT, bool MSE>
+// NST = 2: TWO iterations per launch.  The kernel draws a constant amount of power per instruction and per byte, and
+// with the spectra streaming the chip holds a shader clock of ~1.9 GHz against ~2.3 GHz for the same arithmetic without
+// memory traffic (tools: -DGL_CLOCK): what shortens the launch is energy, not overlap.  So the second iteration is fed
+// from registers: stage A is the iteration above on ring A; its merged spectrum of frame t - lag is normalised to
+// |S| e^{i phi} where it stands (no phasor code written, none read back: 8 instead of 12 bytes per bin and iteration,
+// ~90 VALU instructions per frame and iteration less) and goes straight into stage B -- inverse FFT, overlap-add into
+// ring B in the order of ITS chain, forward FFT of frame t - 2 lag, phasor code, store.  A run then needs halo + lag
+// more frames at either end in stage A (2.6 % more transforms for runs of 144 frames).
+template <int MODE, int WIN_CT, int HOP_CT, bool MSE, int NST = 1>
 __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
+    static_assert(NST == 1 || (NST == 2 && MODE == 0 && !MSE), "two iterations per launch: plain iterations only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int win = WIN_CT ? WIN_CT : p.win;
     const int hop = HOP_CT ? HOP_CT : p.hop;
@@ -960,11 +973,13 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
     const int lag = (halo + 1) * hop > 2 * (MH - wpad) ? halo : halo + 1;
     const int R = p.ring_frames;
     const int ring_len = hop * R;
+    const int ring_floats = (ring_len + acc_len + 128 + 3) & ~3;
     const int L = hop * (p.T - 1);                     // samples of the (trimmed) signal
-    // carve: [exchange: GL_NW * EX_CPLX cf][control][ring: ring_len + acc_len + 128 floats]
+    // carve: [exchange: GL_NW * EX_CPLX cf][control][ring A: ring_len + acc_len + 128 floats][ring B]
     cf* ex_all = reinterpret_cast<cf*>(smem_raw);
     int* ctrl = reinterpret_cast<int*>(ex_all + GL_NW * EX_CPLX);
-    float* ring = reinterpret_cast<float*>(ctrl + CT_SWORDS);
+    float* ringA = reinterpret_cast<float*>(ctrl + CT_SWORDS);
+    float* ringB = ringA + ring_floats;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1034,9 +1049,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                       \
         const unsigned* prow_ = (BASE_C) + (size_t)tf_ * p.FP + lane;                           \
         const float* srow_ = (BASE_M) + (size_t)tf_ * p.FP + lane;                              \
-        GLS_WIDE_LOADS(prow_, srow_) {                                                          \
         _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = GL_ABL_LD(prow_[64 * j_], (unsigned)(tf_ * 64 + j_) * 0x9E3779B9u);              \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_ABL_LD(GL_STREAM_LOAD(srow_ + 64 * j_), (float)(tf_ + j_ + lane)); }\
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_ABL_LD(GL_STREAM_LOAD(srow_ + 64 * j_), (float)(tf_ + j_ + lane)); \
         nyq_c = prow_[MH - lane];                                                               \
         nyq_s = srow_[MH - lane];                                                               \
     }
@@ -1053,19 +1067,6 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
     asm volatile("" : "+v"(gs[0]), "+v"(gs[1]), "+v"(gs[2]), "+v"(gs[3]), "+v"(gs[4]), "+v"(gs[5]), "+v"(gs[6]),       \
                       "+v"(gs[7]), "+v"(gs[8]), "+v"(gs[9]), "+v"(gs[10]), "+v"(gs[11]), "+v"(gs[12]), "+v"(gs[13]), \
                       "+v"(gs[14]), "+v"(gs[15]), "+v"(nyq_s));
-#ifdef GL_ABL_WIDE   // tools only: the same bytes with a quarter of the memory instructions (wrong layout: garbage results)
-#define GLS_WIDE_LOADS(PR, SR)                                                                                 \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                        \
-        const uint4 c4_ = reinterpret_cast<const uint4*>((PR) - lane)[lane + 64 * q_];                         \
-        typedef float gl_f4_ __attribute__((ext_vector_type(4)));                                              \
-        const gl_f4_ m4_ = __builtin_nontemporal_load(reinterpret_cast<const gl_f4_*>((SR) - lane) + lane + 64 * q_); \
-        gc[4 * q_] = c4_.x; gc[4 * q_ + 1] = c4_.y; gc[4 * q_ + 2] = c4_.z; gc[4 * q_ + 3] = c4_.w;            \
-        gs[4 * q_] = m4_.x; gs[4 * q_ + 1] = m4_.y; gs[4 * q_ + 2] = m4_.z; gs[4 * q_ + 3] = m4_.w;            \
-    }                                                                                                          \
-    if (false)
-#else
-#define GLS_WIDE_LOADS(PR, SR)
-#endif
     const unsigned* x_in = reinterpret_cast<const unsigned*>(p.phase_in);
     unsigned* x_out = reinterpret_cast<unsigned*>(p.phase_out);
 
@@ -1095,6 +1096,162 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
 #else
 #define GLS_URGENCY(NEXT_INDEX)
 #endif
+
+    // ---------------- the pieces of an iteration (all inlined; `v` is the wave's FFT register set)
+    // X[k] (bins lane + 64 j, Nyquist bin apart) -> input of the inverse transform (real-FFT split pass)
+    auto split_pass = [&](cf (&gk)[16], cf nyq, cf (&v)[16]) __attribute__((always_inline)) {
+        cf gm[16];   // the mirrored bins X[MH - k]
+        mirror_bins(gk, gm, ex, lane, nyq);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            cf xk = gk[j];
+            cf xr = gm[j];                                         // xm = conj(xr)
+            if (j == 0 && lane == 0) { xk.y = 0.f; xr.y = 0.f; }   // DC and Nyquist bins are real
+            // Zin = E + i O, E = (xk + xm)/2, O = conj(tw) (xk - xm)/2; the transform is fed conj(Zin), the
+            // two 1/2 are in the window.  For j >= 8, conj(tw) = i conj(twr[j - 8]): conj(E + i i O') = conj(E - O')
+            const cf e = cadd_conj(xk, xr);
+            const cf o = cmul_conj(csub_conj(xk, xr), twr[j & 7]);
+            v[j] = j < 8 ? cconj_add_pi(e, o) : cconj_sub(e, o);
+        }
+    };
+    // z[m] = conj(v) / MH, m = lane + 64 c: x[2m] = Re, x[2m+1] = Im; synthesis window (with 1 / window-sum-square)
+    auto synth_window = [&](int t, cf (&v)[16]) __attribute__((always_inline)) {
+        if (t >= halo && t + halo < p.T) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] = v[c] * cmk(wsyn[c][0], -wsyn[c][1]);
+        } else {
+            // frame near an utterance end: fewer overlapping neighbours, 1 / wss per sample (rare)
+            const float* rwp = p.rwss + (size_t)t * hop + wpad;
+#pragma unroll
+            for (int c0 = 0; c0 < 16; c0 += 4) {
+#pragma unroll
+                for (int c = c0; c < c0 + 4; ++c) {
+                    const int nw0 = 2 * (lane + 64 * c) - wpad;
+                    const bool i0 = nw0 >= 0 && nw0 < win, i1 = nw0 + 1 >= 0 && nw0 + 1 < win;
+                    const float r0 = rwp[i0 ? nw0 : 0], r1 = rwp[i1 ? nw0 + 1 : 0];
+                    v[c] = cmk(i0 ? v[c].x * wana[c][0] * r0 : 0.f, i1 ? -v[c].y * wana[c][1] * r1 : 0.f);
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+    };
+    // overlap-add of index idx (ring slot s, frame t) into `ring`, in the order of the chain word `chain`
+    float pk = 0.f;
+    auto overlap_add = [&](float* ring, int chain, int idx, int s, int t, int b, int run_t0, int run_len, const cf (&v)[16])
+                           __attribute__((always_inline)) {
+#ifndef GL_ABL_NOFLAG
+        while (gl_flag_load(ctrl + chain) < idx) __builtin_amdgcn_s_sleep(1);
+#endif
+        asm volatile("" ::: "memory");
+        {
+            float* wr = ring + hop * s + 2 * lane;
+            const float* rd = wr + (s == 0 ? ring_len : 0);       // first index of a lap: fold the guard in
+            // MODE 1: span samples [q_fin, q_fin + hop) of this index are final now; y of span sample 0
+            const int q_fin = wpad - fs;
+            const int y0 = t * hop + fs - MH;
+            const bool emit = MODE == 1 && (t >= run_t0 || run_t0 == 0) && (t < run_t0 + run_len || run_t0 + run_len == p.T);
+            float* wb = MODE == 1 ? p.wav + (size_t)b * L : nullptr;
+            // All reads first, then the adds, then the writes: written slot by slot, every read waits for the
+            // previous slot's write (the compiler cannot tell that they do not alias) and the critical section of
+            // the chain is eight LDS round trips instead of one.
+            float o[16][2];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int j = c - c_lo;
+                o[c][0] = o[c][1] = 0.f;
+                if (j < 0 || j >= n_sl) continue;                  // wave-uniform (static for the reference window)
+                const int qb = 128 * j;
+                if (qb < acc_len) { o[c][0] = rd[qb]; o[c][1] = rd[qb + 1]; }
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int j = c - c_lo;
+                if (j < 0 || j >= n_sl) continue;
+                const int qb = 128 * j;
+                float a0 = o[c][0], a1 = o[c][1];
+                if (qb < acc_len && qb + 127 >= acc_len) {         // the slot where accumulate turns into store
+                    a0 = qb + 2 * lane < acc_len ? a0 : 0.f;
+                    a1 = qb + 2 * lane + 1 < acc_len ? a1 : 0.f;
+                }
+                a0 += v[c].x;
+                a1 += v[c].y;
+                wr[qb] = a0;
+                wr[qb + 1] = a1;
+                if (MODE == 1 && qb + 127 >= q_fin && qb < q_fin + hop) {   // slot holds final samples (wave-uniform)
+                    const int q = qb + 2 * lane;
+                    const int y = y0 + q;
+                    if (emit && q >= q_fin && q < q_fin + hop && y >= 0 && y < L) { wb[y] = a0; pk = fmaxf(pk, fabsf(a0)); }
+                    if (emit && q + 1 >= q_fin && q + 1 < q_fin + hop && y + 1 >= 0 && y + 1 < L) { wb[y + 1] = a1; pk = fmaxf(pk, fabsf(a1)); }
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (lane == 0) gl_flag_store(ctrl + chain, idx + 1);
+    };
+    // windowed input of the forward transform of frame tm, whose overlap-add index was idx - lag (ring slot sm), read in
+    // the iteration of index idx of its stage (y_base: trimmed-signal index of that stage's ring coordinate 0)
+    auto fft_input = [&](const float* ring, int idx, int sm, int tm, int y_base, cf (&v)[16]) __attribute__((always_inline)) {
+        const int ylo = tm * hop + wpad - MH;                    // y index of window sample 0
+        const bool edge = ylo < 0 || ylo + win > L;              // reflect padding needed
+        // The span is read linearly when it does not cross the end of the lap, or when the next lap's fold (index
+        // m + R - sm) has not happened yet: what it will fold is still in the guard, behind the ring.
+        if (!edge && (hop * sm + S <= ring_len || R - sm > lag)) {
+            const float* sf = ring + hop * sm + 2 * lane;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int j = c - c_lo;
+                if (j < 0 || j >= n_sl) v[c] = cmk(0.f, 0.f);
+                else v[c] = cmk(wana[c][0] * sf[128 * j], wana[c][1] * sf[128 * j + 1]);
+            }
+        } else {
+            // index-mapped reads: reflect at the signal's ends; run coordinate u = lap * ring_len + off lives at
+            // ring position off -- unless off < acc_len and that lap's fold (index lap * R) is still to come:
+            // then it is in the guard
+            const int lap0 = (idx - lag) / R;
+            const int ub = y_base + lap0 * ring_len;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                float x[2] = {0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int f = 2 * (lane + 64 * c) + e;
+                    const int nw = f - wpad;
+                    if (nw >= 0 && nw < win) {
+                        int y = ylo + nw;
+                        y = y < 0 ? -y : y;
+                        y = y >= L ? 2 * (L - 1) - y : y;
+                        int off = y - ub, lap = lap0;
+                        if (off >= ring_len) { off -= ring_len; ++lap; }
+                        else if (off < 0) { off += ring_len; --lap; }
+                        const int pos = (off < acc_len && lap * R > idx) ? ring_len + off : off;
+                        x[e] = wana[c][e] * ring[pos];
+                    }
+                }
+                v[c] = cmk(x[0], x[1]);
+            }
+        }
+    };
+    // forward transform output (v, after fft1024) -> X[k] / MH per bin (real-FFT merge pass); sink(c, x) gets bin lane + 64 c
+    auto merge_pass = [&](const cf (&v)[16], auto&& sink) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
+        wave_lds_sync();
+        cf zmr[16];   // all mirrored bins first: one LDS latency for the pass instead of one per bin
+#pragma unroll
+        for (int c = 0; c < 16; ++c) zmr[c] = ex[(MH - (lane + 64 * c)) & (MH - 1)];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const cf zk = v[c];
+            // zm = conj(zmr); 2 X[k] = (zk + zm) - i tw (zk - zm); for c >= 8, tw = -i twr[c - 8]: X = E - O'
+            const cf e = cadd_conj(zk, zmr[c]);
+            const cf o = cmul(csub_conj(zk, zmr[c]), twr[c & 7]);
+            sink(c, c < 8 ? cadd_mi(e, o) : csub(e, o));
+        }
+        wave_lds_sync();
+    };
+
+    const int lead = NST == 2 ? 2 * halo : halo;   // frames the first index lies before the run
     bool have_row = false;   // (per wave) the first row of this run was requested in the last iteration of the previous one
     while (item < p.n_items) {
         int b, run_t0, run_len, slot;
@@ -1103,142 +1260,122 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         const unsigned* phb = x_in + (size_t)b * p.T * p.FP;
         unsigned next_item_reg = 0;
         if (tid == 0) next_item_reg = atomicAdd(p.work_counter, 1u);
-        if (!have_row) GLS_LOAD_ROW(phb, magb, run_t0 - halo + wave)
+        if (!have_row) GLS_LOAD_ROW(phb, magb, run_t0 - lead + wave)
         have_row = false;
-        // run start: the guard reads as zero for index 0, the chain starts at 0
-        for (int q = tid; q < acc_len + 128; q += GL_THREADS) ring[ring_len + q] = 0.f;
-        if (tid == 0) { ctrl[CT_OLA] = 0; ctrl[CT_SNEXT] = (int)next_item_reg; }
+        // run start: the guards read as zero for index 0, the chains start at 0
+        for (int q = tid; q < acc_len + 128; q += GL_THREADS) {
+            ringA[ring_len + q] = 0.f;
+            if (NST == 2) ringB[ring_len + q] = 0.f;
+        }
+        if (tid == 0) { ctrl[CT_OLA] = 0; ctrl[CT_OLB] = 0; ctrl[CT_SNEXT] = (int)next_item_reg; }
         __syncthreads();
         const int next_item = __builtin_amdgcn_readfirstlane(ctrl[CT_SNEXT]);
         int nb = b, nt0 = 0, nlen = 0, nslot = 0;
         if (next_item < p.n_items) decode_item(next_item, nb, nt0, nlen, nslot);
 
-        const int n_idx = run_len + halo + lag;
-        const int y_base = (run_t0 - halo) * hop - MH + fs;   // trimmed-signal index of ring coordinate 0 (lap 0)
-        float mse_acc = 0.f, pk = 0.f;
+        // stage B (the only stage of NST == 1) has the indices of one iteration, j <-> frame run_t0 - halo + j; stage A of
+        // NST == 2 runs halo + lag indices ahead of it: i = j + halo + lag <-> frame run_t0 - 2 halo + i
+        const int n_idx_b = run_len + halo + lag;
+        const int n_idx = NST == 2 ? n_idx_b + halo + lag : n_idx_b;
+        const int y_base_a = (run_t0 - lead) * hop - MH + fs;   // trimmed-signal index of ring coordinate 0 (lap 0)
+        const int y_base_b = (run_t0 - halo) * hop - MH + fs;
+        float mse_acc = 0.f;
+        pk = 0.f;
         int s = wave % R;                                     // ring slot of this wave's index (wave < 8 <= R)
         GLS_TOUCH_ROW()
         for (int i = wave; i < n_idx; i += GL_NW) {
-            const int t = run_t0 - halo + i;
+            const int t = run_t0 - lead + i;
             const bool valid = t >= 0 && t < p.T;             // wave-uniform
             GLS_STAMP()   // 0: iteration start
             GLS_URGENCY(i)
             cf v[16];
             if (valid) {
-                cf gk[16], gm[16];   // X[k] = |S[k]| * phasor[k] and the mirrored bins X[MH - k]
+                cf gk[16];   // X[k] = |S[k]| * phasor[k]
 #pragma unroll
                 for (int j = 0; j < 16; ++j) gk[j] = gl_unpack_phasor(gc[j], gs[j]);
-                const cf nyq = cmk(gl_unpack_phasor(nyq_c, nyq_s).x, 0.f);
-                mirror_bins(gk, gm, ex, lane, nyq);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    cf xk = gk[j];
-                    cf xr = gm[j];                                         // xm = conj(xr)
-                    if (j == 0 && lane == 0) { xk.y = 0.f; xr.y = 0.f; }   // DC and Nyquist bins are real
-                    // Zin = E + i O, E = (xk + xm)/2, O = conj(tw) (xk - xm)/2; the transform is fed conj(Zin), the
-                    // two 1/2 are in the window.  For j >= 8, conj(tw) = i conj(twr[j - 8]): conj(E + i i O') = conj(E - O')
-                    const cf e = cadd_conj(xk, xr);
-                    const cf o = cmul_conj(csub_conj(xk, xr), twr[j & 7]);
-                    v[j] = j < 8 ? cconj_add_pi(e, o) : cconj_sub(e, o);
-                }
+                split_pass(gk, cmk(gl_unpack_phasor(nyq_c, nyq_s).x, 0.f), v);
             } else {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) v[j] = cmk(0.f, 0.f);
             }
             GLS_STAMP()   // 1: decoded, split
             GLS_URGENCY(i)
-            // the row is consumed: request this wave's next one (of this run, or the first of the next item)
-            if (i + GL_NW < n_idx) {
-                GLS_LOAD_ROW(phb, magb, t + GL_NW)
-            } else if (next_item < p.n_items) {
-                GLS_LOAD_ROW(x_in + (size_t)nb * p.T * p.FP, p.mag + (size_t)nb * p.T * p.FP, nt0 - halo + wave)
-                have_row = true;
+            // the row is consumed.  NST == 1: request this wave's next one now (of this run, or the first of the next
+            // item).  NST == 2: the magnitude registers first take |S| of the frame that goes from stage A to stage B
+#define GLS_NEXT_ROW()                                                                                                   \
+            if (i + GL_NW < n_idx) {                                                                                     \
+                GLS_LOAD_ROW(phb, magb, t + GL_NW)                                                                       \
+            } else if (next_item < p.n_items) {                                                                          \
+                GLS_LOAD_ROW(x_in + (size_t)nb * p.T * p.FP, p.mag + (size_t)nb * p.T * p.FP, nt0 - lead + wave)         \
+                have_row = true;                                                                                         \
+            }
+            const int jb = i - (halo + lag);                  // stage B index of this iteration (NST == 2)
+            const int tb = t - lag;                           // ... and its frame = run_t0 - halo + jb
+            const bool valid_b = NST == 2 && jb >= 0 && tb >= 0 && tb < p.T;
+            if (NST == 1) {
+                GLS_NEXT_ROW()
+            } else {
+                const int tq = tb < 0 ? 0 : (tb >= p.T ? p.T - 1 : tb);
+                const float* mrow_ = magb + (size_t)tq * p.FP + lane;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) gs[j] = mrow_[64 * j];
+                nyq_s = mrow_[MH - lane];
             }
             if (valid) {
                 fft1024(v, ex, tw, lane);
-                // z[m] = conj(v) / MH, m = lane + 64 c: x[2m] = Re, x[2m+1] = Im; synthesis window (with 1 / wss)
-                if (t >= halo && t + halo < p.T) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) v[c] = v[c] * cmk(wsyn[c][0], -wsyn[c][1]);
-                } else {
-                    // frame near an utterance end: fewer overlapping neighbours, 1 / wss per sample (rare)
-                    const float* rwp = p.rwss + (size_t)t * hop + wpad;
-#pragma unroll
-                    for (int c0 = 0; c0 < 16; c0 += 4) {
-#pragma unroll
-                        for (int c = c0; c < c0 + 4; ++c) {
-                            const int nw0 = 2 * (lane + 64 * c) - wpad;
-                            const bool i0 = nw0 >= 0 && nw0 < win, i1 = nw0 + 1 >= 0 && nw0 + 1 < win;
-                            const float r0 = rwp[i0 ? nw0 : 0], r1 = rwp[i1 ? nw0 + 1 : 0];
-                            v[c] = cmk(i0 ? v[c].x * wana[c][0] * r0 : 0.f, i1 ? -v[c].y * wana[c][1] * r1 : 0.f);
-                        }
-                        asm volatile("" ::: "memory");
-                    }
-                }
+                synth_window(t, v);
             }
             GLS_STAMP()   // 2: inverse FFT + window done
-            // ---------------- overlap-add, in index order
-#ifndef GL_ABL_NOFLAG
-            while (gl_flag_load(ctrl + CT_OLA) < i) __builtin_amdgcn_s_sleep(1);
-#endif
-            asm volatile("" ::: "memory");
-            GLS_STAMP()   // 3: my turn in the chain
-            {
-                float* wr = ring + hop * s + 2 * lane;
-                const float* rd = wr + (s == 0 ? ring_len : 0);       // first index of a lap: fold the guard in
-                // MODE 1: span samples [q_fin, q_fin + hop) of this index are final now; y of span sample 0
-                const int q_fin = wpad - fs;
-                const int y0 = t * hop + fs - MH;
-                const bool emit = MODE == 1 && (t >= run_t0 || run_t0 == 0) && (t < run_t0 + run_len || run_t0 + run_len == p.T);
-                float* wb = MODE == 1 ? p.wav + (size_t)b * L : nullptr;
-                // All reads first, then the adds, then the writes: written slot by slot, every read waits for the
-                // previous slot's write (the compiler cannot tell that they do not alias) and the critical section of
-                // the chain is eight LDS round trips instead of one.
-                float o[16][2];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const int j = c - c_lo;
-                    o[c][0] = o[c][1] = 0.f;
-                    if (j < 0 || j >= n_sl) continue;                  // wave-uniform (static for the reference window)
-                    const int qb = 128 * j;
-                    if (qb < acc_len) { o[c][0] = rd[qb]; o[c][1] = rd[qb + 1]; }
-                }
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const int j = c - c_lo;
-                    if (j < 0 || j >= n_sl) continue;
-                    const int qb = 128 * j;
-                    float a0 = o[c][0], a1 = o[c][1];
-                    if (qb < acc_len && qb + 127 >= acc_len) {         // the slot where accumulate turns into store
-                        a0 = qb + 2 * lane < acc_len ? a0 : 0.f;
-                        a1 = qb + 2 * lane + 1 < acc_len ? a1 : 0.f;
-                    }
-                    a0 += v[c].x;
-                    a1 += v[c].y;
-                    wr[qb] = a0;
-                    wr[qb + 1] = a1;
-                    if (MODE == 1 && qb + 127 >= q_fin && qb < q_fin + hop) {   // slot holds final samples (wave-uniform)
-                        const int q = qb + 2 * lane;
-                        const int y = y0 + q;
-                        if (emit && q >= q_fin && q < q_fin + hop && y >= 0 && y < L) { wb[y] = a0; pk = fmaxf(pk, fabsf(a0)); }
-                        if (emit && q + 1 >= q_fin && q + 1 < q_fin + hop && y + 1 >= 0 && y + 1 < L) { wb[y + 1] = a1; pk = fmaxf(pk, fabsf(a1)); }
-                    }
-                }
+            overlap_add(ringA, CT_OLA, i, s, t, b, run_t0, run_len, v);
+            GLS_STAMP()   // 3: overlap-add issued, flag passed on
+            if (NST == 1) {
+                // the next row has arrived (requested before the inverse FFT) -- settled on every path round the loop, at
+                // the point of the iteration where the fewest registers are live, before this iteration's stores are issued
+                GLS_TOUCH_ROW()
             }
-            asm volatile("" ::: "memory");
-            if (lane == 0) gl_flag_store(ctrl + CT_OLA, i + 1);
-            // the next row has arrived (requested before the inverse FFT) -- settled on every path round the loop, at the
-            // point of the iteration where the fewest registers are live, before this iteration's stores are issued
-            GLS_STAMP()   // 4: overlap-add issued, flag passed on
-            GLS_TOUCH_ROW()
-            GLS_STAMP()   // 5: next row has arrived
             GLS_URGENCY(i + GL_NW)
 
-            // ---------------- forward FFT of frame t - lag: its signal is final
-            if (MODE == 0 && i >= halo + lag && i < halo + lag + run_len) {
-                const int tm = t - lag;                                  // in [run_t0, run_t0 + run_len), < T
-                int sm = s - lag;
+            int sb = s, jj = i;   // ring slot / index of the stage whose forward transform writes the new spectrum
+            if (NST == 2) {
+                sb = s - (halo + lag);
+                sb += sb < 0 ? R : 0;
+                jj = jb;
+                // ---------------- stage A -> stage B: forward FFT of frame tb, normalised to |S| e^{i phi} in registers
+                if (valid_b) {
+                    int sm = s - lag;
+                    sm += sm < 0 ? R : 0;
+                    fft_input(ringA, i, sm, tb, y_base_a, v);
+                    fft1024(v, ex, tw, lane);
+                    cf gk[16];
+                    // |S| e^{i phi}: x * (|S| / |x|), and (|S|, 0) for a zero bin (numpy's exp(1j * angle(0)) = 1); the
+                    // bins are X / MH of a windowed signal, far from both ends of the float range
+                    merge_pass(v, [&](int c, cf x) {
+                        const float s2 = fmaf(x.x, x.x, x.y * x.y);
+                        const float g = gs[c] * __builtin_amdgcn_rsqf(s2);
+                        const bool nz = s2 > 1.0e-37f;
+                        gk[c] = cmk(nz ? x.x * g : gs[c], nz ? x.y * g : 0.f);
+                    });
+                    const float xn = v[0].x - v[0].y;   // Nyquist bin (lane 0), real: phasor (-1, 0) / (1, 0)
+                    split_pass(gk, cmk(xn < 0.f ? -nyq_s : nyq_s, 0.f), v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) v[j] = cmk(0.f, 0.f);
+                }
+                GLS_NEXT_ROW()
+                if (jb >= 0) {
+                    if (valid_b) {
+                        fft1024(v, ex, tw, lane);
+                        synth_window(tb, v);
+                    }
+                    overlap_add(ringB, CT_OLB, jb, sb, tb, b, run_t0, run_len, v);
+                }
+                GLS_TOUCH_ROW()
+            }
+            GLS_STAMP()   // 4
+            // ---------------- forward FFT of the frame `lag` behind: its signal is final
+            if (MODE == 0 && jj >= halo + lag && jj < halo + lag + run_len) {
+                const int tm = (NST == 2 ? tb : t) - lag;                // in [run_t0, run_t0 + run_len), < T
+                int sm = sb - lag;
                 sm += sm < 0 ? R : 0;
                 const float* mrow = magb + (size_t)tm * p.FP;
                 float mg[16];
@@ -1246,84 +1383,22 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
 #pragma unroll
                     for (int c = 0; c < 16; ++c) mg[c] = fabsf(GL_STREAM_LOAD(mrow + lane + 64 * c));
                 }
-                const int ylo = tm * hop + wpad - MH;                    // y index of window sample 0
-                const bool edge = ylo < 0 || ylo + win > L;              // reflect padding needed
-                // The span is read linearly when it does not cross the end of the lap, or when the next lap's fold (index
-                // m + R - sm) has not happened yet: what it will fold is still in the guard, behind the ring.
-                if (!edge && (hop * sm + S <= ring_len || R - sm > lag)) {
-                    const float* sf = ring + hop * sm + 2 * lane;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        const int j = c - c_lo;
-                        if (j < 0 || j >= n_sl) v[c] = cmk(0.f, 0.f);
-                        else v[c] = cmk(wana[c][0] * sf[128 * j], wana[c][1] * sf[128 * j + 1]);
-                    }
-                } else {
-                    // index-mapped reads: reflect at the signal's ends; run coordinate u = lap * ring_len + off lives at
-                    // ring position off -- unless off < acc_len and that lap's fold (index lap * R) is still to come:
-                    // then it is in the guard
-                    const int lap0 = (i - lag) / R;
-                    const int ub = y_base + lap0 * ring_len;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        float x[2] = {0.f, 0.f};
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const int f = 2 * (lane + 64 * c) + e;
-                            const int nw = f - wpad;
-                            if (nw >= 0 && nw < win) {
-                                int y = ylo + nw;
-                                y = y < 0 ? -y : y;
-                                y = y >= L ? 2 * (L - 1) - y : y;
-                                int off = y - ub, lap = lap0;
-                                if (off >= ring_len) { off -= ring_len; ++lap; }
-                                else if (off < 0) { off += ring_len; --lap; }
-                                const int pos = (off < acc_len && lap * R > i) ? ring_len + off : off;
-                                x[e] = wana[c][e] * ring[pos];
-                            }
-                        }
-                        v[c] = cmk(x[0], x[1]);
-                    }
-                }
+                fft_input(NST == 2 ? ringB : ringA, jj, sm, tm, NST == 2 ? y_base_b : y_base_a, v);
                 fft1024(v, ex, tw, lane);
-                GLS_STAMP()   // 6: forward FFT done
+                GLS_STAMP()   // 5: forward FFT done
                 GLS_URGENCY(i + GL_NW)
-#pragma unroll
-                for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
-                wave_lds_sync();
                 unsigned* orow = x_out + ((size_t)b * p.T + tm) * p.FP;
-#ifdef GL_ABL_WIDE
-                unsigned wide_[4];
-#endif
-                cf zmr[16];   // all mirrored bins first: one LDS latency for the pass instead of one per bin
-#pragma unroll
-                for (int c = 0; c < 16; ++c) zmr[c] = ex[(MH - (lane + 64 * c)) & (MH - 1)];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const int k = lane + 64 * c;
-                    const cf zk = v[c];
-                    // zm = conj(zmr); 2 X[k] = (zk + zm) - i tw (zk - zm); for c >= 8, tw = -i twr[c - 8]: X = E - O'
-                    const cf e = cadd_conj(zk, zmr[c]);
-                    const cf o = cmul(csub_conj(zk, zmr[c]), twr[c & 7]);
-                    const cf x = c < 8 ? cadd_mi(e, o) : csub(e, o);
+                merge_pass(v, [&](int c, cf x) {
 #ifdef GL_ABL_NOSTORE
-                    if (__float_as_uint(x.x) == 0x12345678u) __builtin_nontemporal_store(gl_pack_phasor(x), orow + k);
-#elif defined(GL_ABL_WIDE)
-                    wide_[c & 3] = gl_pack_phasor(x);
-                    if ((c & 3) == 3) {
-                        typedef unsigned gl_u4_ __attribute__((ext_vector_type(4)));
-                        __builtin_nontemporal_store((gl_u4_){wide_[0], wide_[1], wide_[2], wide_[3]}, reinterpret_cast<gl_u4_*>(orow) + lane + 64 * (c >> 2));
-                    }
-#elif defined(GL_PLAIN_STORE)
-                    orow[k] = gl_pack_phasor(x);
+                    if (__float_as_uint(x.x) == 0x12345678u) __builtin_nontemporal_store(gl_pack_phasor(x), orow + lane + 64 * c);
 #else
-                    __builtin_nontemporal_store(gl_pack_phasor(x), orow + k);
+                    __builtin_nontemporal_store(gl_pack_phasor(x), orow + lane + 64 * c);
 #endif
                     if (MSE) {
                         const float d = mg[c] - (float)MH * sqrtf(fmaf(x.x, x.x, x.y * x.y));   // x = X / MH
                         mse_acc += d * d;
                     }
-                }
+                });
                 if (lane == 0) {
                     const cf z0 = v[0];
                     const float xn = z0.x - z0.y;   // Nyquist bin, real
@@ -1333,14 +1408,13 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                         mse_acc += d * d;
                     }
                 }
-                wave_lds_sync();
-                GLS_STAMP()   // 7: merged, encoded, stores issued
+                GLS_STAMP()   // 6: merged, encoded, stores issued
             }
             s += GL_NW;
             s -= s >= R ? R : 0;
         }
         __builtin_amdgcn_s_setprio(0);
-        // ---------------- run end: per-run partial results (fixed order), then everyone is done with the ring
+        // ---------------- run end: per-run partial results (fixed order), then everyone is done with the rings
         if ((MODE == 0 && MSE) || (MODE == 1 && p.peak_partial)) {
             float r = MODE == 0 ? mse_acc : pk;
 #pragma unroll
@@ -1350,7 +1424,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
             if (lane == 0) red[wave] = r;
             __syncthreads();
             if (tid == 0) {
-                float a = MODE == 0 ? 0.f : 0.f;
+                float a = 0.f;
                 for (int w = 0; w < GL_NW; ++w) a = MODE == 0 ? a + red[w] : fmaxf(a, red[w]);
                 (MODE == 0 ? p.mse_partial : p.peak_partial)[(size_t)b * p.slots_per_utt + slot] = a;
             }
@@ -1365,12 +1439,14 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
     }
 #endif
 #ifdef GL_CLOCK
-    if (tid == 0 && (blockIdx.x & 63) == 0 && MODE == 0) {
+    if (tid == 0 && blockIdx.x == 0 && MODE == 0) {
         const unsigned long long dt = __builtin_amdgcn_s_memtime() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
-        printf("wg %3d: %.1f us, shader clock %.0f MHz\n", (int)blockIdx.x, (double)dr * 0.01, (double)dt * 100.0 / (double)dr);
+        const unsigned n = atomicAdd(&gl_clock_n, 1u);
+        if (n < 4096) { gl_clock_log[n][0] = dt; gl_clock_log[n][1] = dr; }
     }
 #endif
 #undef GLS_LOAD_ROW
+#undef GLS_NEXT_ROW
 #undef GLS_TOUCH_ROW
 #undef GLS_STAMP
 #undef GLS_URGENCY
@@ -1402,12 +1478,13 @@ GlStreamGeom gl_stream_geom(int win, int hop) {
 // Frames the ring holds (0: the window / hop pair does not fit).  Lower bound: what keeps an index from overwriting ring
 // positions that a slower wave may still read (see gl_stream_kernel), and the reflect-padded frames' reach; upper
 // bound: LDS.  More frames only make the lap-end read path rarer.
-int gl_stream_ring_frames(int win, int hop) {
+int gl_stream_ring_frames(int win, int hop, int n_stage) {
     const GlStreamGeom g = gl_stream_geom(win, hop);
     if (g.acc_len < 0) return 0;   // hop > span: frames do not even touch (ncol = 1 with a hop beyond the padded slots)
     const int wpad = (NFFT - win) >> 1;
     const int lag = (g.halo + 1) * hop > 2 * (MH - wpad) ? g.halo : g.halo + 1;
-    const int budget = (160 * 1024 - (int)(GL_NW * EX_CPLX * sizeof(cf)) - CT_SWORDS * (int)sizeof(int)) / (int)sizeof(float) - g.acc_len - 128;
+    // (n_stage rings share what the exchange buffers leave of the 160 KB)
+    const int budget = (160 * 1024 - (int)(GL_NW * EX_CPLX * sizeof(cf)) - CT_SWORDS * (int)sizeof(int)) / (int)sizeof(float) / n_stage - g.acc_len - 132;
     int need = 9 + lag + (g.S + hop - 1) / hop + 1;
     const int reach = (g.S + win + 2 * hop + hop - 1) / hop;   // what a reflect-padded frame reads is still in the ring, within one lap
     need = std::max(need, std::max(reach, GL_NW));
@@ -1418,7 +1495,7 @@ int gl_stream_ring_frames(int win, int hop) {
 size_t gl_stream_lds_bytes(const GlParams& p) {
     const GlStreamGeom g = gl_stream_geom(p.win, p.hop);
     return (size_t)(GL_NW * EX_CPLX) * sizeof(cf) + CT_SWORDS * sizeof(int) +
-           (size_t)((p.hop * p.ring_frames + g.acc_len + 128 + 3) & ~3) * sizeof(float);
+           (size_t)(p.n_stage < 2 ? 1 : 2) * (size_t)((p.hop * p.ring_frames + g.acc_len + 128 + 3) & ~3) * sizeof(float);
 }
 
 // Work items of the streaming form: every utterance is cut into nr runs of (almost) equal length, a multiple of the
@@ -1426,7 +1503,9 @@ size_t gl_stream_lds_bytes(const GlParams& p) {
 // filling and draining the stream.  nr is chosen by simulating the list schedule on the workgroups that really run.
 void gl_plan_stream(GlParams& p, int n_workers) {
     const int halo = p.ncol - 1;
-    p.ring_frames = gl_stream_ring_frames(p.win, p.hop);
+    // ONE cut for all launches of a call (single and double iterations alike: the overlap-add order, hence the waveform
+    // bits, must not depend on which kernel form ran an iteration); ring_frames is set per launch (launch_gl_stream)
+    p.ring_frames = gl_stream_ring_frames(p.win, p.hop, 1);
     struct Cut { int L, n_full, rem; };
     Cut best{p.T, 1, 0};
     bool forced = false;
@@ -1491,15 +1570,20 @@ void gl_plan_stream(GlParams& p, int n_workers) {
     p.chunk = p.C = best.L;
 }
 
-template <int MODE, int W, int H, bool MSE>
+template <int MODE, int W, int H, bool MSE, int NST = 1>
 static hipError_t gl_stream_set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_stream_kernel<MODE, W, H, MSE>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_stream_kernel<MODE, W, H, MSE, NST>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 // p.work_counter must point at a zeroed counter that no other launch uses; p planned by gl_plan_stream.
-hipError_t launch_gl_stream(hipStream_t s, const GlParams& p, int n_cus, int final_istft) {
-    if (p.ring_frames < GL_NW) return hipErrorInvalidValue;
+// n_stage = 2: two iterations in this launch (phase_in -> phase_out is then TWO Griffin-Lim iterations); not for the final
+// iSTFT and not with the mse.
+hipError_t launch_gl_stream(hipStream_t s, const GlParams& p_in, int n_cus, int final_istft, int n_stage) {
+    GlParams p = p_in;
+    p.n_stage = n_stage;
+    p.ring_frames = gl_stream_ring_frames(p.win, p.hop, n_stage);
+    if (p.ring_frames < GL_NW || n_stage < 1 || n_stage > 2 || (n_stage == 2 && (final_istft || p.mse_partial))) return hipErrorInvalidValue;
     const size_t lds = gl_stream_lds_bytes(p);
     const int nwg = p.n_items < n_cus ? p.n_items : n_cus;   // one workgroup per compute unit (256 registers x 8 waves)
     dim3 grid(nwg);
@@ -1509,9 +1593,13 @@ hipError_t launch_gl_stream(hipStream_t s, const GlParams& p, int n_cus, int fin
 #ifdef GL_FAST_BUILD
     if (!ref_cfg || mse) return hipErrorInvalidValue;
     if (final_istft) GLS_LAUNCH(1, 1102, 275, false);
+    else if (n_stage == 2) hipLaunchKernelGGL((gl_stream_kernel<0, 1102, 275, false, 2>), grid, dim3(GL_THREADS), lds, s, p);
     else GLS_LAUNCH(0, 1102, 275, false);
 #else
-    if (final_istft) {
+    if (n_stage == 2) {
+        if (ref_cfg) hipLaunchKernelGGL((gl_stream_kernel<0, 1102, 275, false, 2>), grid, dim3(GL_THREADS), lds, s, p);
+        else hipLaunchKernelGGL((gl_stream_kernel<0, 0, 0, false, 2>), grid, dim3(GL_THREADS), lds, s, p);
+    } else if (final_istft) {
         if (ref_cfg) GLS_LAUNCH(1, 1102, 275, false);
         else GLS_LAUNCH(1, 0, 0, false);
     } else if (mse) {
@@ -1533,8 +1621,10 @@ hipError_t gl_stream_configure() {
     if ((e = gl_stream_set_attr<0, 0, 0, true>()) != hipSuccess) return e;
     if ((e = gl_stream_set_attr<1, 0, 0, false>()) != hipSuccess) return e;
     if ((e = gl_stream_set_attr<0, 1102, 275, true>()) != hipSuccess) return e;
+    if ((e = gl_stream_set_attr<0, 0, 0, false, 2>()) != hipSuccess) return e;
 #endif
     if ((e = gl_stream_set_attr<0, 1102, 275, false>()) != hipSuccess) return e;
+    if ((e = gl_stream_set_attr<0, 1102, 275, false, 2>()) != hipSuccess) return e;
     if ((e = gl_stream_set_attr<1, 1102, 275, false>()) != hipSuccess) return e;
     return hipSuccess;
 }
@@ -2083,4 +2173,16 @@ hipError_t launch_peak_normalize(hipStream_t s, float* wav, int B, int n) {
     return hipGetLastError();
 }
 
+#ifdef GL_CLOCK
+extern "C" void gl_clock_dump() {
+    static unsigned long long host[4096][2];
+    unsigned n = 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(gl_clock_n), sizeof(n));
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(gl_clock_log), sizeof(host));
+    if (n > 4096) n = 4096;
+    for (unsigned i = 0; i < n; ++i)
+        printf("launch %4u: workgroup 0 ran %.1f us at %.0f MHz\n", i, (double)host[i][1] * 0.01, (double)host[i][0] * 100.0 / (double)host[i][1]);
+}
+#endif
 }  // namespace tts

@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--nocheck', action='store_true', help='ablation builds produce garbage')
     ap.add_argument('--fused', type=int, default=None, help='override the library default (all iterations in one launch)')
     ap.add_argument('--stream', type=int, default=None, help='override the library default (streaming kernel)')
+    ap.add_argument('--pair', type=int, default=None, help='override the library default (two iterations per launch)')
     ap.add_argument('--compare', action='store_true', help='fused against separate launches: waveforms must be identical')
     a = ap.parse_args()
     sstts = importlib.import_module('single-speaker-tts_amd')
@@ -44,6 +45,8 @@ def main():
         eng.set_option('gl_fused', a.fused)
     if a.stream is not None:
         eng.set_option('gl_stream', a.stream)
+    if a.pair is not None:
+        eng.set_option('gl_pair', a.pair)
     eng.griffin_lim(mag, 2, 1102, 275, 2048, init_phase=init, want_mse=False)
     eng.set_option('profile', 1)
     eng.profile_reset()
