@@ -92,7 +92,7 @@ struct tts_handle_s {
     // configuration allows it.  0: never.
     int persistent_decoder = 1;
     int gl_stream = 1;               // Griffin-Lim iterations by gl_stream_kernel (a run = one stream through an LDS ring)
-    int gl_pair = 1;                 // ... two iterations per launch where nothing per-iteration is asked for
+    int gl_pair = 3;                 // ... iterations per launch (1..3) where nothing per-iteration is asked for
     int gl_fused = 0;                // all Griffin-Lim iterations of a call in one launch (gl_iter_kernel, FUSED): same
                                      // waveforms, measured no faster, so off unless asked for
     bool gl_fused_used = false;      // a fused launch has been enqueued since the last status check
@@ -962,10 +962,14 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
         ProfScope ps(h, ST_GL_ITER, n_iter);
         // the streaming kernel runs two iterations per launch (gl_stream_kernel, NST = 2) wherever no per-iteration result
         // is asked for: all of them, or all but the last (the mse is the last iteration's)
-        const bool pair_ok = stream && h->gl_pair != 0 && gl_stream_ring_frames(win, hop, 2) > 0;
+        // gl_pair = iterations per launch (1, 2 or 3; default in the handle)
+        int per_launch = stream ? h->gl_pair : 1;
+        per_launch = per_launch < 1 ? 1 : (per_launch > 3 ? 3 : per_launch);
+        while (per_launch > 1 && gl_stream_ring_frames(win, hop, per_launch) <= 0) --per_launch;
         for (int it = 0; it < n_iter;) {
             const bool want_mse = mse && it == n_iter - 1;
-            const int n_stage = (pair_ok && it + 2 <= n_iter - (mse ? 1 : 0)) ? 2 : 1;
+            const int left = n_iter - (mse ? 1 : 0) - it;   // iterations that may share a launch
+            const int n_stage = left >= per_launch ? per_launch : (left >= 1 ? left : 1);
             p.phase_in = cur;
             p.phase_out = nxt;
             p.mse_partial = want_mse ? msep : nullptr;

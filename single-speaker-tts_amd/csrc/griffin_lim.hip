@@ -943,7 +943,7 @@ __device__ unsigned gl_clock_n;
 // span crosses the lap end (the final values of the wrapped part are at the ring's start, not in the guard) take an
 // index-mapped read path: 4 + (halo + ceil(S / hop)) / R of the frames.
 // MODE 1 writes out, straight from the overlap-add's registers, the hop samples that index i makes final.
-enum { CT_OLA = 0, CT_SNEXT = 1, CT_OLB = 2, CT_SWORDS = 16 };
+enum { CT_OLA = 0, CT_SNEXT = 1, CT_OLB = 2 /* chain words of stages 1, 2 */, CT_SWORDS = 16 };
 
 // NST = 2: TWO iterations per launch.  The kernel draws a constant amount of power per instruction and per byte, and
 // with the spectra streaming the chip holds a shader clock of ~1.9 GHz against ~2.3 GHz for the same arithmetic without
@@ -955,7 +955,7 @@ enum { CT_OLA = 0, CT_SNEXT = 1, CT_OLB = 2, CT_SWORDS = 16 };
 // more frames at either end in stage A (2.6 % more transforms for runs of 144 frames).
 template <int MODE, int WIN_CT, int HOP_CT, bool MSE, int NST = 1>
 __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
-    static_assert(NST == 1 || (NST == 2 && MODE == 0 && !MSE), "two iterations per launch: plain iterations only");
+    static_assert(NST == 1 || (NST >= 2 && NST <= 3 && MODE == 0 && !MSE), "several iterations per launch: plain iterations only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int win = WIN_CT ? WIN_CT : p.win;
     const int hop = HOP_CT ? HOP_CT : p.hop;
@@ -978,8 +978,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
     // carve: [exchange: GL_NW * EX_CPLX cf][control][ring A: ring_len + acc_len + 128 floats][ring B]
     cf* ex_all = reinterpret_cast<cf*>(smem_raw);
     int* ctrl = reinterpret_cast<int*>(ex_all + GL_NW * EX_CPLX);
-    float* ringA = reinterpret_cast<float*>(ctrl + CT_SWORDS);
-    float* ringB = ringA + ring_floats;
+    float* ringA = reinterpret_cast<float*>(ctrl + CT_SWORDS);   // the ring of stage k follows at k * ring_floats
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1251,7 +1250,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         wave_lds_sync();
     };
 
-    const int lead = NST == 2 ? 2 * halo : halo;   // frames the first index lies before the run
+    const int lead = NST * halo;   // frames the first index (of stage 0) lies before the run
     bool have_row = false;   // (per wave) the first row of this run was requested in the last iteration of the previous one
     while (item < p.n_items) {
         int b, run_t0, run_len, slot;
@@ -1264,21 +1263,19 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         have_row = false;
         // run start: the guards read as zero for index 0, the chains start at 0
         for (int q = tid; q < acc_len + 128; q += GL_THREADS) {
-            ringA[ring_len + q] = 0.f;
-            if (NST == 2) ringB[ring_len + q] = 0.f;
+#pragma unroll
+            for (int k = 0; k < NST; ++k) ringA[k * ring_floats + ring_len + q] = 0.f;
         }
-        if (tid == 0) { ctrl[CT_OLA] = 0; ctrl[CT_OLB] = 0; ctrl[CT_SNEXT] = (int)next_item_reg; }
+        if (tid == 0) { ctrl[CT_OLA] = 0; ctrl[CT_OLB] = 0; ctrl[CT_OLB + 1] = 0; ctrl[CT_SNEXT] = (int)next_item_reg; }
         __syncthreads();
         const int next_item = __builtin_amdgcn_readfirstlane(ctrl[CT_SNEXT]);
         int nb = b, nt0 = 0, nlen = 0, nslot = 0;
         if (next_item < p.n_items) decode_item(next_item, nb, nt0, nlen, nslot);
 
-        // stage B (the only stage of NST == 1) has the indices of one iteration, j <-> frame run_t0 - halo + j; stage A of
-        // NST == 2 runs halo + lag indices ahead of it: i = j + halo + lag <-> frame run_t0 - 2 halo + i
-        const int n_idx_b = run_len + halo + lag;
-        const int n_idx = NST == 2 ? n_idx_b + halo + lag : n_idx_b;
-        const int y_base_a = (run_t0 - lead) * hop - MH + fs;   // trimmed-signal index of ring coordinate 0 (lap 0)
-        const int y_base_b = (run_t0 - halo) * hop - MH + fs;
+        // the LAST stage (the only one of NST == 1) has the indices of one iteration, j <-> frame run_t0 - halo + j; every
+        // stage before it runs halo + lag indices ahead of the next: stage 0 index i <-> frame run_t0 - NST halo + i
+        const int n_idx = run_len + NST * (halo + lag);
+        const int y_base_a = (run_t0 - lead) * hop - MH + fs;   // trimmed-signal index of stage 0's ring coordinate 0 (lap 0)
         float mse_acc = 0.f;
         pk = 0.f;
         int s = wave % R;                                     // ring slot of this wave's index (wave < 8 <= R)
@@ -1309,13 +1306,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                 GLS_LOAD_ROW(x_in + (size_t)nb * p.T * p.FP, p.mag + (size_t)nb * p.T * p.FP, nt0 - lead + wave)         \
                 have_row = true;                                                                                         \
             }
-            const int jb = i - (halo + lag);                  // stage B index of this iteration (NST == 2)
-            const int tb = t - lag;                           // ... and its frame = run_t0 - halo + jb
-            const bool valid_b = NST == 2 && jb >= 0 && tb >= 0 && tb < p.T;
             if (NST == 1) {
                 GLS_NEXT_ROW()
             } else {
-                const int tq = tb < 0 ? 0 : (tb >= p.T ? p.T - 1 : tb);
+                // (|S| of the frame that goes from this stage to the next: the magnitude registers are free until the next row is requested)
+                const int tq = t - lag < 0 ? 0 : (t - lag >= p.T ? p.T - 1 : t - lag);
                 const float* mrow_ = magb + (size_t)tq * p.FP + lane;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) gs[j] = mrow_[64 * j];
@@ -1335,16 +1330,28 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
             }
             GLS_URGENCY(i + GL_NW)
 
-            int sb = s, jj = i;   // ring slot / index of the stage whose forward transform writes the new spectrum
-            if (NST == 2) {
-                sb = s - (halo + lag);
-                sb += sb < 0 ? R : 0;
-                jj = jb;
-                // ---------------- stage A -> stage B: forward FFT of frame tb, normalised to |S| e^{i phi} in registers
-                if (valid_b) {
-                    int sm = s - lag;
+            // ---------------- further stages: stage k runs halo + lag indices behind stage k - 1 and takes the forward
+            // transform of stage k - 1's frame t_k = t_{k-1} - lag, normalised to |S| e^{i phi} in registers, as its input.
+            // A loop, not NST copies of the code: the instruction cache is shared by two compute units.
+            int sk = s, ik = i, tk = t;               // ring slot, index and frame of the current stage
+            float* ring_k = ringA;
+            int yb_k = y_base_a;
+#pragma nounroll
+            for (int k = 1; k < NST; ++k) {
+                const int i_prev = ik, s_prev = sk;
+                const float* ring_prev = ring_k;
+                const int yb_prev = yb_k;
+                ik -= halo + lag;
+                tk -= lag;
+                sk -= halo + lag;
+                sk += sk < 0 ? R : 0;
+                ring_k += ring_floats;
+                yb_k += halo * hop;
+                const bool valid_k = ik >= 0 && tk >= 0 && tk < p.T;
+                if (valid_k) {
+                    int sm = s_prev - lag;
                     sm += sm < 0 ? R : 0;
-                    fft_input(ringA, i, sm, tb, y_base_a, v);
+                    fft_input(ring_prev, i_prev, sm, tk, yb_prev, v);
                     fft1024(v, ex, tw, lane);
                     cf gk[16];
                     // |S| e^{i phi}: x * (|S| / |x|), and (|S|, 0) for a zero bin (numpy's exp(1j * angle(0)) = 1); the
@@ -1361,20 +1368,29 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) v[j] = cmk(0.f, 0.f);
                 }
-                GLS_NEXT_ROW()
-                if (jb >= 0) {
-                    if (valid_b) {
-                        fft1024(v, ex, tw, lane);
-                        synth_window(tb, v);
-                    }
-                    overlap_add(ringB, CT_OLB, jb, sb, tb, b, run_t0, run_len, v);
+                if (k + 1 < NST) {
+                    const int tq = tk - lag < 0 ? 0 : (tk - lag >= p.T ? p.T - 1 : tk - lag);
+                    const float* mrow_ = magb + (size_t)tq * p.FP + lane;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) gs[j] = mrow_[64 * j];
+                    nyq_s = mrow_[MH - lane];
+                } else {
+                    GLS_NEXT_ROW()
                 }
-                GLS_TOUCH_ROW()
+                if (ik >= 0) {
+                    if (valid_k) {
+                        fft1024(v, ex, tw, lane);
+                        synth_window(tk, v);
+                    }
+                    overlap_add(ring_k, CT_OLB + k - 1, ik, sk, tk, b, run_t0, run_len, v);
+                }
             }
+            if (NST > 1) GLS_TOUCH_ROW()
             GLS_STAMP()   // 4
-            // ---------------- forward FFT of the frame `lag` behind: its signal is final
+            // ---------------- forward FFT of the frame `lag` behind in the last stage: its signal is final
+            const int jj = ik, sb = sk;
             if (MODE == 0 && jj >= halo + lag && jj < halo + lag + run_len) {
-                const int tm = (NST == 2 ? tb : t) - lag;                // in [run_t0, run_t0 + run_len), < T
+                const int tm = tk - lag;                                 // in [run_t0, run_t0 + run_len), < T
                 int sm = sb - lag;
                 sm += sm < 0 ? R : 0;
                 const float* mrow = magb + (size_t)tm * p.FP;
@@ -1383,7 +1399,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
 #pragma unroll
                     for (int c = 0; c < 16; ++c) mg[c] = fabsf(GL_STREAM_LOAD(mrow + lane + 64 * c));
                 }
-                fft_input(NST == 2 ? ringB : ringA, jj, sm, tm, NST == 2 ? y_base_b : y_base_a, v);
+                fft_input(ring_k, jj, sm, tm, yb_k, v);
                 fft1024(v, ex, tw, lane);
                 GLS_STAMP()   // 5: forward FFT done
                 GLS_URGENCY(i + GL_NW)
@@ -1495,7 +1511,7 @@ int gl_stream_ring_frames(int win, int hop, int n_stage) {
 size_t gl_stream_lds_bytes(const GlParams& p) {
     const GlStreamGeom g = gl_stream_geom(p.win, p.hop);
     return (size_t)(GL_NW * EX_CPLX) * sizeof(cf) + CT_SWORDS * sizeof(int) +
-           (size_t)(p.n_stage < 2 ? 1 : 2) * (size_t)((p.hop * p.ring_frames + g.acc_len + 128 + 3) & ~3) * sizeof(float);
+           (size_t)(p.n_stage < 1 ? 1 : p.n_stage) * (size_t)((p.hop * p.ring_frames + g.acc_len + 128 + 3) & ~3) * sizeof(float);
 }
 
 // Work items of the streaming form: every utterance is cut into nr runs of (almost) equal length, a multiple of the
@@ -1583,7 +1599,7 @@ hipError_t launch_gl_stream(hipStream_t s, const GlParams& p_in, int n_cus, int 
     GlParams p = p_in;
     p.n_stage = n_stage;
     p.ring_frames = gl_stream_ring_frames(p.win, p.hop, n_stage);
-    if (p.ring_frames < GL_NW || n_stage < 1 || n_stage > 2 || (n_stage == 2 && (final_istft || p.mse_partial))) return hipErrorInvalidValue;
+    if (p.ring_frames < GL_NW || n_stage < 1 || n_stage > 3 || (n_stage > 1 && (final_istft || p.mse_partial))) return hipErrorInvalidValue;
     const size_t lds = gl_stream_lds_bytes(p);
     const int nwg = p.n_items < n_cus ? p.n_items : n_cus;   // one workgroup per compute unit (256 registers x 8 waves)
     dim3 grid(nwg);
@@ -1594,9 +1610,13 @@ hipError_t launch_gl_stream(hipStream_t s, const GlParams& p_in, int n_cus, int 
     if (!ref_cfg || mse) return hipErrorInvalidValue;
     if (final_istft) GLS_LAUNCH(1, 1102, 275, false);
     else if (n_stage == 2) hipLaunchKernelGGL((gl_stream_kernel<0, 1102, 275, false, 2>), grid, dim3(GL_THREADS), lds, s, p);
+    else if (n_stage == 3) hipLaunchKernelGGL((gl_stream_kernel<0, 1102, 275, false, 3>), grid, dim3(GL_THREADS), lds, s, p);
     else GLS_LAUNCH(0, 1102, 275, false);
 #else
-    if (n_stage == 2) {
+    if (n_stage == 3) {
+        if (ref_cfg) hipLaunchKernelGGL((gl_stream_kernel<0, 1102, 275, false, 3>), grid, dim3(GL_THREADS), lds, s, p);
+        else hipLaunchKernelGGL((gl_stream_kernel<0, 0, 0, false, 3>), grid, dim3(GL_THREADS), lds, s, p);
+    } else if (n_stage == 2) {
         if (ref_cfg) hipLaunchKernelGGL((gl_stream_kernel<0, 1102, 275, false, 2>), grid, dim3(GL_THREADS), lds, s, p);
         else hipLaunchKernelGGL((gl_stream_kernel<0, 0, 0, false, 2>), grid, dim3(GL_THREADS), lds, s, p);
     } else if (final_istft) {
@@ -1622,9 +1642,11 @@ hipError_t gl_stream_configure() {
     if ((e = gl_stream_set_attr<1, 0, 0, false>()) != hipSuccess) return e;
     if ((e = gl_stream_set_attr<0, 1102, 275, true>()) != hipSuccess) return e;
     if ((e = gl_stream_set_attr<0, 0, 0, false, 2>()) != hipSuccess) return e;
+    if ((e = gl_stream_set_attr<0, 0, 0, false, 3>()) != hipSuccess) return e;
 #endif
     if ((e = gl_stream_set_attr<0, 1102, 275, false>()) != hipSuccess) return e;
     if ((e = gl_stream_set_attr<0, 1102, 275, false, 2>()) != hipSuccess) return e;
+    if ((e = gl_stream_set_attr<0, 1102, 275, false, 3>()) != hipSuccess) return e;
     if ((e = gl_stream_set_attr<1, 1102, 275, false>()) != hipSuccess) return e;
     return hipSuccess;
 }

@@ -104,3 +104,29 @@ def test_peak_normalize(engine):
     got = engine.peak_normalize(d).to_host()
     for b in range(3):
         assert np.array_equal(got[b], A.peak_normalize(wav[b]))
+
+
+@pytest.mark.parametrize('per_launch', [1, 2, 3])
+@pytest.mark.parametrize('B,T,n_iter,want_mse', [(2, 40, 6, False), (1, 70, 7, True), (3, 151, 5, True), (2, 9, 4, False)])
+def test_griffin_lim_iterations_per_launch(engine, per_launch, B, T, n_iter, want_mse):
+    """gl_stream_kernel runs 1, 2 or 3 iterations per launch (the spectrum goes from one iteration to the next in
+    registers, normalised to |S| e^{i phi} without the 32-bit phasor code in between): every split of n_iter into
+    launches -- with the mse the last iteration is always a launch of its own -- against the oracle.  Runs shorter
+    than the stages' lead (T = 9), runs that wrap the rings several times (T = 151), both utterance ends in one run."""
+    rng = np.random.default_rng(1000 * T + n_iter)
+    mag = synth_mag(rng, B, T)
+    init = rng.random(mag.shape).astype(np.float32)
+    engine.set_option('gl_pair', per_launch)
+    try:
+        wav, mse = engine.griffin_lim(mag, n_iter, WIN, HOP, N_FFT, init_phase=init, want_mse=want_mse)
+        wav = wav.to_host()
+        mse = mse.to_host() if want_mse else None
+    finally:
+        engine.set_option('gl_pair', 3)
+    for b in range(B):
+        ref_wav, ref_mse = A.griffin_lim_v2(mag[b], WIN, HOP, N_FFT, n_iter, init_phase=init[b])
+        e = rel_l2(wav[b], ref_wav)
+        print('GL {} per launch, B={} T={} it={} b={}: wav rel-L2 {:.3e}'.format(per_launch, B, T, n_iter, b, e))
+        assert e < 1e-4 * n_iter
+        if want_mse:
+            assert abs(mse[b] - ref_mse) <= 1e-3 * abs(ref_mse) + 1e-9
