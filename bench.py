@@ -31,6 +31,7 @@ B_PER_GPU = 64
 TS = 150
 N_STEPS = 200
 N_ITER = 60
+GL_PER_LAUNCH = 3   # the library's default (tts_set_option "gl_pair")
 WIN, HOP, N_FFT = 1102, 275, 2048
 REF_DB, MAX_DB, POWER = 6.02, 99.89, 1.3
 SR = 22050
@@ -199,7 +200,6 @@ def main():
     ap.add_argument('--hold-lds-kb', type=int, default=None)
     ap.add_argument('--persistent-decoder', type=int, default=None, help='override the library default (0 never, 1 pipelined, 2 always)')
     ap.add_argument('--gl-pair', type=int, default=None, help='override the library default (Griffin-Lim iterations per launch, 1..3)')
-    ap.add_argument('--gl-fused', type=int, default=None, help='override the library default (all Griffin-Lim iterations in one launch)')
     ap.add_argument('--through-facade', action='store_true',
                     help='also time the reference-shaped host API (tacotron.inference.synthesize_stream: host ids in, host '
                          'waveforms out, upload and download inside the timed region) and report facade_ms_per_step')
@@ -277,8 +277,6 @@ def main():
         eng.set_option('hold_lds_kb', args.hold_lds_kb)
     if args.persistent_decoder is not None:
         eng.set_option('persistent_decoder', args.persistent_decoder)
-    if args.gl_fused is not None:
-        eng.set_option('gl_fused', args.gl_fused)
     if args.gl_pair is not None:
         eng.set_option('gl_pair', args.gl_pair)
 
@@ -339,7 +337,7 @@ def main():
     # (non-zero magnitudes: an all-zero spectrogram would send every frame down the kernel's exact
     #  zero-bin path, which the synthesised spectrograms of the timed steps never take)
     mag_alone = eng.to_device((np.random.default_rng(1).random((B, F, T), dtype=np.float32) ** 4) * 10 + 1e-3)
-    eng.griffin_lim(mag_alone, 8, WIN, HOP, N_FFT, init_phase=init, want_mse=False)
+    eng.griffin_lim(mag_alone, 3 * GL_PER_LAUNCH, WIN, HOP, N_FFT, init_phase=init, want_mse=False)
     ms_alone, n_alone = eng.profile_get('gl_iter')
     gl_alone_ms = ms_alone / max(1, n_alone)
     mag_alone.free()
@@ -386,10 +384,13 @@ def main():
         frames_total = world * B_PER_GPU * T
         ms_per_step = 1e3 * elapsed / args.steps
         audio_s = B_PER_GPU * HOP * (T - 1) / SR
-        # dominant kernel: gl_iter_kernel<0>, one launch = one Griffin-Lim iteration over the batch.
-        # Algorithmic bytes per launch: 20 B per bin = |S| 4 + phase in 8 + phase out 8.
-        gl_launch_ms = stage_ms['gl_iter'] / max(1, launches['gl_iter'])
-        alg_bytes = 20.0 * F * T * B_PER_GPU
+        # dominant kernel: gl_stream_kernel<0, 1102, 275, false, 3>, one launch = GL_PER_LAUNCH Griffin-Lim iterations over
+        # the batch (the library counts the stage in iterations).  Algorithmic bytes per iteration: 20 B
+        # per bin = |S| 4 + phase in 8 + phase out 8.
+        gl_iter_ms = stage_ms['gl_iter'] / max(1, launches['gl_iter'])
+        per_launch = args.gl_pair if args.gl_pair is not None else GL_PER_LAUNCH
+        gl_launch_ms = gl_iter_ms * per_launch
+        alg_bytes = 20.0 * F * T * B_PER_GPU * per_launch
         achieved = alg_bytes / (gl_launch_ms * 1e-3) / 1e9 if gl_launch_ms > 0 else 0.0
         # HBM bytes per launch from the PMC passes of the same build (FETCH_SIZE / WRITE_SIZE cannot be read
         # inside this process): newest profiles/*gl_iter_hbm_bytes_per_launch.json
@@ -398,7 +399,9 @@ def main():
         pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*gl_iter_hbm_bytes_per_launch.json')))
         if pmcs:
             with open(pmcs[-1]) as f:
-                traffic = json.load(f).get('hbm_bytes_per_launch')
+                rec = json.load(f)
+            if rec.get('iterations_per_launch', 1) == per_launch:
+                traffic = rec.get('hbm_bytes_per_launch')
         out = {
             'metric': 'mel-frames/sec (end-to-end text->waveform incl. 60-iter Griffin-Lim, 64-utt LJ-Speech-shaped batch per GPU)',
             'value': frames_total * args.steps / elapsed,
@@ -424,17 +427,19 @@ def main():
             'facade_ms_per_step': facade_ms,
             'outputs_per_step': 'wav (peak-normalised)' + ('' if args.no_aux_outputs else ', linear spectrograms, alignments') +
                                 ', mel (library-owned double buffer); all resident in HBM, none copied to the host in the timed region',
-            'roofline': {'kernel': 'gl_iter_kernel<0> (one Griffin-Lim iteration, iSTFT+STFT fused)', 'bound': 'hbm',
+            'roofline': {'kernel': 'gl_stream_kernel<0, 1102, 275, false, {0}> ({0} Griffin-Lim iterations per launch: iSTFT + STFT '
+                                   'of every iteration fused, the spectrum passed from one iteration to the next in registers)'.format(per_launch),
+                         'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'launch_ms': gl_launch_ms, 'launch_ms_alone': gl_alone_ms,
+                         'traffic': traffic, 'launch_ms': gl_launch_ms, 'iterations_per_launch': per_launch,
+                         'iteration_ms': gl_iter_ms, 'iteration_ms_alone': gl_alone_ms,
                          'algorithmic_bytes_per_launch': alg_bytes,
-                         # the same launch priced on the bytes the kernel really moves (12 B per bin: 4 B phasor code in and
-                         # out, 4 B magnitude in), and on the measured HBM traffic
-                         'achieved_moved': 12.0 * F * T * B_PER_GPU / (gl_launch_ms * 1e-3) / 1e9 if gl_launch_ms > 0 else 0.0,
-                         'frac_moved': 12.0 * F * T * B_PER_GPU / (gl_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if gl_launch_ms > 0 else 0.0,
+                         # the same launch priced on the measured HBM traffic (what the memory system really carries)
                          'frac_traffic': (traffic / (gl_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and gl_launch_ms > 0) else None,
-                         'note': 'achieved = algorithmic bytes (20 B per bin and iteration, SURVEY.md 8(d)) / launch time; the kernel '
-                                 'itself moves 12 B per bin (32-bit phasor code in and out, 4 B magnitude in), which is what traffic shows'},
+                         'note': 'achieved = algorithmic bytes (20 B per bin and iteration, SURVEY.md 8(d)) / launch time.  A launch '
+                                 'requests 4 B phasor code + 4 B |S| per bin in its first iteration, 4 B |S| in each further one '
+                                 '(rows other waves read microseconds earlier) and writes 4 B code in its last; the kernel is bound by '
+                                 'the power budget, not by either roof: DESIGN.md section 5'},
             'roofline_mfma': {'kernel': 'gemm_f32_kernel (post-net projection 1: conv1d k=3, 1024 -> 256, max-pool in the loader, M = {})'.format(M),
                               'bound': 'mfma', 'achieved': gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
                               'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',

@@ -91,12 +91,7 @@ struct tts_handle_s {
     // at B = 64; tools/pipeline_sweep.py: 16.0 against 19.6 ms per call at B = 32), so it stays.  2: whenever the
     // configuration allows it.  0: never.
     int persistent_decoder = 1;
-    int gl_stream = 1;               // Griffin-Lim iterations by gl_stream_kernel (a run = one stream through an LDS ring)
-    int gl_pair = 3;                 // ... iterations per launch (1..3) where nothing per-iteration is asked for
-    int gl_fused = 0;                // all Griffin-Lim iterations of a call in one launch (gl_iter_kernel, FUSED): same
-                                     // waveforms, measured no faster, so off unless asked for
-    bool gl_fused_used = false;      // a fused launch has been enqueued since the last status check
-    int* gl_status = nullptr;
+    int gl_pair = 3;                 // Griffin-Lim iterations per launch (1..3) where nothing per-iteration is asked for
     int n_cus_dev = 0;
     bool pd_configured = false;
     bool pd_used = false;            // a persistent launch has been enqueued since the last status check
@@ -121,8 +116,8 @@ struct tts_handle_s {
         hipEvent_t ev_d2h[2] = {nullptr, nullptr};      // waveforms have arrived in pinned memory
         bool d2h_pending[2] = {false, false}, enc_pending[2] = {false, false};
         size_t n_floats[2] = {0, 0};
-        int* status_pinned = nullptr;   // [2][2]: the sticky status words (fused Griffin-Lim, persistent decoder) as they
-                                        // stood behind each call's download
+        int* status_pinned = nullptr;   // [2][2]: the persistent decoder's sticky status word ([.][1]) as it stood behind
+                                        // each call's download
         int tickets = 0;
     } hio;
     hipEvent_t input_event = nullptr;   // set around a tts_synthesize call: its first kernel waits for this event
@@ -538,22 +533,10 @@ GruOffsets pack_dec_gru(tts_handle_t h, Packer& p, const std::string& scope, int
 }
 
 // ------------------------------------------------------------------------------------ workspace
-// Did every bounded wait of the persistent kernels enqueued so far end by arrival?  Both status words are STICKY on the
-// device (no launch clears them): a timeout in call j is still there when call j + 1 has been queued behind it; the
-// host clears a word when it has read it.  The caller has synchronised the streams the kernels ran on.
+// Did every bounded wait of the persistent decoder's launches so far end by arrival?  The status word is STICKY on the
+// device (no launch clears it): a timeout in call j is still there when call j + 1 has been queued behind it; the
+// host clears the word when it has read it.  The caller has synchronised the streams the kernels ran on.
 int check_status(tts_handle_t h) {
-    if (h->gl_fused_used) {
-        h->gl_fused_used = false;
-        int status = 0;
-        HIPCHK(h, hipMemcpy(&status, h->gl_status, sizeof(int), hipMemcpyDeviceToHost));
-        if (status) {
-            HIPCHK(h, hipMemset(h->gl_status, 0, sizeof(int)));
-            return fail(h, TTS_ERR_HIP,
-                        "fused Griffin-Lim: a workgroup waited for a neighbour run longer than the bound (not all "
-                        "workgroups were co-resident); the waveforms of that call are invalid -- "
-                        "tts_set_option(h, \"gl_fused\", 0) selects one launch per iteration");
-        }
-    }
     if (h->pd_used) {
         h->pd_used = false;
         int status = 0;
@@ -921,15 +904,13 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     p.T = T; p.FP = FP; p.win = win; p.hop = hop;
     p.ncol = (win + hop - 1) / hop;
     p.B = B;
-    if (gl_max_item_frames(win, hop) < 1 && gl_stream_ring_frames(win, hop) < 1)
-        return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: window does not fit in LDS");
+    if (gl_stream_ring_frames(win, hop) < 1)
+        return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: this window / hop pair does not fit the LDS ring (hop beyond the window's 128-sample slots, or too long)");
     const int n_cus = device_cus(h);
     // workgroups that really run side by side: the pipelined tts_synthesize keeps `reserve_cus` compute units
     // free of Griffin-Lim for its second stream
     const int held = (under_reservation && h->reserve_cus > 0) ? h->reserve_cus : 0;
-    const bool stream = h->gl_stream != 0 && gl_stream_ring_frames(win, hop) > 0;
-    if (stream) gl_plan_stream(p, n_cus - held > 16 ? n_cus - held : n_cus);
-    else gl_plan_items(p, n_cus - held > 16 ? n_cus - held : n_cus);
+    gl_plan_stream(p, n_cus - held > 16 ? n_cus - held : n_cus);
     const int nchunks = p.slots_per_utt;
     WS(h, "gl.mse_partial", float, (size_t)B * nchunks, msep);
     // one zeroed work counter per launch (the persistent workgroups draw their item ids from it)
@@ -938,32 +919,13 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     if (!phase_ready) HIPCHK(h, launch_phase_init(h->stream, init_ft, seed, ph0, B, F, T, FP));
     float2* cur = ph0;
     float2* nxt = ph1;
-    // One launch for all iterations when nothing per-iteration is asked for (gl_iter_kernel, FUSED); `free_cus`
-    // workgroups must all be resident, so under the call pipeline it is only used on the compute units the plan counts
     const int free_cus = n_cus - held > 16 ? n_cus - held : n_cus;
-    const bool fused = !stream && h->gl_fused != 0 && !mse && n_iter > 1 && gl_fused_supported(p);
-    if (fused) {
-        ProfScope ps(h, ST_GL_ITER, n_iter);   // counted in iterations, like the separate launches
-        WS(h, "gl.done", unsigned, (size_t)p.n_items + 1, done);
-        HIPCHK(h, hipMemsetAsync(done, 0, ((size_t)p.n_items + 1) * sizeof(unsigned), h->stream));
-        p.n_fused = n_iter;
-        p.buf[0] = ph0; p.buf[1] = ph1;
-        p.done = done;
-        if (!h->gl_status) {   // sticky status word of the fused launches (check_status)
-            HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->gl_status), sizeof(int)));
-            HIPCHK(h, hipMemsetAsync(h->gl_status, 0, sizeof(int), h->stream));
-        }
-        p.status = h->gl_status;
-        p.work_counter = counters;
-        HIPCHK(h, launch_gl_fused(h->stream, p, free_cus));
-        if (n_iter & 1) std::swap(cur, nxt);
-        h->gl_fused_used = true;
-    } else {
+    {
         ProfScope ps(h, ST_GL_ITER, n_iter);
         // the streaming kernel runs two iterations per launch (gl_stream_kernel, NST = 2) wherever no per-iteration result
         // is asked for: all of them, or all but the last (the mse is the last iteration's)
         // gl_pair = iterations per launch (1, 2 or 3; default in the handle)
-        int per_launch = stream ? h->gl_pair : 1;
+        int per_launch = h->gl_pair;
         per_launch = per_launch < 1 ? 1 : (per_launch > 3 ? 3 : per_launch);
         while (per_launch > 1 && gl_stream_ring_frames(win, hop, per_launch) <= 0) --per_launch;
         for (int it = 0; it < n_iter;) {
@@ -984,8 +946,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
             // no more workgroups than the plan counts on: one that finds its compute unit taken (the call pipeline's other
             // stream) would start when the first of the others leaves, load its tables, find no item and only
             // lengthen the launch
-            if (stream) HIPCHK(h, launch_gl_stream(h->stream, p, free_cus, 0, n_stage));
-            else HIPCHK(h, launch_gl_iter(h->stream, p, free_cus, 0));
+            HIPCHK(h, launch_gl_stream(h->stream, p, free_cus, 0, n_stage));
             std::swap(cur, nxt);
             it += n_stage;
         }
@@ -1038,8 +999,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
         p.wav = wav;
         p.peak_partial = peak_normalize ? msep : nullptr;   // the mse partials are consumed by now
         p.work_counter = counters + n_iter;
-        if (stream) HIPCHK(h, launch_gl_stream(h->stream, p, free_cus, 1, 1));
-        else HIPCHK(h, launch_gl_iter(h->stream, p, free_cus, 1));
+        HIPCHK(h, launch_gl_stream(h->stream, p, free_cus, 1, 1));
     }
     if (peak_normalize) HIPCHK(h, launch_peak_scale(h->stream, wav, B, hop * (T - 1), msep, nchunks));
     return TTS_OK;
@@ -1149,7 +1109,6 @@ int tts_destroy(tts_handle_t h) {
         hipStreamDestroy(h->aux);
     }
     if (h->hold_flags) hipFree(h->hold_flags);
-    if (h->gl_status) hipFree(h->gl_status);
     for (int i = 0; i < 2; ++i) {
         if (h->hio.ids_pinned[i]) hipHostFree(h->hio.ids_pinned[i]);
         if (h->hio.ids_dev[i]) hipFree(h->hio.ids_dev[i]);
@@ -1207,8 +1166,6 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     if (!std::strcmp(key, "use_graph")) h->use_graph = value;
     else if (!std::strcmp(key, "profile")) h->profile = value;
     else if (!std::strcmp(key, "persistent_decoder")) h->persistent_decoder = value;
-    else if (!std::strcmp(key, "gl_fused")) h->gl_fused = value;
-    else if (!std::strcmp(key, "gl_stream")) h->gl_stream = value;
     else if (!std::strcmp(key, "gl_pair")) h->gl_pair = value;
     else if (!std::strcmp(key, "pd_debug_delay")) pd_debug_delay = value;   // tests only (decoder_persistent.hip)
     else if (!std::strcmp(key, "reserve_cus")) {
@@ -1993,8 +1950,6 @@ int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, 
     // the sticky status words of the persistent kernels travel with the waveforms (tts_wait_host must not wait for
     // anything but this call: a stream synchronisation there would wait for the NEXT call's download as well)
     io.status_pinned[2 * par] = io.status_pinned[2 * par + 1] = 0;
-    if (h->gl_fused_used && h->gl_status)
-        HIPCHK(h, hipMemcpyAsync(&io.status_pinned[2 * par], h->gl_status, sizeof(int), hipMemcpyDeviceToHost, io.out));
     if (h->pd_used && h->pd_sync)
         HIPCHK(h, hipMemcpyAsync(&io.status_pinned[2 * par + 1], h->pd_sync + 64 * h->pd_clusters + 1, sizeof(int),
                                  hipMemcpyDeviceToHost, io.out));
@@ -2014,8 +1969,6 @@ int tts_wait_host(tts_handle_t h, int ticket, const float** wav_host, size_t* n_
     const int par = ticket & 1;
     HIPCHK(h, hipEventSynchronize(io.ev_d2h[par]));
     // the download is behind everything the call launched: a timed-out persistent kernel must not pass for a result
-    if (io.status_pinned[2 * par])
-        return fail(h, TTS_ERR_HIP, "fused Griffin-Lim: a wait for a neighbour run timed out; the waveforms of that call are invalid");
     if (io.status_pinned[2 * par + 1])
         return fail(h, TTS_ERR_HIP, "persistent decoder: a wait for the cluster timed out; the outputs of that call are invalid -- "
                                      "tts_set_option(h, \"persistent_decoder\", 0) selects the launch-per-layer path");
@@ -2044,10 +1997,10 @@ int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_worker
     std::memset(&p, 0, sizeof(p));
     p.T = T; p.B = B; p.win = win_length; p.hop = hop_length;
     p.ncol = (win_length + hop_length - 1) / hop_length;
-    const int cmax = gl_max_item_frames(win_length, hop_length);
-    if (p.ncol > 8 || cmax < 1) return TTS_ERR_UNSUPPORTED;
-    gl_plan_items(p, n_workers);
-    if (max_item_frames) *max_item_frames = p.chunk;
+    const int ring = gl_stream_ring_frames(win_length, hop_length);
+    if (p.ncol > 8 || ring < 1) return TTS_ERR_UNSUPPORTED;
+    gl_plan_stream(p, n_workers);
+    if (max_item_frames) *max_item_frames = ring;
     for (int k = 0; k < GL_MAX_CLASSES; ++k) {
         classes[2 * k] = p.cls_C[k];
         classes[2 * k + 1] = p.cls_n[k];

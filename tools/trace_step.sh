@@ -1,29 +1,31 @@
 # Kernel-trace timeline of two pipelined bench steps (both streams), consecutive launches of the same kernel merged:
-#   bash tools/trace_step.sh > profiles/<tag>_step_timeline.txt   (on the GPU box)
+#   bash tools/trace_step.sh [tag] > profiles/<tag>_step_timeline.txt   (on the GPU box)
 set -e
-mkdir -p gpurun_out/r02
+TAG=${1:-r03}
+mkdir -p gpurun_out/$TAG
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/r02/steptrace
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r02/steptrace -o st -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $R/gpurun_out/r02/steptrace.log 2>&1
+rm -rf $R/gpurun_out/$TAG/steptrace
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/steptrace -o st -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $R/gpurun_out/$TAG/steptrace.log 2>&1
 cd $R
-python3 - <<'PY'
-import csv,glob,collections
-f=glob.glob('gpurun_out/r02/steptrace/**/*kernel_trace.csv',recursive=True)[0]
+python3 - $TAG <<'PY'
+import csv,glob,collections,sys
+tag=sys.argv[1]
+f=glob.glob('gpurun_out/%s/steptrace/**/*kernel_trace.csv'%tag,recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
-print(rows[0].keys())
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-# find the last-but-one persistent decoder launch and print everything from there for ~30 ms
+# find the last-but-two persistent decoder launch and print everything from there for ~50 ms
 pd=[i for i,r in enumerate(rows) if 'dec_persistent' in r['Kernel_Name']]
 i0=pd[-3]; t0=int(rows[i0]['Start_Timestamp'])
 last=None
 for r in rows[i0:]:
     s=(int(r['Start_Timestamp'])-t0)/1e6; e=(int(r['End_Timestamp'])-t0)/1e6
     if s>50: break
-    n=r['Kernel_Name'][:60]
+    n=r['Kernel_Name'][:70]
     key=(n,r.get('Queue_Id'))
-    if 'gl_iter_kernel<0' in n or 'dec_gemm' in n:
+    if 'gl_stream_kernel<0' in n or 'gl_iter_kernel<0' in n or 'dec_gemm' in n:
         if last and last[0]==key: last[2]=e; last[3]+=1; continue
     if last: print('%8.3f %8.3f x%-3d q%s %s'%(last[1],last[2],last[3],last[0][1],last[0][0]))
     last=[key,s,e,1]
+if last: print('%8.3f %8.3f x%-3d q%s %s'%(last[1],last[2],last[3],last[0][1],last[0][0]))
 PY
