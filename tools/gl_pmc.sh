@@ -4,7 +4,7 @@
 # gpurun_out/<tag>_gl_pmc.txt; copy it to profiles/ to have it judged.
 #   bash tools/gl_pmc.sh r02
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${TAG}_gl_pmc
 mkdir -p $OUT
