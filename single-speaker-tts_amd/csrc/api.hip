@@ -120,6 +120,12 @@ struct tts_handle_s {
                                         // each call's download
         int tickets = 0;
     } hio;
+    // Under the call pipeline the decoder's output projection (y history -> mel, one GEMM) is not issued behind the decoder
+    // on the front stream, where it gets the decoder's 32 compute units (0.3 ms), but at the head of the post-net on the
+    // main stream (0.03 ms); the y history is then a buffer per call parity.
+    bool defer_projection = false, has_pending_proj = false;
+    int defer_parity = 0;
+    GemmGroup pending_proj;
     hipEvent_t input_event = nullptr;   // set around a tts_synthesize call: its first kernel waits for this event
     hipEvent_t enc_done_event = nullptr;   // ... and this one is recorded behind its encoder
 
@@ -1001,6 +1007,8 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
         p.work_counter = counters + n_iter;
         HIPCHK(h, launch_gl_stream(h->stream, p, free_cus, 1, 1));
     }
+    // (dividing by the peak inside the final launch -- by the workgroup that finishes an utterance's last run -- was built
+    //  and measured: +0.09 ms on that launch against the 0.05 ms of this kernel)
     if (peak_normalize) HIPCHK(h, launch_peak_scale(h->stream, wav, B, hop * (T - 1), msep, nchunks));
     return TTS_OK;
 }
@@ -1450,7 +1458,13 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
     WS(h, "dec.tmp", float, (size_t)B * (c.dec_prenet_units[0] + c.dec_prenet_units[1] + 6 * (size_t)U), tmp);
     WS(h, "dec.ctx_parts", float, (size_t)TTS_ATT_PARTS * B * mem, ctx_parts);
     WS(h, "dec.att_stats", float, (size_t)n_steps * B * TTS_ATT_PARTS * 2, att_stats);
-    WS(h, "dec.yhist", float, (size_t)B * n_steps * U, yhist);
+    // (the launch-per-layer path replays a captured graph with its buffers baked in: one y history there)
+    const int pd_budget = h->cur_cu_budget > 0 ? h->cur_cu_budget : h->n_cus_dev;
+    const bool pd_wanted = h->persistent_decoder >= 2 || (h->persistent_decoder == 1 && h->cur_cu_budget > 0 && B > 48);
+    const bool use_pd = pd_wanted && decoder_persistent_supports(h->dec, c.force_cudnn, B, Ts) &&
+                        decoder_persistent_workgroups(B) <= pd_budget;
+    const bool defer_proj = h->defer_projection && use_pd;
+    WS(h, defer_proj ? (h->defer_parity ? "dec.yhist.odd" : "dec.yhist.even") : "dec.yhist", float, (size_t)B * n_steps * U, yhist);
     WS(h, "dec.align_raw", float, (size_t)n_steps * B * Ts, align_raw);
     DecoderScratch sc;
     std::memset(&sc, 0, sizeof(sc));
@@ -1492,10 +1506,6 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
     // keys = memory_layer(memory), no bias (LuongAttention; values stay the raw memory)
     if ((rc = run_single(h, dense_group(memory, mem, h->mem_wt, nullptr, keys, A, B * Ts, A, mem, ACT_NONE)))) return rc;
 
-    const int pd_budget = h->cur_cu_budget > 0 ? h->cur_cu_budget : h->n_cus_dev;
-    const bool pd_wanted = h->persistent_decoder >= 2 || (h->persistent_decoder == 1 && h->cur_cu_budget > 0 && B > 48);
-    const bool use_pd = pd_wanted && decoder_persistent_supports(h->dec, c.force_cudnn, B, Ts) &&
-                        decoder_persistent_workgroups(B) <= pd_budget;
     if (use_pd) {
         if (!h->pd_configured) {
             HIPCHK(h, decoder_persistent_configure());
@@ -1541,8 +1551,15 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
         HIPCHK(h, hipGraphLaunch(h->dec_graph, h->stream));
     }
     // OutputProjectionWrapper for all steps at once: mel[b][t][:] = y[b][t] W_o + b_o
-    if ((rc = run_single(h, dense_group(yhist, U, h->dec.out_wt, h->dec.out_b, mel, OUT, B * n_steps, OUT, U, ACT_NONE))))
-        return rc;
+    {
+        const GemmGroup proj = dense_group(yhist, U, h->dec.out_wt, h->dec.out_b, mel, OUT, B * n_steps, OUT, U, ACT_NONE);
+        if (defer_proj) {
+            h->pending_proj = proj;
+            h->has_pending_proj = true;
+        } else if ((rc = run_single(h, proj))) {
+            return rc;
+        }
+    }
     if (predictive) {
         // a predicted window that leaves the memory: the reference fails at run time (attention.py:288-304)
         int flag = 0;
@@ -1838,7 +1855,11 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     if (!rc && h->enc_done_event) HIPCHK(h, hipEventRecord(h->enc_done_event, h->stream));
     h->cur_hold_flag = hold_flag;
     h->cur_cu_budget = (pipelined && h->reserve_cus > 0) ? h->reserve_cus : 0;
+    h->defer_projection = pipelined;
+    h->defer_parity = parity;
+    h->has_pending_proj = false;
     if (!rc) rc = tts_decoder_forward(h, memory, B, Ts, sp->n_steps, mel, align_out);
+    h->defer_projection = false;
     h->cur_hold_flag = nullptr;
     h->cur_cu_budget = 0;
     h->stream = main_stream;
@@ -1862,6 +1883,10 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         HIPCHK(h, hipEventRecord(h->ev_front_done, h->front));
         h->front_pending = true;
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_front_done, 0));
+    }
+    if (h->has_pending_proj) {   // the decoder's output projection, on the main stream (see defer_projection)
+        h->has_pending_proj = false;
+        if ((rc = run_single(h, h->pending_proj))) return rc;
     }
     int* db_flag = nullptr;
     if (denorm_can_assert(sp->ref_db, sp->max_db) && (rc = denorm_flag_arm(h, &db_flag))) return rc;

@@ -14,7 +14,7 @@ struct GlParams {
     float2* phase_out;       // [B][T][FP]       (iteration)
     float* wav;              // [B][hop*(T-1)]   (final iSTFT)
     float* mse_partial;      // [B][slots_per_utt] or null
-    float* peak_partial;     // [B][slots_per_utt] or null (final iSTFT: per-item max |wav|)
+    float* peak_partial;     // [B][slots_per_utt] or null (final iSTFT: per-run max |wav|)
     const float* window;     // [win] periodic hann
     const float* wlane;      // [2][64 lanes][16][2] per-lane window images (gl_build_wlane): analysis / interior synthesis
     const float* rwss;       // [n_fft + hop*(T-1)] 1 / window sum-square (librosa window_sumsquare) where it is > tiny, else 1
