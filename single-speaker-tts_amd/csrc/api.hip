@@ -548,11 +548,12 @@ int check_status(tts_handle_t h) {
         int status = 0;
         HIPCHK(h, hipMemcpy(&status, h->pd_sync + 64 * h->pd_clusters + 1, sizeof(int), hipMemcpyDeviceToHost));
         if (status) HIPCHK(h, hipMemset(h->pd_sync + 64 * h->pd_clusters + 1, 0, sizeof(int)));
+        if (status) h->persistent_decoder = 0;   // every later call takes the launch-per-layer path by itself
         if (status)
             return fail(h, TTS_ERR_HIP,
                         "persistent decoder: a workgroup waited for its cluster longer than the bound (not all "
-                        "workgroups were co-resident); the outputs of that call are invalid -- "
-                        "tts_set_option(h, \"persistent_decoder\", 0) selects the launch-per-layer path");
+                        "workgroups were co-resident); the outputs of that call are invalid -- the handle has "
+                        "switched to the launch-per-layer path (tts_set_option(h, \"persistent_decoder\", 1) switches back)");
     }
     return TTS_OK;
 }
