@@ -62,6 +62,8 @@ struct tts_handle_s {
     bool own_stream = false;
     std::string err;
     int use_graph = 1;
+    int fused_tail = 1;          // CBHG: lifter + highway stack + GRU input projections as one launch (cbhg_tail.hip)
+    bool tail_configured = false;
     int profile = 0;
     // tts_synthesize pipelining: encoder + decoder (latency bound, few CUs) of call k+1 run on
     // `front` while post-net + Griffin-Lim (throughput bound) of call k run on `stream`.
@@ -728,29 +730,47 @@ int run_cbhg(tts_handle_t h, const CbhgWeights& w, const char* tag, const float*
         if (rc) return rc;
         ++*launches;
     }
-    // lifter
-    {
-        int rc = run_single(h, dense_group(p2, w.proj_filters[1], w.lifter_wt, w.lifter_b, hw0, U, M, U,
-                                           w.proj_filters[1], ACT_RELU));
-        if (rc) return rc;
+    if (h->fused_tail && cbhg_tail_supports(w.proj_filters[1], U, H, (int)w.hw_wt.size(), M)) {
+        // lifter, highway stack and the GRU input projections in one launch: the rows stay in LDS between the layers
+        if (!h->tail_configured) {
+            HIPCHK(h, cbhg_tail_configure());
+            h->tail_configured = true;
+        }
+        CbhgTailParams tp;
+        std::memset(&tp, 0, sizeof(tp));
+        tp.X = p2; tp.ldx = w.proj_filters[1]; tp.c_in = w.proj_filters[1];
+        tp.lifter_wt = w.lifter_wt; tp.lifter_b = w.lifter_b;
+        tp.n_hw = (int)w.hw_wt.size();
+        for (int l = 0; l < tp.n_hw; ++l) { tp.hw_wt[l] = w.hw_wt[l]; tp.hw_b[l] = w.hw_b[l]; }
+        tp.gru_wt = w.gru_in_wt; tp.gru_b = w.gru_in_b;
+        tp.hw_out = hw0; tp.xproj = xproj; tp.M = M;
+        HIPCHK(h, launch_cbhg_tail(h->stream, tp));
         ++*launches;
-    }
-    // highway layers (H|T in one GEMM, gate mix in the epilogue), ping-pong buffers
-    float* cur = hw0;
-    float* nxt = hw1;
-    for (size_t l = 0; l < w.hw_wt.size(); ++l) {
-        GemmGroup g = dense_group(cur, U, w.hw_wt[l], w.hw_b[l], nxt, U, M, 2 * U, U, ACT_NONE);
-        g.epi = EPI_HIGHWAY;
-        int rc = run_single(h, g);
-        if (rc) return rc;
-        ++*launches;
-        std::swap(cur, nxt);
-    }
-    // GRU input projections for both directions, then the recurrent kernel
-    {
-        int rc = run_single(h, dense_group(cur, U, w.gru_in_wt, w.gru_in_b, xproj, 6 * H, M, 6 * H, U, ACT_NONE));
-        if (rc) return rc;
-        ++*launches;
+    } else {
+        // lifter
+        {
+            int rc = run_single(h, dense_group(p2, w.proj_filters[1], w.lifter_wt, w.lifter_b, hw0, U, M, U,
+                                               w.proj_filters[1], ACT_RELU));
+            if (rc) return rc;
+            ++*launches;
+        }
+        // highway layers (H|T in one GEMM, gate mix in the epilogue), ping-pong buffers
+        float* cur = hw0;
+        float* nxt = hw1;
+        for (size_t l = 0; l < w.hw_wt.size(); ++l) {
+            GemmGroup g = dense_group(cur, U, w.hw_wt[l], w.hw_b[l], nxt, U, M, 2 * U, U, ACT_NONE);
+            g.epi = EPI_HIGHWAY;
+            int rc = run_single(h, g);
+            if (rc) return rc;
+            ++*launches;
+            std::swap(cur, nxt);
+        }
+        // GRU input projections for both directions, then the recurrent kernel
+        {
+            int rc = run_single(h, dense_group(cur, U, w.gru_in_wt, w.gru_in_b, xproj, 6 * H, M, 6 * H, U, ACT_NONE));
+            if (rc) return rc;
+            ++*launches;
+        }
     }
     HIPCHK(h, launch_bigru(h->stream, xproj, 6 * H, w.gru_rec, out, B, T, H, c.force_cudnn));
     ++*launches;
@@ -1174,6 +1194,7 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     if (!h || !key) return TTS_ERR_INVALID;
     if (!std::strcmp(key, "use_graph")) h->use_graph = value;
     else if (!std::strcmp(key, "profile")) h->profile = value;
+    else if (!std::strcmp(key, "fused_tail")) h->fused_tail = value;
     else if (!std::strcmp(key, "persistent_decoder")) h->persistent_decoder = value;
     else if (!std::strcmp(key, "gl_pair")) h->gl_pair = value;
     else if (!std::strcmp(key, "pd_debug_delay")) pd_debug_delay = value;   // tests only (decoder_persistent.hip)

@@ -95,6 +95,22 @@ hipError_t launch_bigru(hipStream_t s, const float* xproj, int xld, const float*
                         int B, int T, int H, int cudnn);
 size_t bigru_wrec_floats(int H, int cudnn);
 
+// ----------------------------------------------------------------------------- CBHG tail (cbhg_tail.hip)
+// lifter + highway stack + GRU input projections of a CBHG in one launch; the rows stay in LDS between the layers.
+#define CBHG_TAIL_MAX_HW 8
+struct CbhgTailParams {
+    const float* X; int ldx; int c_in;        // [M][ldx], c_in valid floats per row (the projections' residual output)
+    const float* lifter_wt; const float* lifter_b;                       // [128][c_in], [128]
+    const float* hw_wt[CBHG_TAIL_MAX_HW]; const float* hw_b[CBHG_TAIL_MAX_HW]; int n_hw;   // [256][128] / [256], H|T packed per 64-row span
+    const float* gru_wt; const float* gru_b;  // [768][128], [768]
+    float* hw_out;                            // [M][128] the highway stack's output (null: not wanted)
+    float* xproj;                             // [M][768]
+    int M;
+};
+bool cbhg_tail_supports(int c_in, int units, int gru_units, int n_hw, long long M);
+hipError_t cbhg_tail_configure();             // per device, before the first launch
+hipError_t launch_cbhg_tail(hipStream_t s, const CbhgTailParams& p);
+
 // ----------------------------------------------------------------------------- CU reservation (reserve.hip)
 hipError_t cu_hold_configure();   // per device, before the first launch_cu_hold
 hipError_t launch_cu_hold(hipStream_t s, int n_cus, const int* flag, double timeout_ms, int lds_kb = 64);

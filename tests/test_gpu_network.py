@@ -106,3 +106,51 @@ def test_full_network_small(engine, hparams, weights64):
     lin = engine.postnet_forward(mel.to_host().reshape(B, -1, 80))
     assert rel_l2(mel.to_host(), ref['reduced_mel']) < FINAL_TOL
     assert rel_l2(lin.to_host(), ref['linear']) < FINAL_TOL
+
+
+# ---- CBHG tail (csrc/cbhg_tail.hip): lifter + highway stack + GRU input projections in one launch, against the oracle and
+# against the layer-by-layer GEMM chain it replaces
+@pytest.mark.parametrize('fused', [1, 0])
+@pytest.mark.parametrize('B,T', [(1, 1), (2, 63), (3, 129), (5, 200)])   # one row, a partial tile, tile + 1 row + remainder, several tiles
+def test_cbhg_tail_forms(engine, hparams, weights64, fused, B, T):
+    rng = np.random.default_rng(900 + B)
+    mel = rng.random((B, T, 80)).astype(np.float32)
+    stages = {}
+    ref = O.post_process(mel.astype(np.float64), weights64, hparams, stages)
+    engine.set_option('fused_tail', fused)
+    try:
+        lin = engine.postnet_forward(mel).to_host()
+        hw = engine.debug_workspace('post.hw0', (B, T, 128))
+        gru = engine.debug_workspace('post.gru', (B, T, 256))
+    finally:
+        engine.set_option('fused_tail', 1)
+    e = {'highway': rel_l2(hw, stages['highway']), 'gru': rel_l2(gru, stages['gru']), 'linear': rel_l2(lin, ref)}
+    print('cbhg tail fused={} B={} T={}: {}'.format(fused, B, T, e))
+    assert e['highway'] < STAGE_TOL and e['gru'] < FINAL_TOL and e['linear'] < FINAL_TOL, e
+
+
+@pytest.mark.parametrize('n_hw', [0, 1, 3])
+def test_cbhg_tail_layer_counts(hparams, n_hw):
+    """other highway depths than the reference's four (layers.py:546-558 takes any): encoder (128-wide input, the lifter sees
+    full k-chunks) and post-net (80-wide: a padded chunk) against the oracle"""
+    import copy
+    hp = copy.deepcopy(hparams)
+    hp.encoder.n_highway_layers = n_hw
+    hp.post.n_highway_layers = n_hw
+    w = pkg('tacotron.weights').synthetic_weights(3, hp)
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    eng = pkg().Engine(hp)
+    try:
+        eng.load_weights(w)
+        rng = np.random.default_rng(n_hw)
+        ids = make_ids(rng, 3, 50)
+        mem = eng.encoder_forward(ids).to_host()
+        assert rel_l2(mem, O.encoder(ids, w64, hp, {})) < FINAL_TOL
+        mel = rng.random((2, 70, 80)).astype(np.float32)
+        st = {}
+        ref = O.post_process(mel.astype(np.float64), w64, hp, st)
+        lin = eng.postnet_forward(mel).to_host()
+        assert rel_l2(eng.debug_workspace('post.hw0', (2, 70, 128)), st['highway']) < STAGE_TOL
+        assert rel_l2(lin, ref) < FINAL_TOL
+    finally:
+        eng.close()

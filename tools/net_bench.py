@@ -14,9 +14,13 @@ mel = eng.to_device(rng.random((64, 1000, 80), dtype=np.float32))
 mem = eng.encoder_forward(ids)
 lin = eng.postnet_forward(mel)
 eng.set_option('profile', 1)
-eng.profile_reset()
 n = 5
-for _ in range(n):
+for fused in (0, 1, 0, 1):   # the CBHG tail as the GEMM chain / as one launch (csrc/cbhg_tail.hip)
+    eng.set_option('fused_tail', fused)
     eng.encoder_forward(ids, out=mem)
     eng.postnet_forward(mel, out=lin)
-print('encoder %.3f ms, postnet %.3f ms' % (eng.profile_get('encoder')[0] / n, eng.profile_get('postnet')[0] / n))
+    eng.profile_reset()
+    for _ in range(n):
+        eng.encoder_forward(ids, out=mem)
+        eng.postnet_forward(mel, out=lin)
+    print('fused_tail %d: encoder %.3f ms, postnet %.3f ms' % (fused, eng.profile_get('encoder')[0] / n, eng.profile_get('postnet')[0] / n))
