@@ -296,8 +296,15 @@ def main():
     lin_out = None if args.no_aux_outputs else eng.empty((B, T, F))
     ali_out = None if args.no_aux_outputs else eng.empty((N_STEPS, B, TS))
 
+    # Initial phases: drawn per call inside the path, as the reference does (np.random.rand in audio/synthesis.py:91) -- here
+    # a counter-based draw from a per-call seed, made by the first Griffin-Lim launch itself (csrc/griffin_lim.hip,
+    # gl_seed_phasor).  `init` (an explicit (B, F, T) array, what the parity tests pass) is only used by the stand-alone
+    # Griffin-Lim measurement below.
+    calls = [0]
+
     def step():
-        eng.synthesize(ids, N_STEPS, REF_DB, MAX_DB, POWER, N_ITER, WIN, HOP, init_phase=init,
+        calls[0] += 1
+        eng.synthesize(ids, N_STEPS, REF_DB, MAX_DB, POWER, N_ITER, WIN, HOP, seed=1000 * (rank + 1) + calls[0],
                        peak_normalize=True, wav=wav, want_linear=lin_out, want_alignments=ali_out)
 
     def barrier():

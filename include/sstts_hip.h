@@ -104,8 +104,12 @@ int tts_set_stream(tts_handle_t h, void* hip_stream);
  * of that reservation allocates), "persistent_decoder" (the whole decoder loop as ONE launch of co-resident
  * workgroup clusters, two decoder GRU layers, at most 64 utterances under the pipeline: 1 = under the call pipeline
  * with more than 48 utterances per call, where it pays (default), 2 = whenever the configuration allows, 0 = never; tts_synchronize reports TTS_ERR_HIP if one of its bounded waits timed out),
- * "gl_fused" (default 0; 1 = all Griffin-Lim iterations of a call in one launch when no per-iteration mse is
- * asked for: identical waveforms, same bounded-wait error report). */
+ * "gl_pair" (Griffin-Lim iterations per launch, 1..3, default 3: the spectrum passes from one iteration to the next in
+ * registers; identical arithmetic per iteration), "fused_tail" (default 1: lifter + highway stack + GRU input
+ * projections of a CBHG as one launch; 0 = layer by layer).
+ * Initial phases of Griffin-Lim: `init_phase` (a (B, F, T) array of U[0,1) numbers, angle = 2 pi u) or, when it is NULL,
+ * a counter-based draw from `seed` made inside the first iteration's launch (the reference draws np.random.rand per call,
+ * audio/synthesis.py:91). */
 int tts_set_option(tts_handle_t h, const char* key, int value);
 int tts_synchronize(tts_handle_t h);
 

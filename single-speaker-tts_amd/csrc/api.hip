@@ -943,7 +943,11 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     // one zeroed work counter per launch (the persistent workgroups draw their item ids from it)
     WS(h, "gl.counters", unsigned, (size_t)n_iter + 1, counters);
     HIPCHK(h, hipMemsetAsync(counters, 0, ((size_t)n_iter + 1) * sizeof(unsigned), h->stream));
-    if (!phase_ready) HIPCHK(h, launch_phase_init(h->stream, init_ft, seed, ph0, B, F, T, FP));
+    // a seeded start with at least one iteration needs no codes: the first launch makes the initial phasors itself
+    const bool seed_in_kernel = !init_ft && n_iter >= 1;
+    if (!phase_ready && !seed_in_kernel) HIPCHK(h, launch_phase_init(h->stream, init_ft, seed, ph0, B, F, T, FP));
+    p.F = F;
+    p.seed = seed;
     float2* cur = ph0;
     float2* nxt = ph1;
     const int free_cus = n_cus - held > 16 ? n_cus - held : n_cus;
@@ -961,6 +965,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
             const int n_stage = left >= per_launch ? per_launch : (left >= 1 ? left : 1);
             p.phase_in = cur;
             p.phase_out = nxt;
+            p.seeded = seed_in_kernel && it == 0;
             p.mse_partial = want_mse ? msep : nullptr;
             p.work_counter = counters + it;
 #ifdef GL_TIMELINE   // tools only: stamps of workgroup 0 during the last launch
@@ -1020,6 +1025,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     }
     {
         ProfScope ps(h, ST_GL_FINAL, 1);
+        p.seeded = 0;
         p.phase_in = cur;
         p.phase_out = nullptr;
         p.mse_partial = nullptr;
@@ -1894,7 +1900,8 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         if (hold_flag) hipMemsetAsync(hold_flag, 1, sizeof(int), h->front);
         return rc;
     }
-    const bool phase_on_front = pipelined && sp->n_iter >= 0;
+    // (a seeded start with iterations needs no initial codes at all: gl_run)
+    const bool phase_on_front = pipelined && sp->n_iter >= 0 && (init_phase != nullptr || sp->n_iter == 0);
     if (pipelined) {
         if (hold_flag) HIPCHK(h, hipMemsetAsync(hold_flag, 1, sizeof(int), h->front));   // release the held CUs
         if (phase_on_front) {

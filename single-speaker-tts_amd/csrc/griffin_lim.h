@@ -32,6 +32,10 @@ struct GlParams {
     int cls_C[GL_MAX_CLASSES], cls_n[GL_MAX_CLASSES], cls_t0[GL_MAX_CLASSES], cls_slot0[GL_MAX_CLASSES], cls_first[GL_MAX_CLASSES];
     int ring_frames;         // streaming form (gl_stream_kernel): frames an LDS ring holds
     int n_stage;             // ... iterations per launch (1..3), set by launch_gl_stream
+    // seeded start (no initial-phase array): the first launch of a call makes the initial phasor of every bin itself
+    // (gl_seed_phasor of the seed and the bin's index in the reference's (B, F, T) layout) instead of reading codes
+    int seeded, F;
+    unsigned long long seed;
     unsigned* work_counter;  // zeroed counter of THIS launch: the persistent workgroups draw item ids from it
     unsigned long long* dbg; // tools only (-DGL_TIMELINE builds): [GL waves][64] s_memrealtime stamps of workgroup 0
 };

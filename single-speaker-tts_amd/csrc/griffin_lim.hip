@@ -323,6 +323,17 @@ __device__ __forceinline__ void gl_stream_store(cf* p, cf v) { __builtin_nontemp
 // to (1, 0), numpy's exp(1j * angle(0)) (and -0.0 + 0j to (-1, 0), also numpy's).  Worst-case error of a decoded
 // component 3e-7 (two dropped mantissa bits of r, one v_rcp_f32, one v_rsq_f32; tests/test_host_logic.py::
 // test_phasor_code_emulation), the size of the rounding in the x * rsq(|x|^2) * |S| product it replaces.
+// Seeded start: the initial phasor e^{2 pi i u} of a bin, u = 24 bits of a 32-bit mix (lowbias32) of the seed and the
+// bin's index in the reference's (B, F, T) layout.  The reference draws np.random.rand per call (audio/synthesis.py:91);
+// a counter-based draw gives every bin its number wherever it is needed, so the first Griffin-Lim launch of a call makes
+// its own initial estimate instead of reading 4 bytes per bin that another kernel wrote.  v_sin_f32 / v_cos_f32 take
+// revolutions; their ~1e-6 error is a perturbation of a random angle.
+__device__ __forceinline__ cf gl_seed_phasor(unsigned long long seed, unsigned long long idx) {
+    unsigned x = (unsigned)idx ^ ((unsigned)(idx >> 32) * 0x9E3779B9u) ^ (unsigned)seed ^ ((unsigned)(seed >> 32) * 0x85EBCA6Bu);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    const float u = (float)(x >> 8) * (1.0f / 16777216.0f);
+    return cmk(__builtin_amdgcn_cosf(u), __builtin_amdgcn_sinf(u));
+}
 __device__ __forceinline__ unsigned gl_pack_phasor(cf x) {   // x: any scale
     const bool sw = fabsf(x.x) < fabsf(x.y);
     const float small = sw ? x.x : x.y;
@@ -397,8 +408,11 @@ enum { CT_OLA = 0, CT_SNEXT = 1, CT_OLB = 2 /* chain words of stages 1, 2 */, CT
 // ~90 VALU instructions per frame and iteration less) and goes straight into stage B -- inverse FFT, overlap-add into
 // ring B in the order of ITS chain, forward FFT of frame t - 2 lag, phasor code, store.  A run then needs halo + lag
 // more frames at either end in stage A (2.6 % more transforms for runs of 144 frames).
-template <int MODE, int WIN_CT, int HOP_CT, bool MSE, int NST = 1>
+// SEEDED: stage 0 makes its input from the seed (the first launch of a call without an initial-phase array) -- an
+// instantiation of its own: as a run-time branch it cost every launch 38 more spilled registers.
+template <int MODE, int WIN_CT, int HOP_CT, bool MSE, int NST = 1, bool SEEDED = false>
 __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
+    static_assert(!SEEDED || MODE == 0, "the seeded start is an iteration's");
     static_assert(NST == 1 || (NST >= 2 && NST <= 3 && MODE == 0 && !MSE), "several iterations per launch: plain iterations only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int win = WIN_CT ? WIN_CT : p.win;
@@ -486,15 +500,18 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
     float gs[16];
     unsigned nyq_c;
     float nyq_s;
+    constexpr bool seeded = SEEDED;
 #define GLS_LOAD_ROW(BASE_C, BASE_M, TF)                                                        \
     {                                                                                           \
         int tf_ = (TF);                                                                         \
         tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                       \
         const unsigned* prow_ = (BASE_C) + (size_t)tf_ * p.FP + lane;                           \
         const float* srow_ = (BASE_M) + (size_t)tf_ * p.FP + lane;                              \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = GL_ABL_LD(prow_[64 * j_], (unsigned)(tf_ * 64 + j_) * 0x9E3779B9u);              \
+        if (!seeded) {                                                                          \
+            _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = GL_ABL_LD(prow_[64 * j_], (unsigned)(tf_ * 64 + j_) * 0x9E3779B9u);          \
+            nyq_c = prow_[MH - lane];                                                           \
+        }                                                                                       \
         _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_ABL_LD(GL_STREAM_LOAD(srow_ + 64 * j_), (float)(tf_ + j_ + lane)); \
-        nyq_c = prow_[MH - lane];                                                               \
         nyq_s = srow_[MH - lane];                                                               \
     }
     // vmcnt counts loads and stores together, in issue order.  The row for the next iteration is requested early in
@@ -732,9 +749,20 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
             cf v[16];
             if (valid) {
                 cf gk[16];   // X[k] = |S[k]| * phasor[k]
+                if (seeded) {
+                    const unsigned long long row0 = (unsigned long long)b * p.F * p.T + (unsigned long long)t;   // bin f: + f T
 #pragma unroll
-                for (int j = 0; j < 16; ++j) gk[j] = gl_unpack_phasor(gc[j], gs[j]);
-                split_pass(gk, cmk(gl_unpack_phasor(nyq_c, nyq_s).x, 0.f), v);
+                    for (int j = 0; j < 16; ++j) {
+                        const cf e = gl_seed_phasor(p.seed, row0 + (unsigned long long)(lane + 64 * j) * p.T);
+                        gk[j] = cmk(gs[j] * e.x, gs[j] * e.y);
+                    }
+                    const cf en = gl_seed_phasor(p.seed, row0 + (unsigned long long)(MH - lane) * p.T);
+                    split_pass(gk, cmk(nyq_s * en.x, 0.f), v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) gk[j] = gl_unpack_phasor(gc[j], gs[j]);
+                    split_pass(gk, cmk(gl_unpack_phasor(nyq_c, nyq_s).x, 0.f), v);
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) v[j] = cmk(0.f, 0.f);
@@ -1024,7 +1052,10 @@ void gl_plan_stream(GlParams& p, int n_workers) {
 
 template <int MODE, int W, int H, bool MSE, int NST = 1>
 static hipError_t gl_stream_set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_stream_kernel<MODE, W, H, MSE, NST>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_stream_kernel<MODE, W, H, MSE, NST, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess || MODE != 0) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gl_stream_kernel<0, W, H, MSE, NST, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -1041,31 +1072,37 @@ hipError_t launch_gl_stream(hipStream_t s, const GlParams& p_in, int n_cus, int 
     dim3 grid(nwg);
     const bool ref_cfg = p.win == 1102 && p.hop == 275;
     const bool mse = p.mse_partial != nullptr;
-#define GLS_LAUNCH(MODE, W, H, M) hipLaunchKernelGGL((gl_stream_kernel<MODE, W, H, M>), grid, dim3(GL_THREADS), lds, s, p)
+#define GLS_LAUNCH_N(MODE, W, H, M, N)                                                                                   \
+    {                                                                                                                    \
+        if (MODE == 0 && p.seeded) hipLaunchKernelGGL((gl_stream_kernel<0, W, H, M, N, true>), grid, dim3(GL_THREADS), lds, s, p);   \
+        else hipLaunchKernelGGL((gl_stream_kernel<MODE, W, H, M, N, false>), grid, dim3(GL_THREADS), lds, s, p);        \
+    }
+#define GLS_LAUNCH(MODE, W, H, M) GLS_LAUNCH_N(MODE, W, H, M, 1)
 #ifdef GL_FAST_BUILD
     if (!ref_cfg || mse) return hipErrorInvalidValue;
-    if (final_istft) GLS_LAUNCH(1, 1102, 275, false);
-    else if (n_stage == 2) hipLaunchKernelGGL((gl_stream_kernel<0, 1102, 275, false, 2>), grid, dim3(GL_THREADS), lds, s, p);
-    else if (n_stage == 3) hipLaunchKernelGGL((gl_stream_kernel<0, 1102, 275, false, 3>), grid, dim3(GL_THREADS), lds, s, p);
-    else GLS_LAUNCH(0, 1102, 275, false);
+    if (final_istft) GLS_LAUNCH(1, 1102, 275, false)
+    else if (n_stage == 2) GLS_LAUNCH_N(0, 1102, 275, false, 2)
+    else if (n_stage == 3) GLS_LAUNCH_N(0, 1102, 275, false, 3)
+    else GLS_LAUNCH(0, 1102, 275, false)
 #else
     if (n_stage == 3) {
-        if (ref_cfg) hipLaunchKernelGGL((gl_stream_kernel<0, 1102, 275, false, 3>), grid, dim3(GL_THREADS), lds, s, p);
-        else hipLaunchKernelGGL((gl_stream_kernel<0, 0, 0, false, 3>), grid, dim3(GL_THREADS), lds, s, p);
+        if (ref_cfg) GLS_LAUNCH_N(0, 1102, 275, false, 3)
+        else GLS_LAUNCH_N(0, 0, 0, false, 3)
     } else if (n_stage == 2) {
-        if (ref_cfg) hipLaunchKernelGGL((gl_stream_kernel<0, 1102, 275, false, 2>), grid, dim3(GL_THREADS), lds, s, p);
-        else hipLaunchKernelGGL((gl_stream_kernel<0, 0, 0, false, 2>), grid, dim3(GL_THREADS), lds, s, p);
+        if (ref_cfg) GLS_LAUNCH_N(0, 1102, 275, false, 2)
+        else GLS_LAUNCH_N(0, 0, 0, false, 2)
     } else if (final_istft) {
-        if (ref_cfg) GLS_LAUNCH(1, 1102, 275, false);
-        else GLS_LAUNCH(1, 0, 0, false);
+        if (ref_cfg) GLS_LAUNCH(1, 1102, 275, false)
+        else GLS_LAUNCH(1, 0, 0, false)
     } else if (mse) {
-        if (ref_cfg) GLS_LAUNCH(0, 1102, 275, true);
-        else GLS_LAUNCH(0, 0, 0, true);
+        if (ref_cfg) GLS_LAUNCH(0, 1102, 275, true)
+        else GLS_LAUNCH(0, 0, 0, true)
     } else {
-        if (ref_cfg) GLS_LAUNCH(0, 1102, 275, false);
-        else GLS_LAUNCH(0, 0, 0, false);
+        if (ref_cfg) GLS_LAUNCH(0, 1102, 275, false)
+        else GLS_LAUNCH(0, 0, 0, false)
     }
 #endif
+#undef GLS_LAUNCH_N
 #undef GLS_LAUNCH
     return hipGetLastError();
 }
@@ -1313,16 +1350,8 @@ hipError_t launch_tf_to_ft(hipStream_t s, const float* in, float* out, int B, in
     return hipGetLastError();
 }
 
-// counter-based uniform [0,1) generator (splitmix64 finaliser) for the initial phases
-__device__ __forceinline__ float u01(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
-
-// angles = exp(2 pi i u): u from init (B,F,T) reference layout or from the seed; out (B,T,FP) phasor codes (no magnitudes
+// angles = exp(2 pi i u): u from init (B,F,T) reference layout, or the seeded start (gl_seed_phasor: only needed as codes when
+// no iteration follows -- the first launch of an iteration makes it itself); out (B,T,FP) phasor codes (no magnitudes
 // needed: the state is the phasor alone).  Running it on a side stream beside the post-net was tried and cost 1.3 ms
 // per step instead of saving 0.17: a third busy stream slows the Griffin-Lim launches of the main one.
 __global__ void phase_init_kernel(const float* init_ft, uint64_t seed, unsigned* out, int F, int T, int FP) {
@@ -1335,7 +1364,7 @@ __global__ void phase_init_kernel(const float* init_ft, uint64_t seed, unsigned*
         float u = 0.f;
         if (f < F && t < T) {
             const size_t idx = ((size_t)b * F + f) * T + t;
-            u = init_ft ? init_ft[idx] : u01(seed, idx);
+            u = init_ft ? init_ft[idx] : 0.f;
         }
         tile[i][tx] = u;
     }
@@ -1345,7 +1374,9 @@ __global__ void phase_init_kernel(const float* init_ft, uint64_t seed, unsigned*
         if (t < T && f < FP) {
             float sn, cs;
             sincospif(2.0f * tile[tx][i], &sn, &cs);
-            out[((size_t)b * T + t) * FP + f] = gl_pack_phasor(cmk(cs, sn));   // phasor of exp(2 pi i u)
+            cf e = cmk(cs, sn);   // phasor of exp(2 pi i u)
+            if (!init_ft) e = f < F ? gl_seed_phasor(seed, ((unsigned long long)b * F + f) * T + t) : cmk(1.f, 0.f);   // the seeded start
+            out[((size_t)b * T + t) * FP + f] = gl_pack_phasor(e);
         }
     }
 }
