@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 echo "== bench"; python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/bench.err; tail -c 400 $O/${TAG}_bench.json; echo
 for PL in 1 0; do
   rm -rf $O/stats$PL
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats$PL -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --pipeline $PL > $O/stats$PL.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats$PL -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --pipeline $PL > $O/stats$PL.log 2>&1
   cp $(ls $O/stats$PL/*/*kernel_stats.csv | head -1) $O/${TAG}_bench_kernel_stats_pipeline$PL.csv
   echo "== kernel stats pipeline=$PL done"
 done
