@@ -110,3 +110,72 @@ def test_hip_denorm_power_against_the_reference(engine, fx):
     assert mag1.shape == arrays['chain_mag'].shape == (1025, lin.shape[1])
     assert np.abs(mag1 / arrays['chain_mag'] - 1.0).max() <= 5e-6                 # one fp32 exp2 of |x| < 17
     assert np.abs(magp / arrays['chain_pow'] - 1.0).max() <= 8e-6                 # ... of |x| < 22
+
+
+# ---- hyper-parameters: the mirror's defaults against the reference's own HParams calls (tests/golden/params.json, read
+# out of tacotron/params/{model,inference,dataset}.py and datasets/lj_speech.py with ast by make_params_fixtures.py)
+_NAMES = {'tf.nn.relu': 'relu', 'LuongAttention': 'LuongAttention', 'LocalLuongAttention': 'LocalLuongAttention',
+          'AttentionScore.DOT': 'dot', 'AttentionMode.MONOTONIC': 'monotonic', 'AttentionMode.PREDICTIVE': 'predictive',
+          'LJSpeechDatasetHelper': 'LJSpeechDatasetHelper'}
+
+
+def _norm(v):
+    """reference value as stored in the fixture -> the form the mirror keeps (names as strings, tuples as lists)"""
+    if isinstance(v, dict) and set(v) == {'name'}:
+        return _NAMES[v['name']]
+    if isinstance(v, dict):
+        return {k: _norm(x) for k, x in v.items()}
+    if isinstance(v, list):
+        return [_norm(x) for x in v]
+    return v
+
+
+def _plain(v):
+    import dataclasses
+    if dataclasses.is_dataclass(v) and not isinstance(v, type):
+        return {f.name: _plain(getattr(v, f.name)) for f in dataclasses.fields(v)}
+    if isinstance(v, (tuple, list)):
+        return [_plain(x) for x in v]
+    if isinstance(v, dict):
+        return {k: _plain(x) for k, x in v.items()}
+    return v
+
+
+def test_hyper_parameters_equal_the_reference():
+    import json
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'params.json')))
+    P = pkg('tacotron.params')
+    mine = _plain(P.ModelParams())
+    theirs = _norm(ref['model_params'])
+    assert set(mine) == set(theirs), set(mine) ^ set(theirs)
+    # the one documented difference: the reference ships force_cudnn=True (CudnnGRU, no CPU kernel in TF 1.8); the parity
+    # target named by BASELINE.json is the TF CPU path = force_cudnn=False (params.py docstring, SURVEY.md section 8)
+    assert theirs.pop('force_cudnn') is True and mine.pop('force_cudnn') is False
+    assert mine == theirs, {k: (mine[k], theirs[k]) for k in mine if mine[k] != theirs[k]}
+    assert _plain(P.InferenceParams()) == _norm(ref['inference_params'])
+    d_mine, d_ref = _plain(P.DatasetParams()), _norm(ref['dataset_params'])
+    assert d_mine.pop('dataset_loader').__name__ in ('LJSpeechConstants', 'LJSpeechDatasetHelper') and d_ref.pop('dataset_loader') == 'LJSpeechDatasetHelper'
+    assert d_mine == d_ref
+    for k, v in ref['lj_speech_constants'].items():
+        assert getattr(P.LJSpeechConstants, k) == v, k
+    # ... and what the C ABI's default configuration says (tts_default_config) is what those parameters say
+    import ctypes
+    H = pkg('_hip')
+    if os.path.exists(H.LIB_PATH):
+        lib = ctypes.CDLL(H.LIB_PATH)
+        cfg = H.TtsConfig()
+        lib.tts_default_config(ctypes.byref(cfg))
+        m = ref['model_params']
+        assert (cfg.vocabulary_size, cfg.embedding_size, cfg.n_mels, cfg.reduction, cfg.n_fft) == \
+               (m['vocabulary_size'], m['encoder']['embedding_size'], m['n_mels'], m['reduction'], m['n_fft'])
+        assert [cfg.enc_prenet_units[0], cfg.enc_prenet_units[1]] == [l[0] for l in m['encoder']['pre_net_layers']]
+        assert [cfg.dec_prenet_units[0], cfg.dec_prenet_units[1]] == [l[0] for l in m['decoder']['pre_net_layers']]
+        assert (cfg.enc_n_banks, cfg.enc_n_filters, cfg.post_n_banks, cfg.post_n_filters) == \
+               (m['encoder']['n_banks'], m['encoder']['n_filters'], m['post']['n_banks'], m['post']['n_filters'])
+        assert [cfg.enc_proj_filters[0], cfg.enc_proj_filters[1]] == [p[0] for p in m['encoder']['projections']]
+        assert [cfg.post_proj_filters[0], cfg.post_proj_filters[1]] == [p[0] for p in m['post']['projections']]
+        assert (cfg.n_highway_layers, cfg.n_highway_units, cfg.n_gru_units) == \
+               (m['encoder']['n_highway_layers'], m['encoder']['n_highway_units'], m['encoder']['n_gru_units'])
+        assert (cfg.n_attention_units, cfg.n_decoder_gru_units, cfg.n_decoder_gru_layers) == \
+               (m['decoder']['n_attention_units'], m['decoder']['n_decoder_gru_units'], m['decoder']['n_gru_layers'])
+        assert cfg.luong_local_window_d == m['attention']['luong_local_window_D'] and cfg.luong_force_gaussian == 1
