@@ -130,3 +130,45 @@ def test_griffin_lim_iterations_per_launch(engine, per_launch, B, T, n_iter, wan
         assert e < 1e-4 * n_iter
         if want_mse:
             assert abs(mse[b] - ref_mse) <= 1e-3 * abs(ref_mse) + 1e-9
+
+
+def seed_u(seed, B, F, T):
+    """numpy restatement of gl_seed_phasor's angle (csrc/griffin_lim.hip): u = 24 bits of lowbias32(index ^ seed mix),
+    index = (b F + f) T + t in the reference's (B, F, T) layout"""
+    idx = np.arange(B * F * T, dtype=np.uint64)
+    lo, hi = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32)
+    s_lo, s_hi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+    with np.errstate(over='ignore'):
+        x = lo ^ (hi * np.uint32(0x9E3779B9)) ^ s_lo ^ np.uint32((int(s_hi) * 0x85EBCA6B) & 0xFFFFFFFF)
+        x ^= x >> np.uint32(16); x *= np.uint32(0x7FEB352D); x ^= x >> np.uint32(15); x *= np.uint32(0x846CA68B); x ^= x >> np.uint32(16)
+    return ((x >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).reshape(B, F, T)
+
+
+@pytest.mark.parametrize('per_launch,n_iter,want_mse', [(1, 1, False), (2, 2, False), (3, 3, False), (3, 7, False), (3, 4, True), (3, 0, False)])
+@pytest.mark.parametrize('seed', [0, 5, (7 << 32) + 12345])
+def test_griffin_lim_seeded_start(engine, per_launch, n_iter, want_mse, seed):
+    """With no initial-phase array the first launch of the iteration draws every bin's phasor from the seed itself (the
+    SEEDED instantiations of gl_stream_kernel for 1, 2 and 3 iterations per launch and the mse form; with no iteration
+    the codes come from phase_init_kernel): the same waveform, to the v_sin / v_cos error, as an explicit array holding
+    the numpy restatement of those draws, and as the oracle started from that array."""
+    B, T = 3, 41
+    rng = np.random.default_rng(77)
+    mag = synth_mag(rng, B, T)
+    u = seed_u(seed, B, mag.shape[1], T)
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.02
+    engine.set_option('gl_pair', per_launch)
+    try:
+        w_seed, m_seed = engine.griffin_lim(mag, n_iter, WIN, HOP, N_FFT, seed=seed, want_mse=want_mse)
+        w_expl, m_expl = engine.griffin_lim(mag, n_iter, WIN, HOP, N_FFT, init_phase=u, want_mse=want_mse)
+        w_again, _ = engine.griffin_lim(mag, n_iter, WIN, HOP, N_FFT, seed=seed, want_mse=want_mse)
+    finally:
+        engine.set_option('gl_pair', 3)
+    w_seed, w_expl = w_seed.to_host(), w_expl.to_host()
+    assert np.array_equal(w_seed, w_again.to_host())
+    tol = 2e-5 * max(1, n_iter)
+    assert rel_l2(w_seed, w_expl) < tol, rel_l2(w_seed, w_expl)
+    for b in range(B):
+        ref_wav, ref_mse = A.griffin_lim_v2(mag[b], WIN, HOP, N_FFT, n_iter, init_phase=u[b])
+        assert rel_l2(w_seed[b], ref_wav) < 1e-4 * max(1, n_iter)
+        if want_mse:
+            assert abs(m_seed.to_host()[b] - ref_mse) <= 1e-3 * abs(ref_mse) + 1e-9
