@@ -216,7 +216,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit('WORLD_SIZE ({}) != --gpus ({})'.format(world, args.gpus))
     dist = None
-    if world > 1:
+    # SSTTS_DIST_SINGLE=1: bring the process group up for a single rank too (a one-GPU box cannot hold two RCCL ranks; this
+    # is how far the RCCL path -- communicator, broadcast, barrier, all-reduce beside the library's streams -- can be
+    # rehearsed there: tests/test_gpu_bench_launch.py)
+    if world > 1 or (os.environ.get('SSTTS_DIST_SINGLE') == '1' and 'RANK' in os.environ):
         import torch
         import torch.distributed as dist
         # one process per GPU over RCCL ("nccl" IS RCCL on ROCm).  SSTTS_DIST_BACKEND=gloo lets the
@@ -251,7 +254,7 @@ def main():
     else:
         blob = np.empty(n_floats, np.float32)
     broadcast_ms = None
-    if world > 1:
+    if dist is not None:
         # the ONE collective of the path (RCCL over xGMI under "nccl"); nothing is exchanged afterwards
         if dist.get_world_size() != args.gpus:
             raise SystemExit('process group has {} ranks, --gpus says {}'.format(dist.get_world_size(), args.gpus))
@@ -262,7 +265,7 @@ def main():
         dist.barrier()
         broadcast_ms = 1e3 * (time.perf_counter() - t0)   # includes the communicator set-up of the first collective
     eng = sstts.Engine(hp, device_id=local_rank)
-    if world > 1 and dist.get_backend() == 'nccl':
+    if dist is not None and dist.get_backend() == 'nccl':
         import torch
         # one process per GPU: this rank's handle and its RCCL communicator sit on the same device, a different one per rank
         if eng.device_id != local_rank or torch.cuda.current_device() != local_rank:

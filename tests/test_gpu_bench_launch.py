@@ -24,3 +24,23 @@ def test_bench_gpus2_self_launch_gloo():
     assert rec['n_gpus'] == 2 and rec['world_size_seen'] == 2
     assert rec['config']['global_batch'] == 128 and rec['scaling'] == 'weak'
     assert rec['value'] > 0 and rec['steps'] == 2
+
+
+def test_bench_under_torchrun_one_rccl_rank():
+    """The driver's launch line (python -m torch.distributed.run ... bench.py --gpus N) with the `nccl` = RCCL backend, as
+    far as a one-GPU box allows: ONE rank (two RCCL ranks cannot share a device), SSTTS_DIST_SINGLE=1 makes bench.py bring
+    the process group up anyway -- communicator set-up, the weight broadcast from a device tensor, barriers around the timed
+    region and the max all-reduce all run on RCCL beside the library's own streams."""
+    env = dict(os.environ, SSTTS_DIST_SINGLE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('SSTTS_DIST_BACKEND', None)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+                          '--master-addr', '127.0.0.1', '--master-port', '29533', os.path.join(ROOT, 'bench.py'),
+                          '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    assert 'backend nccl world size 1' in out.stderr.decode()
+    rec = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert rec['n_gpus'] == 1 and rec['world_size_seen'] == 1 and rec['weight_broadcast_ms'] is not None
+    assert rec['value'] > 0 and rec['steps'] == 3
