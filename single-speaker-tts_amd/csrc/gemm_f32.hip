@@ -18,6 +18,12 @@
 
 namespace tts {
 
+// Register cap: amdgpu_num_vgpr(80) makes hipcc allocate 160 unified registers (accumulators included, four values spilled)
+// instead of 104 + 64 accumulation registers: still three waves per SIMD, the encoder / post-net 2.5 % faster alone (2.83 ->
+// 2.75 ms) and 32 registers per lane left on a CU that holds three GEMM workgroups (small kernels of the other stream fit).
+#ifndef GEMM_NUM_VGPR
+#define GEMM_NUM_VGPR 80
+#endif
 #define BM 128
 #define BN 128
 #define BK 32
@@ -33,7 +39,7 @@ __device__ __forceinline__ float4 max4(float4 a, float4 b) {
 // POOL: instantiation whose A loader takes max(x[t], x[t+1]) (the two k = 3 projections that follow a max-pool): kept
 // apart so that every other GEMM carries neither its second load nor its registers.
 template <bool DENORM, bool POOL>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR))) void gemm_f32_kernel(GemmBatch batch) {
     const GemmGroup& g = batch.g[blockIdx.z];
     const int M = g.M, N = g.N, K = g.K;
     // Workgroup -> tile map.  Workgroups are dealt round-robin over the 8 XCDs in launch order (x fastest),
