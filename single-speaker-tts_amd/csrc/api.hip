@@ -941,7 +941,11 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     // workgroups that really run side by side: the pipelined tts_synthesize keeps `reserve_cus` compute units
     // free of Griffin-Lim for its second stream
     const int held = (under_reservation && h->reserve_cus > 0) ? h->reserve_cus : 0;
-    gl_plan_stream(p, n_cus - held > 16 ? n_cus - held : n_cus);
+    // gl_pair = iterations per launch (1, 2 or 3; default in the handle); the run cut is made for that launch form
+    int per_launch = h->gl_pair;
+    per_launch = per_launch < 1 ? 1 : (per_launch > 3 ? 3 : per_launch);
+    while (per_launch > 1 && gl_stream_ring_frames(win, hop, per_launch) <= 0) --per_launch;
+    gl_plan_stream(p, n_cus - held > 16 ? n_cus - held : n_cus, per_launch);
     const int nchunks = p.slots_per_utt;
     WS(h, "gl.mse_partial", float, (size_t)B * nchunks, msep);
     // one zeroed work counter per launch (the persistent workgroups draw their item ids from it)
@@ -959,10 +963,6 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
         ProfScope ps(h, ST_GL_ITER, n_iter);
         // the streaming kernel runs two iterations per launch (gl_stream_kernel, NST = 2) wherever no per-iteration result
         // is asked for: all of them, or all but the last (the mse is the last iteration's)
-        // gl_pair = iterations per launch (1, 2 or 3; default in the handle)
-        int per_launch = h->gl_pair;
-        per_launch = per_launch < 1 ? 1 : (per_launch > 3 ? 3 : per_launch);
-        while (per_launch > 1 && gl_stream_ring_frames(win, hop, per_launch) <= 0) --per_launch;
         for (int it = 0; it < n_iter;) {
             const bool want_mse = mse && it == n_iter - 1;
             const int left = n_iter - (mse ? 1 : 0) - it;   // iterations that may share a launch
@@ -2069,7 +2069,9 @@ int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_worker
     p.ncol = (win_length + hop_length - 1) / hop_length;
     const int ring = gl_stream_ring_frames(win_length, hop_length);
     if (p.ncol > 8 || ring < 1) return TTS_ERR_UNSUPPORTED;
-    gl_plan_stream(p, n_workers);
+    int n_stage = 3;   // the handle's default launch form (option "gl_pair")
+    while (n_stage > 1 && gl_stream_ring_frames(win_length, hop_length, n_stage) <= 0) --n_stage;
+    gl_plan_stream(p, n_workers, n_stage);
     if (max_item_frames) *max_item_frames = ring;
     for (int k = 0; k < GL_MAX_CLASSES; ++k) {
         classes[2 * k] = p.cls_C[k];

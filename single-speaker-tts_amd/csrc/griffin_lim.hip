@@ -398,6 +398,7 @@ __device__ unsigned gl_clock_n;
 // span crosses the lap end (the final values of the wrapped part are at the ring's start, not in the guard) take an
 // index-mapped read path: 4 + (halo + ceil(S / hop)) / R of the frames.
 // MODE 1 writes out, straight from the overlap-add's registers, the hop samples that index i makes final.
+#define GL_NO_ITEM 0x7FFFFFFEu   // "not drawn yet" in the control word of the next item (item ids are < 2^31 - 2)
 enum { CT_OLA = 0, CT_SNEXT = 1, CT_OLB = 2 /* chain words of stages 1, 2 */, CT_SWORDS = 16 };
 
 // NST = 2: TWO iterations per launch.  The kernel draws a constant amount of power per instruction and per byte, and
@@ -718,8 +719,15 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         decode_item(item, b, run_t0, run_len, slot);
         const float* magb = p.mag + (size_t)b * p.T * p.FP;
         const unsigned* phb = x_in + (size_t)b * p.T * p.FP;
-        unsigned next_item_reg = 0;
-        if (tid == 0) next_item_reg = atomicAdd(p.work_counter, 1u);
+        // The next item is drawn LATE in a run (by the wave of index n_idx - 24, read by every wave in its last iteration):
+        // drawn at the start, a workgroup committed itself to a second run before it knew how long the first would take, and
+        // a cut with runs of two lengths (gl_plan_stream) paired long runs with short ones at random.  Runs too short for
+        // that (fewer than four rounds of the waves) still draw it at the start.
+        const int n_idx = run_len + NST * (halo + lag);
+        const bool late = n_idx >= 4 * GL_NW;
+        const int i_res = n_idx - 3 * GL_NW;
+        unsigned next_item_reg = GL_NO_ITEM;
+        if (tid == 0 && !late) next_item_reg = atomicAdd(p.work_counter, 1u);
         if (!have_row) GLS_LOAD_ROW(phb, magb, run_t0 - lead + wave)
         have_row = false;
         // run start: the guards read as zero for index 0, the chains start at 0
@@ -729,13 +737,12 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         }
         if (tid == 0) { ctrl[CT_OLA] = 0; ctrl[CT_OLB] = 0; ctrl[CT_OLB + 1] = 0; ctrl[CT_SNEXT] = (int)next_item_reg; }
         __syncthreads();
-        const int next_item = __builtin_amdgcn_readfirstlane(ctrl[CT_SNEXT]);
+        int next_item = __builtin_amdgcn_readfirstlane(ctrl[CT_SNEXT]);   // (late: GL_NO_ITEM until the wave's last iteration)
         int nb = b, nt0 = 0, nlen = 0, nslot = 0;
-        if (next_item < p.n_items) decode_item(next_item, nb, nt0, nlen, nslot);
+        if (!late && next_item < p.n_items) decode_item(next_item, nb, nt0, nlen, nslot);
 
         // the LAST stage (the only one of NST == 1) has the indices of one iteration, j <-> frame run_t0 - halo + j; every
         // stage before it runs halo + lag indices ahead of the next: stage 0 index i <-> frame run_t0 - NST halo + i
-        const int n_idx = run_len + NST * (halo + lag);
         const int y_base_a = (run_t0 - lead) * hop - MH + fs;   // trimmed-signal index of stage 0's ring coordinate 0 (lap 0)
         float mse_acc = 0.f;
         pk = 0.f;
@@ -744,6 +751,16 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         for (int i = wave; i < n_idx; i += GL_NW) {
             const int t = run_t0 - lead + i;
             const bool valid = t >= 0 && t < p.T;             // wave-uniform
+            unsigned drawn = 0;
+            if (late && i == i_res && lane == 0) drawn = atomicAdd(p.work_counter, 1u);   // (consumed before this index's overlap-add)
+            if (late && i + GL_NW >= n_idx) {
+                // this wave's last iteration: its previous one waited for the chain to pass index i - 8 > i_res, whose wave
+                // stored the item before it passed the chain on (LDS executes a wave's operations in order)
+                int nv;
+                while ((nv = gl_flag_load(ctrl + CT_SNEXT)) == (int)GL_NO_ITEM) __builtin_amdgcn_s_sleep(1);
+                next_item = __builtin_amdgcn_readfirstlane(nv);
+                if (next_item < p.n_items) decode_item(next_item, nb, nt0, nlen, nslot);
+            }
             GLS_STAMP()   // 0: iteration start
             GLS_URGENCY(i)
             cf v[16];
@@ -793,6 +810,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                 synth_window(t, v);
             }
             GLS_STAMP()   // 2: inverse FFT + window done
+            if (late && i == i_res && lane == 0) gl_flag_store(ctrl + CT_SNEXT, (int)drawn);
             overlap_add(ringA, CT_OLA, i, s, t, b, run_t0, run_len, v);
             GLS_STAMP()   // 3: overlap-add issued, flag passed on
             if (NST == 1) {
@@ -982,8 +1000,9 @@ size_t gl_stream_lds_bytes(const GlParams& p) {
 // Work items of the streaming form: every utterance is cut into nr runs of (almost) equal length, a multiple of the
 // eight waves; a run costs its frames plus the 2 halo indices that are only inverse-transformed plus a constant for
 // filling and draining the stream.  nr is chosen by simulating the list schedule on the workgroups that really run.
-void gl_plan_stream(GlParams& p, int n_workers) {
+void gl_plan_stream(GlParams& p, int n_workers, int n_stage) {
     const int halo = p.ncol - 1;
+    n_stage = n_stage < 1 ? 1 : (n_stage > 3 ? 3 : n_stage);
     // ONE cut for all launches of a call (single and double iterations alike: the overlap-add order, hence the waveform
     // bits, must not depend on which kernel form ran an iteration); ring_frames is set per launch (launch_gl_stream)
     p.ring_frames = gl_stream_ring_frames(p.win, p.hop, 1);
@@ -998,23 +1017,38 @@ void gl_plan_stream(GlParams& p, int n_workers) {
             forced = true;
         }
     }
+    if (const char* ov = getenv("SSTTS_GL_RUN_LEN")) {   // experiments: frames per (full) run
+        const int L = atoi(ov) / GL_NW * GL_NW;
+        if (L >= GL_NW) {
+            best = Cut{L, p.T / L, p.T - (p.T / L) * L};
+            forced = true;
+        }
+    }
     if (!forced) {
         static std::map<std::vector<int>, Cut> cache;
         static std::mutex cache_mutex;
         std::lock_guard<std::mutex> lock(cache_mutex);
-        const std::vector<int> key = {p.T, p.B, p.win, p.hop, n_workers};
+        const std::vector<int> key = {p.T, p.B, p.win, p.hop, n_workers, n_stage};
         auto it = cache.find(key);
         if (it != cache.end()) {
             best = it->second;
         } else {
             double best_t = 1e300;
             const double fill = 6.0;   // frames' worth of time to fill and drain the stream of a run
-            for (int nr = 1; nr <= p.T; ++nr) {
-                const int L = ((p.T + nr - 1) / nr + GL_NW - 1) / GL_NW * GL_NW;
-                if (nr > 1 && L == ((p.T + nr - 2) / (nr - 1) + GL_NW - 1) / GL_NW * GL_NW) continue;   // same cut as nr - 1
+            // What a run costs beyond its own frames: every stage of a launch starts halo + lag indices before the next
+            // one's first frame (gl_stream_kernel: n_idx = run_len + NST (halo + lag)) -- 27 indices per run at three
+            // iterations per launch, which is why the cut is made for the launch form the call will mostly use.
+            const int wpad = (TTS_GL_NFFT - p.win) >> 1;
+            const int lag = (halo + 1) * p.hop > 2 * (TTS_GL_NFFT / 2 - wpad) ? halo : halo + 1;
+            const double over = (double)n_stage * (halo + lag) + fill;
+            // Every run length that is a multiple of the eight waves is a candidate: n_full runs of L frames and one of the
+            // rest per utterance.  (Only the equal cuts ceil(T / n) used to be: at T = 1000, 64 utterances, 224 workgroups
+            // they give two runs of 144 / 136 frames per workgroup = 2 x (144 + 27) indices; three runs of 296 frames and
+            // one of 112 per utterance give 192 workgroups one long run and 32 workgroups two short ones: 296 + 27.)
+            for (int L = GL_NW; L < p.T + GL_NW; L += GL_NW) {
                 const int n_full = p.T / L, rem = p.T - n_full * L;
                 // list schedule, longest runs first: n_full * B items of cost cL, then B items of cost cR
-                const double cL = L + 2 * halo + fill, cR = rem > 0 ? rem + 2 * halo + fill : 0.0;   // (lag - halo <= 1: in `fill`)
+                const double cL = L + over, cR = rem > 0 ? rem + over : 0.0;
                 std::vector<double> heap((size_t)n_workers, 0.0);
                 auto cmp = [](double a, double b) { return a > b; };
                 auto deal = [&](long long items, double cost) {
@@ -1028,7 +1062,6 @@ void gl_plan_stream(GlParams& p, int n_workers) {
                 if (rem > 0) deal(p.B, cR);
                 const double t = *std::max_element(heap.begin(), heap.end());
                 if (t < best_t - 1e-9) { best_t = t; best = Cut{L, n_full, rem}; }
-                if (L <= GL_NW) break;
             }
             cache[key] = best;
         }
