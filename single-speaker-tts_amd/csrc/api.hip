@@ -76,8 +76,8 @@ struct tts_handle_s {
     unsigned call_count = 0;
     hipStream_t front = nullptr;     // the front stream of the current / last pipelined call: one of the two below
     hipStream_t front_hi = nullptr;  // greatest priority: ~2000 dependent launches of the launch-per-layer decoder beside Griffin-Lim
-    hipStream_t front_lo = nullptr;  // default priority: the persistent decoder holds its CUs by being resident, and an encoder
-                                     // that outranks the main stream only delays the final iSTFT / post-net it runs beside
+    hipStream_t front_lo = nullptr;  // the main stream's priority: the persistent decoder holds its CUs by being resident; its
+                                     // encoder and the main stream's final iSTFT / post-net share the chip as equals
     hipEvent_t ev_front_done = nullptr;
     hipEvent_t ev_post_done[2] = {nullptr, nullptr};   // post-net of the calls of even / odd parity
     bool post_pending[2] = {false, false};
@@ -1834,7 +1834,11 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
             int prio_least = 0, prio_greatest = 0;
             HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
             HIPCHK(h, hipStreamCreateWithPriority(&h->front_hi, hipStreamNonBlocking, prio_greatest));
-            HIPCHK(h, hipStreamCreateWithPriority(&h->front_lo, hipStreamNonBlocking, prio_least));
+            // (the main stream's own priority: between the range's ends.  With the lowest the encoder lost 0.1 ms per step to
+            // the main stream's GEMMs once Griffin-Lim's run cut had given the main stream slack; with the greatest it took
+            // 0.15 ms from the final iSTFT and the post-net before that -- equal priority is within 0.05 ms of the better one
+            // in both states)
+            HIPCHK(h, hipStreamCreateWithPriority(&h->front_lo, hipStreamNonBlocking, (prio_least + prio_greatest) / 2));
             h->front = h->front_hi;
             HIPCHK(h, hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, prio_greatest));
             HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->hold_flags), 2 * sizeof(int)));
