@@ -74,10 +74,13 @@ struct tts_handle_s {
     int* hold_flags = nullptr;      // two flag words, alternating per call
     hipEvent_t ev_aux = nullptr;
     unsigned call_count = 0;
-    hipStream_t front = nullptr;     // the front stream of the current / last pipelined call: one of the two below
-    hipStream_t front_hi = nullptr;  // greatest priority: ~2000 dependent launches of the launch-per-layer decoder beside Griffin-Lim
-    hipStream_t front_lo = nullptr;  // the main stream's priority: the persistent decoder holds its CUs by being resident; its
-                                     // encoder and the main stream's final iSTFT / post-net share the chip as equals
+    // The front stream (encoder, decoder, explicit initial phases of the NEXT call beside this call's post-net and Griffin-Lim):
+    // greatest priority.  Measured alternatives for the calls of the persistent decoder (which keeps its CUs by being
+    // resident): lowest priority was 0.15 ms per step better while the main stream was the longer one and 0.1 ms worse once
+    // Griffin-Lim's run cut had given it slack; the main stream's own priority is as good as the greatest in a device-resident
+    // loop but HALVES the throughput of tts_synthesize_host -- streams of one priority share a few hardware queues, and with
+    // the two copy streams of the host path the front stream lands on the main stream's queue.
+    hipStream_t front = nullptr;
     hipEvent_t ev_front_done = nullptr;
     hipEvent_t ev_post_done[2] = {nullptr, nullptr};   // post-net of the calls of even / odd parity
     bool post_pending[2] = {false, false};
@@ -565,8 +568,7 @@ int check_status(tts_handle_t h) {
 
 int sync_all(tts_handle_t h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (hipStream_t f : {h->front_hi, h->front_lo})
-        if (f && f != h->stream) HIPCHK(h, hipStreamSynchronize(f));
+    if (h->front && h->front != h->stream) HIPCHK(h, hipStreamSynchronize(h->front));
     if (h->aux) HIPCHK(h, hipStreamSynchronize(h->aux));
     if (h->hio.in) HIPCHK(h, hipStreamSynchronize(h->hio.in));
     if (h->hio.out) HIPCHK(h, hipStreamSynchronize(h->hio.out));
@@ -1139,11 +1141,10 @@ int tts_destroy(tts_handle_t h) {
     if (h->an.window) hipFree(h->an.window);
     if (h->an.mel_wt) hipFree(h->an.mel_wt);
     if (h->an.flag) hipFree(h->an.flag);
-    for (hipStream_t f : {h->front_hi, h->front_lo})
-        if (f) {
-            hipStreamSynchronize(f);
-            hipStreamDestroy(f);
-        }
+    if (h->front) {
+        hipStreamSynchronize(h->front);
+        hipStreamDestroy(h->front);
+    }
     if (h->aux) {
         hipStreamSynchronize(h->aux);
         hipStreamDestroy(h->aux);
@@ -1833,13 +1834,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         if (!h->front) {
             int prio_least = 0, prio_greatest = 0;
             HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-            HIPCHK(h, hipStreamCreateWithPriority(&h->front_hi, hipStreamNonBlocking, prio_greatest));
-            // (the main stream's own priority: between the range's ends.  With the lowest the encoder lost 0.1 ms per step to
-            // the main stream's GEMMs once Griffin-Lim's run cut had given the main stream slack; with the greatest it took
-            // 0.15 ms from the final iSTFT and the post-net before that -- equal priority is within 0.05 ms of the better one
-            // in both states)
-            HIPCHK(h, hipStreamCreateWithPriority(&h->front_lo, hipStreamNonBlocking, (prio_least + prio_greatest) / 2));
-            h->front = h->front_hi;
+            HIPCHK(h, hipStreamCreateWithPriority(&h->front, hipStreamNonBlocking, prio_greatest));
             HIPCHK(h, hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, prio_greatest));
             HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->hold_flags), 2 * sizeof(int)));
             HIPCHK(h, cu_hold_configure());
@@ -1852,8 +1847,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
             // calls made before these events existed recorded nothing: the front stream's first work starts behind
             // everything that is on the main stream now
             HIPCHK(h, hipEventRecord(h->ev_aux, h->stream));
-            HIPCHK(h, hipStreamWaitEvent(h->front_hi, h->ev_aux, 0));
-            HIPCHK(h, hipStreamWaitEvent(h->front_lo, h->ev_aux, 0));
+            HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_aux, 0));
         }
     }
     hipStream_t main_stream = h->stream;
@@ -1866,14 +1860,6 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         const bool pd_path = (h->persistent_decoder >= 2 || (h->persistent_decoder == 1 && B > 48)) && h->reserve_cus > 0 &&
                              decoder_persistent_supports(h->dec, c.force_cudnn, B, Ts) &&
                              decoder_persistent_workgroups(B) <= h->reserve_cus;
-        {   // the front stream of this call (see front_hi / front_lo); a change of stream is ordered behind the last call's front work
-            static const int force = getenv("SSTTS_FRONT_PRIO") ? atoi(getenv("SSTTS_FRONT_PRIO")) : -1;   // tools: 0 / 2 = always lo / hi
-            hipStream_t want = force == 0 ? h->front_lo : (force == 2 ? h->front_hi : (pd_path ? h->front_lo : h->front_hi));
-            if (want != h->front) {
-                if (h->front_pending) HIPCHK(h, hipStreamWaitEvent(want, h->ev_front_done, 0));
-                h->front = want;
-            }
-        }
         // the post-net of the call two back read the mel buffer this call's decoder writes; with a caller's
         // mel buffer (possibly the same one every call) the previous call's post-net has to finish as well
         if (h->post_pending[parity]) HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_post_done[parity], 0));
