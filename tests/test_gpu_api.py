@@ -302,3 +302,41 @@ def test_host_facade_two_calls_in_flight_equals_serial_calls(engine, hparams):
     sstts = pkg()
     with pytest.raises(sstts.TtsError):
         engine.wait_host(0)
+
+
+def test_host_facade_keeps_the_call_pipeline(engine, hparams):
+    """Throughput guard: through host memory (tts_synthesize_host / tts_wait_host, two calls in flight) a batch takes what it
+    takes in a device-resident loop -- the copy streams must not end up serialising the front and the main stream (they did
+    once: streams of one priority share a few hardware queues).  Bench shape, a few calls; the bound is loose (the failure
+    mode is a factor of two)."""
+    import time
+    Inf = pkg('tacotron.inference')
+    Tm = pkg('tacotron.model')
+    P = pkg('tacotron.params')
+    model = Tm.Tacotron(inputs=Tm.Tacotron.model_placeholders(), mode=Tm.Mode.PREDICT, engine=engine, hparams=hparams)
+    rng = np.random.default_rng(3)
+    B, Ts, S, n_iter, n = 64, 150, 200, 60, 8
+    ids = rng.integers(2, 39, (B, Ts)).astype(np.int32)
+    ids[:, -1] = 1
+    loader = P.dataset_params.dataset_loader
+    args = (S, loader.mel_mag_ref_db, loader.mel_mag_max_db, hparams.magnitude_power, n_iter, 1102, 275)
+    d_ids = engine.to_device(ids)
+    out = engine.synthesize(d_ids, *args, seed=1)
+    for k in range(3):
+        engine.synthesize(d_ids, *args, seed=2 + k, wav=out['wav'])
+    engine.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n):
+        engine.synthesize(d_ids, *args, seed=10 + k, wav=out['wav'])
+    engine.synchronize()
+    t_dev = (time.perf_counter() - t0) / n
+    for _ in Inf.synthesize_stream(model, (ids for _ in range(3)), n_steps=S, n_iter=n_iter, peak_normalize=True):
+        pass
+    engine.synchronize()
+    t0 = time.perf_counter()
+    for w in Inf.synthesize_stream(model, (ids for _ in range(n)), n_steps=S, n_iter=n_iter, peak_normalize=True):
+        assert np.isfinite(w[0, :100]).all()
+    engine.synchronize()
+    t_host = (time.perf_counter() - t0) / n
+    print('per batch: device-resident loop {:.2f} ms, through host memory {:.2f} ms'.format(1e3 * t_dev, 1e3 * t_host))
+    assert t_host < 1.35 * t_dev, (t_dev, t_host)
