@@ -1954,8 +1954,13 @@ int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, 
     const size_t ids_bytes = (size_t)B * Ts * sizeof(int32_t);
     const size_t n_wav = (size_t)B * sp->hop_length * (size_t)(T - 1);
     if (!io.in) {
-        HIPCHK(h, hipStreamCreateWithFlags(&io.in, hipStreamNonBlocking));
-        HIPCHK(h, hipStreamCreateWithFlags(&io.out, hipStreamNonBlocking));
+        // The copy streams get the LOWEST priority: streams of one priority share a few hardware queues in creation order
+        // (whatever else the process has created counts), and a copy stream that lands on the main stream's queue holds the
+        // main stream's kernels behind its event waits and its 70 MB download.  Nothing else in the library uses this level.
+        int prio_least = 0, prio_greatest = 0;
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        HIPCHK(h, hipStreamCreateWithPriority(&io.in, hipStreamNonBlocking, prio_least));
+        HIPCHK(h, hipStreamCreateWithPriority(&io.out, hipStreamNonBlocking, prio_least));
         for (int i = 0; i < 2; ++i) {
             HIPCHK(h, hipEventCreateWithFlags(&io.ev_h2d[i], hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&io.ev_enc[i], hipEventDisableTiming));

@@ -364,7 +364,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int slic
 
 // The slice count depends on the layer's K only -- never on the batch -- so that an utterance's result does
 // not depend on how many others share the batch (the summation order over k is part of the result).
-int gemm_splitk_slices(int K) { return K >= 4096 ? 4 : 1; }
+int gemm_splitk_slices(int K) { return K >= 4096 ? 8 : 1; }   // (8: 600 workgroups for the encoder projection at 64 x 150 tokens; 4 left a CU with 1.2)
 
 hipError_t launch_gemm_splitk(hipStream_t s, const GemmGroup& g, int slices, float* partial) {
     if (slices < 2 || slices > TTS_GEMM_MAX_GROUPS || g.epi != EPI_STD || g.C2) return hipErrorInvalidValue;

@@ -304,39 +304,22 @@ def test_host_facade_two_calls_in_flight_equals_serial_calls(engine, hparams):
         engine.wait_host(0)
 
 
-def test_host_facade_keeps_the_call_pipeline(engine, hparams):
+def test_host_facade_keeps_the_call_pipeline():
     """Throughput guard: through host memory (tts_synthesize_host / tts_wait_host, two calls in flight) a batch takes what it
     takes in a device-resident loop -- the copy streams must not end up serialising the front and the main stream (they did
-    once: streams of one priority share a few hardware queues).  Bench shape, a few calls; the bound is loose (the failure
-    mode is a factor of two)."""
-    import time
-    Inf = pkg('tacotron.inference')
-    Tm = pkg('tacotron.model')
-    P = pkg('tacotron.params')
-    model = Tm.Tacotron(inputs=Tm.Tacotron.model_placeholders(), mode=Tm.Mode.PREDICT, engine=engine, hparams=hparams)
-    rng = np.random.default_rng(3)
-    B, Ts, S, n_iter, n = 64, 150, 200, 60, 8
-    ids = rng.integers(2, 39, (B, Ts)).astype(np.int32)
-    ids[:, -1] = 1
-    loader = P.dataset_params.dataset_loader
-    args = (S, loader.mel_mag_ref_db, loader.mel_mag_max_db, hparams.magnitude_power, n_iter, 1102, 275)
-    d_ids = engine.to_device(ids)
-    out = engine.synthesize(d_ids, *args, seed=1)
-    for k in range(3):
-        engine.synthesize(d_ids, *args, seed=2 + k, wav=out['wav'])
-    engine.synchronize()
-    t0 = time.perf_counter()
-    for k in range(n):
-        engine.synthesize(d_ids, *args, seed=10 + k, wav=out['wav'])
-    engine.synchronize()
-    t_dev = (time.perf_counter() - t0) / n
-    for _ in Inf.synthesize_stream(model, (ids for _ in range(3)), n_steps=S, n_iter=n_iter, peak_normalize=True):
-        pass
-    engine.synchronize()
-    t0 = time.perf_counter()
-    for w in Inf.synthesize_stream(model, (ids for _ in range(n)), n_steps=S, n_iter=n_iter, peak_normalize=True):
-        assert np.isfinite(w[0, :100]).all()
-    engine.synchronize()
-    t_host = (time.perf_counter() - t0) / n
-    print('per batch: device-resident loop {:.2f} ms, through host memory {:.2f} ms'.format(1e3 * t_dev, 1e3 * t_host))
-    assert t_host < 1.35 * t_dev, (t_dev, t_host)
+    once: streams of one priority share a few hardware queues).  Bench shape, `bench.py --through-facade` in a process of
+    its own: a process that has imported torch runs the library on torch's bundled HIP runtime, where the same loop is
+    about 50 % slower through host memory, and pytest's collection imports torch.  The bound is loose
+    (the failure mode is a factor of two)."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '8', '--warmup', '3', '--through-facade',
+                          '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    rec = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1])
+    t_dev, t_host = rec['ms_per_step'], rec['facade_ms_per_step']
+    print('per batch: device-resident loop {:.2f} ms, through host memory {:.2f} ms'.format(t_dev, t_host))
+    assert t_host < 1.3 * t_dev, (t_dev, t_host)
