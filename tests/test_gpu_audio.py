@@ -172,3 +172,31 @@ def test_griffin_lim_seeded_start(engine, per_launch, n_iter, want_mse, seed):
         assert rel_l2(w_seed[b], ref_wav) < 1e-4 * max(1, n_iter)
         if want_mse:
             assert abs(m_seed.to_host()[b] - ref_mse) <= 1e-3 * abs(ref_mse) + 1e-9
+
+
+@pytest.mark.parametrize('run_len', [8, 16, 40, 104, 296])
+@pytest.mark.parametrize('per_launch,n_iter,want_mse', [(1, 2, True), (3, 4, False)])
+def test_griffin_lim_forced_run_cuts(engine, run_len, per_launch, n_iter, want_mse):
+    """Every cut of the utterances into runs gives the same waveform (to rounding: the overlap-add order at the run borders
+    is part of the sums): forced run lengths from one round of the waves to longer than the utterance -- many runs per
+    workgroup, runs too short to draw the next item late (fewer than four rounds: drawn at the start) next to runs that draw
+    it 24 indices before their end, remainders of one class."""
+    import os
+    B, T = 5, 151
+    rng = np.random.default_rng(run_len)
+    mag = synth_mag(rng, B, T)
+    init = rng.random(mag.shape).astype(np.float32)
+    engine.set_option('gl_pair', per_launch)
+    os.environ['SSTTS_GL_RUN_LEN'] = str(run_len)
+    try:
+        wav, mse = engine.griffin_lim(mag, n_iter, WIN, HOP, N_FFT, init_phase=init, want_mse=want_mse)
+        wav = wav.to_host()
+        mse = mse.to_host() if want_mse else None
+    finally:
+        del os.environ['SSTTS_GL_RUN_LEN']
+        engine.set_option('gl_pair', 3)
+    for b in range(B):
+        ref_wav, ref_mse = A.griffin_lim_v2(mag[b], WIN, HOP, N_FFT, n_iter, init_phase=init[b])
+        assert rel_l2(wav[b], ref_wav) < 1e-4 * n_iter
+        if want_mse:
+            assert abs(mse[b] - ref_mse) <= 1e-3 * abs(ref_mse) + 1e-9
