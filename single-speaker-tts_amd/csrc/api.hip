@@ -102,6 +102,7 @@ struct tts_handle_s {
     int gl_pair = 3;                 // Griffin-Lim iterations per launch (1..3) where nothing per-iteration is asked for
     int n_cus_dev = 0;
     bool pd_configured = false;
+    int pd_debug_delay = 0;   // tests only (tts_set_option "pd_debug_delay"): PdParams::dbg_delay
     bool pd_used = false;            // a persistent launch has been enqueued since the last status check
     unsigned* pd_sync = nullptr;     // counters + status word of the last persistent launch
     int pd_clusters = 0;
@@ -1209,7 +1210,7 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     else if (!std::strcmp(key, "fused_tail")) h->fused_tail = value;
     else if (!std::strcmp(key, "persistent_decoder")) h->persistent_decoder = value;
     else if (!std::strcmp(key, "gl_pair")) h->gl_pair = value;
-    else if (!std::strcmp(key, "pd_debug_delay")) pd_debug_delay = value;   // tests only (decoder_persistent.hip)
+    else if (!std::strcmp(key, "pd_debug_delay")) h->pd_debug_delay = value;   // tests only (decoder_persistent.hip), per handle
     else if (!std::strcmp(key, "reserve_cus")) {
         h->reserve_cus = value;
     } else if (!std::strcmp(key, "hold_lds_kb")) {
@@ -1549,8 +1550,9 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
         WS(h, "dec.pd_sync", unsigned, (size_t)64 * clusters + 2, pd_sync);
         if (pd_sync != h->pd_sync || clusters != h->pd_clusters)   // new buffer / new layout: the sticky status word starts clean
             HIPCHK(h, hipMemsetAsync(pd_sync + 64 * clusters + 1, 0, sizeof(unsigned), h->stream));
+        WS(h, "dec.pd_arena", unsigned char, decoder_persistent_arena_bytes(B), pd_arena);
         HIPCHK(h, decoder_persistent_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, alignments, pd_sync,
-                                             h->cur_hold_flag, c.force_cudnn));
+                                             h->cur_hold_flag, c.force_cudnn, pd_arena, h->pd_debug_delay));
         h->pd_sync = pd_sync;
         h->pd_clusters = clusters;
         h->pd_used = true;
