@@ -7,11 +7,21 @@
 //   max_pooling1d  :518-521  (fused into the A loader of the first projection: pool=1)
 //   highway        :241-258  (H|T share one GEMM; gate mix in the epilogue)
 //
-// Tile 128x128x32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x2_f32
-// accumulators.  Operands are staged global -> registers -> LDS ([row][32+4] floats, b128
-// conflict-free) with the next tile's global loads in flight during the MFMAs.
-// The k index inside a tile is permuted (lane half h of MFMA step (q,j) uses k = 8q+4h+j) so
-// that each lane fetches its 4 consecutive k values with one ds_read_b128 for both operands.
+// Tile 128x128x32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 blocks of 32x32 accumulators (f32).
+// Operands are staged global -> registers -> LDS with the next tile's global loads in flight during the MFMAs.
+//
+// Round 4: the products run on the bf16 matrix pipe at f32 accuracy.  Every f32 operand is split EXACTLY into three
+// bf16 terms where it is staged (x = hi + mid + lo: truncate to the top 16 bits, subtract, twice; 8 + 8 + 8 significand
+// bits, the subtractions are exact), and a 16-deep step of a block is six v_mfma_f32_32x32x16_bf16 into the same f32
+// accumulator: hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi.  The three products left out (mid*lo, lo*mid, lo*lo) are
+// below 2^-23 of |a||b|: the size of one f32 rounding, measured against the float64 oracle in tests/test_gpu_gemm.py
+// (same error as the v_mfma_f32_32x32x2_f32 form, which -DGEMM_F32_MFMA still builds for A/B runs).  Six bf16 MFMAs of
+// 8 passes replace eight f32 MFMAs of 16 passes per 16 k: 2.67x less matrix-pipe time; the splits are ~5.5 VALU
+// instructions per element on the otherwise idle vector pipe.  LDS image per operand: [split][row][4 chunks of 8 bf16]
+// with the chunk index XOR-swizzled by (row >> 2) & 3 (ds_read_b128 of 16 rows at one chunk hit 16 different bank
+// quads without padding: 48 KB per workgroup, three workgroups per CU).
+// (f32 MFMA form: [row][32+4] floats, b128 conflict-free; the k index inside a tile permuted -- lane half h of MFMA
+// step (q,j) uses k = 8q+4h+j -- so that each lane fetches its 4 consecutive k values with one ds_read_b128.)
 #include "tts_common.h"
 #include <cstring>
 #include <type_traits>
@@ -28,6 +38,31 @@ namespace tts {
 #define BN 128
 #define BK 32
 #define LDS_LD (BK + 4)
+#ifndef GEMM_F32_MFMA
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// x = hi + mid + lo exactly, each a bf16 (the top 16 bits of an f32): bits of x, of x - hi, of x - hi - mid
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(h & 0xFFFF0000u);
+    m = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(m & 0xFFFF0000u);
+    l = __float_as_uint(r2);
+}
+// the top halves of two words as one: (hi16(b) << 16) | hi16(a)
+__device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+// four consecutive k of one row -> 8 bytes per split at (split, row, k): byte offset inside an operand's image
+__device__ __forceinline__ void store_split4(unsigned char* img, int row, int kq, float4 v) {
+    unsigned h[4], m[4], l[4];
+    split3(v.x, h[0], m[0], l[0]);
+    split3(v.y, h[1], m[1], l[1]);
+    split3(v.z, h[2], m[2], l[2]);
+    split3(v.w, h[3], m[3], l[3]);
+    const int off = (row * 4 + ((kq >> 1) ^ ((row >> 2) & 3))) * 16 + (kq & 1) * 8;
+    *reinterpret_cast<uint2*>(img + off) = make_uint2(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]));
+    *reinterpret_cast<uint2*>(img + BM * 64 + off) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
+    *reinterpret_cast<uint2*>(img + 2 * BM * 64 + off) = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
+}
+#endif
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 max4(float4 a, float4 b) {
@@ -54,8 +89,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR))
     const int n0 = (seq % nyb) * BN;
     if (n0 >= N || m0 >= M) return;
 
+#ifdef GEMM_F32_MFMA
     __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+#else
+    __shared__ __attribute__((aligned(16))) unsigned char As[3 * BM * 64];   // [split][row][32 bf16], chunks swizzled
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * BN * 64];
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -190,8 +230,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR))
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (tid >> 3) + 32 * i;
+#ifdef GEMM_F32_MFMA
             *reinterpret_cast<float4*>(&As[row * LDS_LD + 4 * kq]) = ra[i];
             *reinterpret_cast<float4*>(&Bs[row * LDS_LD + 4 * kq]) = rb[i];
+#else
+            store_split4(As, row, kq, ra[i]);
+            store_split4(Bs, row, kq, rb[i]);
+#endif
         }
     };
 
@@ -223,6 +268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR))
         store_tile();
         __syncthreads();
         if (kt + BK < k_end) load_tile(kt + BK);
+#ifdef GEMM_F32_MFMA
         // Two register sets for the LDS fragments: the ds_read_b128 of MFMA step q + 1 are requested before the 16 MFMAs
         // of step q are issued, so a step never starts by waiting for LDS (hipcc leaves part of that latency exposed
         // when the steps are written as one loop: 105 -> 119 TFLOP/s on the 64000 x 256 x 3072 shape in
@@ -257,6 +303,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR))
             mma(a0, b0);
             mma(a1, b1);
         }
+#else
+        // Two 16-deep steps per tile.  Lane (li, lh) of a 32-row block holds k = 16 q + 8 lh .. + 7 of row li: chunk
+        // 2 q + lh of the row, one ds_read_b128 per split.  The A fragments of both row blocks stay for the step, the B
+        // fragments of one column block at a time (36 fragment registers).
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ch = 2 * q + lh;
+            uint4 fa[2][3];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const int row = wm * 64 + tm * 32 + li;
+                const int off = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) fa[tm][sp] = *reinterpret_cast<const uint4*>(As + sp * BM * 64 + off);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int row = wn * 64 + tn * 32 + li;
+                const int off = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
+                uint4 fb[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) fb[sp] = *reinterpret_cast<const uint4*>(Bs + sp * BN * 64 + off);
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    if (EDGE && !blk_live[tm][tn]) continue;   // wave-uniform
+#define GEMM_MMA(SA, SB)                                                                                              \
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[tm][SA]),    \
+                                                                          __builtin_bit_cast(bf16x8_t, fb[SB]), acc[tm][tn], 0, 0, 0);
+                    GEMM_MMA(0, 2) GEMM_MMA(2, 0) GEMM_MMA(1, 1) GEMM_MMA(0, 1) GEMM_MMA(1, 0) GEMM_MMA(0, 0)
+#undef GEMM_MMA
+                }
+            }
+        }
+#endif
         __syncthreads();
     }
     };
