@@ -34,6 +34,9 @@ namespace tts {
 #ifndef GEMM_NUM_VGPR
 #define GEMM_NUM_VGPR 80
 #endif
+#ifndef GEMM_NUM_VGPR_POOL
+#define GEMM_NUM_VGPR_POOL 128
+#endif
 #define BM 128
 #define BN 128
 #define BK 32
@@ -74,7 +77,7 @@ __device__ __forceinline__ float4 max4(float4 a, float4 b) {
 // POOL: instantiation whose A loader takes max(x[t], x[t+1]) (the two k = 3 projections that follow a max-pool): kept
 // apart so that every other GEMM carries neither its second load nor its registers.
 template <bool DENORM, bool POOL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR))) void gemm_f32_kernel(GemmBatch batch) {
+__device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
     const GemmGroup& g = batch.g[blockIdx.z];
     const int M = g.M, N = g.N, K = g.K;
     // Workgroup -> tile map.  Workgroups are dealt round-robin over the 8 XCDs in launch order (x fastest),
@@ -123,7 +126,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR))
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (tid >> 3) + 32 * i;
-        const int m = m0 + row;
+        // POOL: a thread stages four CONSECUTIVE rows, so that row i + 1 of the max-pool is a value it has loaded anyway
+        // (five loads per tile instead of eight)
+        const int m = m0 + (POOL ? 4 * (tid >> 3) + i : row);
         a_ok[i] = m < M;
         const int mm = a_ok[i] ? m : 0;
         a_t[i] = mm % g.T;
@@ -143,6 +148,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR))
     }
 
     float4 ra[4], rb[4];
+    float4 ra4 = make_float4(0.f, 0.f, 0.f, 0.f);   // POOL: the raw row behind this thread's four
+    unsigned pool_own = 0, pool_nxt = 0;            // POOL (fast path): validity bits of the loaded tile's tap, per row
+    bool pool_raw = false;                          // POOL: ra holds raw rows (fast path), to be pooled when stored
     // k order of a convolution whose channel count is a multiple of the tile depth: channel chunk outer, tap
     // inner, so that the k+1 shifted copies of one activation chunk are loaded in consecutive tiles (they hit
     // in L1 / L2) instead of Cin/BK tiles apart.  The weight tile follows the same map.
@@ -191,14 +199,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR))
             const int tap = per_thread ? my_tap : cur_tap;
             const int kk = per_thread ? my_tap * g.Cin + my_ch : cur_kb + 4 * kq;
             const bool kin = kk < K;
+            if (POOL) {
+                // rows r .. r + 4 of this thread, each loaded once: row j is wanted as itself (own_j: its tap lies inside
+                // the sequence) or as the successor of row j - 1 (nxt_{j-1}); at a sequence boundary the two differ, hence
+                // the selects: pooled_i = nxt_i ? max(x_i, x_{i+1}) : x_i with x_i = own_i ? raw_i : 0
+                bool own[4], nxt[4];
+                pool_raw = true;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    own[i] = kin && ((tapmask[i] >> tap) & 1u);
+                    nxt[i] = kin && ((tapmask[i] >> (16 + tap)) & 1u);
+                }
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    // (a row wanted only as a successor is addressed from its predecessor: past the last row of the
+                    // tensor this thread's own offset for it is not a row's)
+                    const bool mine = j < 4 && own[j < 4 ? j : 3];
+                    const bool succ = j > 0 && nxt[j > 0 ? j - 1 : 0];
+                    const int base = mine ? a_off[j < 4 ? j : 3] : a_off[j > 0 ? j - 1 : 0] + g.lda;
+                    const float4 v = buf4(a_rs, (mine || succ) ? (unsigned)(base + kk) * 4u : 0xFFFFFFFFu);
+                    if (j < 4) ra[j] = v;
+                    else ra4 = v;
+                }
+                // the values are only combined when the tile is stored (store_tile): touched here, the loads would have to
+                // land before the MFMAs of the tile in front of them are even issued
+                pool_own = (own[0] ? 1u : 0u) | (own[1] ? 2u : 0u) | (own[2] ? 4u : 0u) | (own[3] ? 8u : 0u);
+                pool_nxt = (nxt[0] ? 1u : 0u) | (nxt[1] ? 2u : 0u) | (nxt[2] ? 4u : 0u) | (nxt[3] ? 8u : 0u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    rb[i] = buf4(b_rs, (b_ok[i] && kin) ? (unsigned)(b_off[i] + kk) * 4u : 0xFFFFFFFFu);
+            } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool ok = kin && ((tapmask[i] >> tap) & 1u);
                 const unsigned off = ok ? (unsigned)(a_off[i] + kk) * 4u : 0xFFFFFFFFu;
-                float4 v = buf4(a_rs, off);
-                if (POOL) v = max4(v, buf4(a_rs, (kin && ((tapmask[i] >> (16 + tap)) & 1u)) ? off + (unsigned)g.lda * 4u : off));
-                ra[i] = v;
+                ra[i] = buf4(a_rs, off);
                 rb[i] = buf4(b_rs, (b_ok[i] && kin) ? (unsigned)(b_off[i] + kk) * 4u : 0xFFFFFFFFu);
+            }
             }
             // advance to the next tile
             if (tap_inner) {          // tap inner, channel chunk outer
@@ -227,14 +264,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR))
         }
     };
     auto store_tile = [&]() {
+        if (POOL && pool_raw) {   // pooled_i = nxt_i ? max(x_i, x_{i+1}) : x_i with x_i = own_i ? raw_i : 0 (x_{i+1}: the raw value)
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 x = ((pool_own >> i) & 1u) ? ra[i] : z;
+                const float4 nx = i < 3 ? ra[i < 3 ? i + 1 : 3] : ra4;
+                ra[i] = ((pool_nxt >> i) & 1u) ? max4(x, nx) : x;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (tid >> 3) + 32 * i;
+            const int arow = POOL ? 4 * (tid >> 3) + i : row;
 #ifdef GEMM_F32_MFMA
-            *reinterpret_cast<float4*>(&As[row * LDS_LD + 4 * kq]) = ra[i];
+            *reinterpret_cast<float4*>(&As[arow * LDS_LD + 4 * kq]) = ra[i];
             *reinterpret_cast<float4*>(&Bs[row * LDS_LD + 4 * kq]) = rb[i];
 #else
-            store_split4(As, row, kq, ra[i]);
+            store_split4(As, arow, kq, ra[i]);
             store_split4(Bs, row, kq, rb[i]);
 #endif
         }
@@ -405,6 +452,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR))
     }
 }
 
+template <bool DENORM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR))) void gemm_f32_kernel(GemmBatch batch) {
+    gemm_body<DENORM, false>(batch);
+}
+// the max-pool loader keeps a fifth raw row and the validity bits of the tile in flight: a register budget of its own
+// (two waves per SIMD) instead of spilling inside the k loop -- scratch accesses queue behind the tile's global loads
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR_POOL))) void gemm_f32_pool_kernel(GemmBatch batch) {
+    gemm_body<false, true>(batch);
+}
+
 hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups) {
     int max_n = 0;
     for (int i = 0; i < n_groups; ++i) {
@@ -422,9 +479,9 @@ hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups) {
     for (int i = 0; i < n_groups; ++i) pool = pool || b.g[i].pool != 0;
     for (int i = 0; i < n_groups; ++i)
         if (pool && (!b.g[i].pool || b.g[i].C2)) return hipErrorInvalidValue;   // a pooled launch is homogeneous, never de-normalising
-    if (pool) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, b);
-    else if (denorm) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, b);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, b);
+    if (pool) hipLaunchKernelGGL(gemm_f32_pool_kernel, grid, dim3(256), 0, s, b);
+    else if (denorm) hipLaunchKernelGGL((gemm_f32_kernel<true>), grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false>), grid, dim3(256), 0, s, b);
     return hipGetLastError();
 }
 
