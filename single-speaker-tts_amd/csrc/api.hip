@@ -1550,9 +1550,8 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
         WS(h, "dec.pd_sync", unsigned, (size_t)64 * clusters + 2, pd_sync);
         if (pd_sync != h->pd_sync || clusters != h->pd_clusters)   // new buffer / new layout: the sticky status word starts clean
             HIPCHK(h, hipMemsetAsync(pd_sync + 64 * clusters + 1, 0, sizeof(unsigned), h->stream));
-        WS(h, "dec.pd_arena", unsigned char, decoder_persistent_arena_bytes(B), pd_arena);
         HIPCHK(h, decoder_persistent_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, alignments, pd_sync,
-                                             h->cur_hold_flag, c.force_cudnn, pd_arena, h->pd_debug_delay));
+                                             h->cur_hold_flag, c.force_cudnn, h->pd_debug_delay));
         h->pd_sync = pd_sync;
         h->pd_clusters = clusters;
         h->pd_used = true;

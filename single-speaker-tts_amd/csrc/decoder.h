@@ -82,11 +82,11 @@ struct PdParams {
     const float* al_w;                            // attention layer
     const float *g_gw[2], *g_gb[2], *g_cw[2], *g_cb[2];
     const float *memory, *keys;                   // [B][Ts][256]
-    void* gran;                                   // granule arena: every hand-off buffer and recurrent state as 8-byte {value, tag}
-                                                  // pairs (decoder_persistent.hip: PdBuf), zeroed per call
-    float* yhist;                                 // [B][n_steps][256] top-layer outputs as plain floats (output projection)
-    int dbg_delay;                                // tests only: workgroup 3 of every cluster sleeps this long before it sweeps
+    float *att, *p1, *p2, *rh, *ctx, *y0, *yhist;   // hand-off buffers [B][.] (state zeroed per call)
+    float *h_att2[2], *h_dec2[2][2];              // recurrent states, double-buffered by step parity (zeroed per call)
+    int dbg_delay;                                // tests only: workgroup 3 of every cluster sleeps this long before it stages
     float* align;                                 // [n_steps][B][Ts] or null
+    unsigned* counters;                           // [clusters][64]: one arrival counter per cluster, zeroed per call
     unsigned* resident;                           // workgroups that have started
     int* status;                                  // set to 1 when a wait timed out (results are then invalid)
     int* hold_flag;                               // optional: raised once every workgroup is resident (reserve.hip sleepers)
@@ -100,11 +100,10 @@ struct PdParams {
 bool decoder_persistent_supports(const DecoderWeights& w, int cudnn, int B, int Ts);
 int decoder_persistent_workgroups(int B);         // compute units the launch needs all to itself
 hipError_t decoder_persistent_configure();        // per device
-size_t decoder_persistent_arena_bytes(int B);     // the granule arena of a call with B utterances
-// `sync`: 64 * ceil(B / 16) + 2 unsigned words; `arena`: decoder_persistent_arena_bytes(B) bytes (zeroed by the call);
-// `dbg_delay`: tests only (tts_set_option "pd_debug_delay", per handle), see PdParams::dbg_delay
+// `sync`: 64 * ceil(B / 16) + 2 unsigned words; `dbg_delay`: tests only (tts_set_option "pd_debug_delay", per handle),
+// see PdParams::dbg_delay
 hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, const DecoderScratch& sc, const float* memory,
                                       const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync,
-                                      int* hold_flag, int cudnn, void* arena, int dbg_delay);
+                                      int* hold_flag, int cudnn, int dbg_delay);
 
 }  // namespace tts

@@ -9,20 +9,22 @@
 //     and the cell state of its units never leave its LDS), K split over the waves, v_mfma_f32_16x16x4_f32;
 //   * the weights of the NEXT phase are fetched from L2 into registers BEFORE the workgroup waits for its peers
 //     (they do not depend on data);
-//   * activations travel between the workgroups of a cluster through small global buffers of 8-byte GRANULES
-//     {value, tag} (cdna_hip_programming.md Guideline 16, form R2: the data is the flag).  tag = 1 + 16 step + phase
-//     of the phase that produced the value; a producer's epilogue stores its granules write-through (16-byte sc1
-//     stores of two granules, each 8-byte half whole) and goes on -- no drain, no barrier, no counter; a consumer
-//     sweeps its part of the cluster's A tile with 16-byte sc1 loads (every wave, four loads per lane in flight
-//     together) and repeats the loads whose tags are not yet the expected ones.  One fabric round trip per phase
-//     when the data is there, instead of three dependent ones (counter poll, then the staging loads, behind the
-//     producers' store drain and counter add): round 4, 7.5 -> ~5 us per phase.  The granule arena is zeroed per
-//     call, which is also the zero_state of the recurrent cells (value 0, tag 0 = "before step 0").  No cache-wide
-//     release or acquire anywhere, no grid-wide barrier: clusters never talk to each other;
+//   * activations travel between the workgroups of a cluster through small global buffers with the write-through
+//     hand-off of MI355X_MICROARCH.md ("valid forms"): every byte stored sc1, every storing wave waits vmcnt(0),
+//     a workgroup barrier, ONE lane adds to the cluster's counter (agent scope); consumers poll that counter with
+//     an sc1 load in one lane, then a workgroup barrier, then sc1 loads of the bytes.  No cache-wide release or
+//     acquire anywhere, no grid-wide barrier: clusters never talk to each other;
+//   (Round 4 measured the alternative hand-off of cdna_hip_programming.md Guideline 16 R2 -- every value an 8-byte
+//   {value, tag} granule, the consumers sweeping the tile until the tags match, no counter and no drained stores --
+//   on one box against this form: 15.48 against 14.86 ms alone, 16.1 against 15.5 ms beside Griffin-Lim.  A phase is bound
+//   by the bytes its compute unit moves (128 KB of weights, the staged tile, the attention rows), not by the round trips
+//   of the protocol, and the granules double the tile's bytes.  Requesting the next phase's weights a phase ahead did not
+//   pay either: at 128 registers it spills, and scratch accesses queue behind the weight loads; with 512-thread
+//   workgroups and 256 registers the dependent MFMA chain of a wave doubles: 18.3 ms.  git history has both.)
 //   * attention: workgroup j scores, normalises and contracts two of the cluster's 16 rows itself, so softmax
 //     needs no cross-workgroup merge and the alignments are written normalised.
-// Every sweep is bounded (PD_SPIN_LIMIT passes); on a timeout the status word is set, every workgroup of the grid
-// sees it in its next sweep and the kernel drains.  All workgroups must be co-resident: the host only uses this
+// Every wait is bounded (PD_SPIN_LIMIT polls); on a timeout the status word is set, every workgroup of the grid
+// sees it at its next wait and the kernel drains.  All workgroups must be co-resident: the host only uses this
 // path when 8 * ceil(B / 16) compute units are free for it (api.hip).
 #include "tts_common.h"
 #include "decoder.h"
@@ -61,15 +63,6 @@ __device__ __forceinline__ float4 pd_ld4(const __amdgpu_buffer_rsrc_t& rs, unsig
 __device__ __forceinline__ void pd_st4(const __amdgpu_buffer_rsrc_t& rs, unsigned byte_off, float4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pd_u32x4, v), rs, (int)byte_off, 0, 16);
 }
-// Four consecutive values of one row as four granules {value, tag}: two 16-byte write-through stores, each 8-byte half
-// (one granule) whole.  `g`: index of the first granule in the arena.
-__device__ __forceinline__ void pd_st_gran4(const __amdgpu_buffer_rsrc_t& rs, unsigned g, float4 v, unsigned tag) {
-    const float tg = __uint_as_float(tag);
-    pd_st4(rs, g * 8u, make_float4(v.x, tg, v.y, tg));
-    pd_st4(rs, g * 8u + 16u, make_float4(v.z, tg, v.w, tg));
-}
-// tag of what phase k of step t produces (never 0: a zeroed arena reads as "before step 0")
-__device__ __forceinline__ unsigned pd_tag(int t, int k) { return t < 0 ? 0u : 1u + 16u * (unsigned)t + (unsigned)k; }
 
 // PD_GATES + PD_CAND: TF GRUCell (candidate on [x ; r*h], two hops per cell).  PD_CUDNN_RU + PD_CUDNN_HX:
 // CudnnCompatibleGRUCell (reference layers.py:560-577, model.py:226-227,257-259): c = tanh(x Wci + bci + r*(h Wch + bch));
@@ -88,31 +81,20 @@ __device__ __shared__ float* pd_tl_lds;
 #define PD_STAMP(I)
 #endif
 
-// Granule arena (decoder.h: pd_granules): per-row widths of the hand-off buffers, in granules
-enum PdBuf { PB_ATT = 0, PB_P1, PB_P2, PB_RH, PB_CTX, PB_Y0, PB_YG, PB_HATT0, PB_HATT1, PB_HD00, PB_HD01, PB_HD10, PB_HD11, PB_COUNT };
-__host__ __device__ inline int pd_buf_width(int b) { return b == PB_P2 ? PD_P2 : PD_D; }
-__host__ __device__ inline unsigned pd_buf_off(int b, int B) {   // first granule of buffer b
-    unsigned o = 0;
-    for (int i = 0; i < b; ++i) o += (unsigned)B * (unsigned)pd_buf_width(i);
-    return o;
-}
-size_t pd_granules(int B) { return (size_t)pd_buf_off(PB_COUNT, B); }
-
 struct PdPhase {
-    int a0; int lda0; int k0; unsigned tag0;   // A columns [0, k0): granules from a0 (-1 = zeros), row stride lda0, expected tag
-    int a1; int lda1; unsigned tag1;           // A columns [k0, K)
+    const float* a0; int lda0; int k0;   // A columns [0, k0): a0 (null = zeros), row stride lda0
+    const float* a1; int lda1;           // A columns [k0, K)
     int K;
     const float* Wt;                     // [N][K]
     const float* bias;                   // [N] or null
     int row0;                            // first of the (one or two) 256-row weight blocks this phase uses
-    int cont;                            // continues on the A tile the previous phase staged: no sweep, no staging
-    int more;                            // a `cont` phase follows: nothing handed over yet
+    int cont;                            // continues on the A tile the previous phase staged: no wait, no staging
+    int more;                            // a `cont` phase follows: nothing to publish yet
     int ub;                              // units of this layer owned per workgroup (32 or 16)
     int epi, act, layer;
-    int delay;                           // tests only: workgroup 3 sleeps delay x ~3.4 us before it sweeps
-    int out; int ldo; unsigned otag;     // PD_ACT: activations; PD_GATES: r*h; PD_CAND: new state h (granules)
-    int yout; int ldy;                   // PD_CAND with residual: y = x + h' (granules; -1 = none)
-    float* yplain; int ldyp;             // ... and as plain floats (the y history that the output projection reads)
+    int delay;                           // tests only: workgroup 3 sleeps delay x ~3.4 us between the wait and the staging
+    float* out; int ldo;                 // PD_ACT: activations; PD_GATES: r*h; PD_CAND: new state h
+    float* yout; int ldy;                // PD_CAND with residual: y = x + h'
 };
 
 // LDS map (floats)
@@ -129,25 +111,38 @@ size_t pd_lds_bytes(int Ts) { return ((size_t)PD_OFF_SC + 2 * (size_t)((Ts + 3) 
 size_t pd_lds_bytes(int Ts) { return ((size_t)PD_OFF_SC + 2 * (size_t)((Ts + 3) & ~3)) * sizeof(float); }
 #endif
 
-typedef __attribute__((address_space(3))) int pd_lds_int;
-// One more pass of a sweep is needed: back off, and every 256 passes look at the clock and at the other workgroups.
-// Returns true when the sweep must give up (the status word is then set and this workgroup stops waiting for good).
-__device__ __forceinline__ bool pd_spin_fail(unsigned& spins, int* status, int* ctrl) {
-    __builtin_amdgcn_s_sleep(1);
-    if ((++spins & 255u) == 0 &&
-        (spins > PD_SPIN_LIMIT || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store((pd_lds_int*)ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // drain: no further waits
-        return true;
+// Start of a phase: signal that this workgroup's stores of the PREVIOUS phase are complete (pd_publish ran), then
+// wait until `target` arrivals have been counted on the cluster's counter.  Lane 0 of the workgroup does both; the
+// arrival is issued here, after the caller has put its weight loads in flight, because the lane that adds also
+// waits for the add's round trip before its next memory access returns.
+__device__ __forceinline__ void pd_wait(unsigned* cnt, unsigned target, int* status, int* ctrl) {
+    if (threadIdx.x == 0 && target > 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ctrl[0] == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 1023u) == 0 &&
+                    (spins > PD_SPIN_LIMIT || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ctrl[0] = 1;   // drain: no further waits in this workgroup
+                    break;
+                }
+            }
+        }
     }
-    return false;
+    __syncthreads();
 }
-__device__ __forceinline__ bool pd_draining(int* ctrl) {
-    return __hip_atomic_load((pd_lds_int*)ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+
+// End of a phase: every storing wave waits for its (write-through) stores, then the workgroup barrier -- after it
+// one lane may signal for all of them (pd_wait of the next phase).
+__device__ __forceinline__ void pd_publish() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 }
 
 // One GEMM-shaped phase of the cluster: out[16 rows][this workgroup's units] = epi([a0 | a1] . Wt^T + bias).
-__device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, const __amdgpu_buffer_rsrc_t& rs, int j, int b0, int B,
+__device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, int j, int b0, int B, unsigned* cnt, unsigned target,
                                          int* status) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -166,71 +161,57 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, const __
     const int gate = tile / tpg, within = tile - gate * tpg;
     const int nch = ph.K >> 4;
 
-    // ---- this wave's weight fragments: independent of every other workgroup, so they are in flight during the sweep
+    // ---- this wave's weight fragments: independent of every other workgroup, so they are in flight during the wait
     const int n = ph.row0 + gate * PD_D + j * ph.ub + 16 * within + r;
     const float* wrow = ph.Wt + (size_t)n * ph.K + 4 * q;
     float4 bv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = slice + ksl * i;
-#ifdef PD_ABL_NOWEIGHTS   // tools only (garbage results): what a phase costs when its weights are already on chip
-        bv[i] = make_float4(1e-3f * (float)(c + lane), 2e-3f, -1e-3f, 1e-3f * (float)n);
-#else
         bv[i] = *reinterpret_cast<const float4*>(wrow + 16 * (c < nch ? c : nch - 1));
-#endif
     }
 
-    PD_STAMP(0)
+    // ---- where this thread's (at most two) float4 of the cluster's A tile come from and go to: computed before the
+    // wait as well (an integer division per element; behind the wait it was ~0.6 us of every phase)
+    unsigned soff[2];   // byte offset into a0 (ssel 0) or a1 (ssel 1); ssel 2 = zeros
+    int sdst[2], ssel[2];
     if (!ph.cont) {
-        // ---- this thread's (at most four) 16-byte chunks = pairs of granules = two consecutive k of one row of the
-        // cluster's A tile (16 rows x K <= 512): where they come from and where they go
-        unsigned soff[4];   // byte offset into the arena
-        int sdst[4], ssel[4];   // ssel 0 / 1: segment a0 / a1 (expected tag0 / tag1); 2: zeros; 3: past the tile
-        const int k2 = ph.K >> 1;                 // chunks per row
-        const int total = 16 * k2;
+        const int k4 = ph.K >> 2;                 // float4 per row
+        const int total = 16 * k4;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const int i = tid + u * PD_THREADS;
             const int ic = i < total ? i : 0;
-            const int row = ic / k2, kk = (ic - row * k2) * 2;
+            const int row = ic / k4, kk = (ic - row * k4) * 4;
             const int b = b0 + row < B ? b0 + row : B - 1;
             sdst[u] = i < total ? row * PD_LDA + kk : -1;
             const bool first = kk < ph.k0;
-            ssel[u] = i >= total ? 3 : (first ? (ph.a0 >= 0 ? 0 : 2) : 1);
-            soff[u] = first ? (unsigned)(ph.a0 + b * ph.lda0 + kk) * 8u : (unsigned)(ph.a1 + b * ph.lda1 + kk - ph.k0) * 8u;
+            ssel[u] = i >= total ? 3 : (first ? (ph.a0 ? 0 : 2) : 1);
+            soff[u] = first ? (unsigned)(b * ph.lda0 + kk) * 4u : (unsigned)(b * ph.lda1 + kk - ph.k0) * 4u;
         }
-        if (ph.delay && j == 3)   // a late reader: what a workgroup that falls behind looks like to its peers
-            for (int i = 0; i < ph.delay; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
-        // ---- sweep: all chunks requested together; a chunk is taken when both of its granules carry the tag of the phase
-        // that produces them, the others are requested again (the data is the flag: no counter, no separate poll)
-        float4 sv[4];
-        unsigned pend = 0;
+    PD_STAMP(0)
+    if (!ph.cont) pd_wait(cnt, target, status, ctrl);
+    PD_STAMP(1)
+    if (ph.delay && !ph.cont && j == 3)   // a late stager: what a workgroup that clears its poll late looks like to its peers
+        for (int i = 0; i < ph.delay; ++i) __builtin_amdgcn_s_sleep(127);
+
+    // ---- stage the cluster's A tile (16 rows x K) in LDS: sc1 loads of the handed-off activations.  K <= 512: at most
+    // two float4 per thread, BOTH requested before either is written to LDS (written as a loop of load-then-store the
+    // second request waited for the first: two fabric round trips per phase instead of one)
+    if (!ph.cont) {
+        const __amdgpu_buffer_rsrc_t r0 = pd_rsrc(ph.a0 ? ph.a0 : ph.a1), r1 = pd_rsrc(ph.a1);
+        float4 sv[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2; ++u) {
             sv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ssel[u] < 2) pend |= 1u << u;
+            if (ssel[u] == 0) sv[u] = pd_ld4(r0, soff[u]);
+            else if (ssel[u] == 1) sv[u] = pd_ld4(r1, soff[u]);
         }
-        const bool drain = pd_draining(ctrl);
-        unsigned spins = 0;
-        for (;;) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (pend & (1u << u)) sv[u] = pd_ld4(rs, soff[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (pend & (1u << u)) {
-                    const unsigned e = ssel[u] ? ph.tag1 : ph.tag0;
-                    if (drain || (__float_as_uint(sv[u].y) == e && __float_as_uint(sv[u].w) == e)) pend &= ~(1u << u);
-                }
-            if (!__any(pend != 0)) break;
-            if (pd_spin_fail(spins, status, ctrl)) break;
-        }
-        PD_STAMP(1)
-        __syncthreads();   // every wave is done with the previous phase's tile, partial sums and attention scratch
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (sdst[u] >= 0) *reinterpret_cast<float2*>(As + sdst[u]) = make_float2(sv[u].x, sv[u].z);
+        for (int u = 0; u < 2; ++u)
+            if (sdst[u] >= 0) *reinterpret_cast<float4*>(As + sdst[u]) = sv[u];
         __syncthreads();
     }
     PD_STAMP(2)
@@ -253,8 +234,7 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, const __
     __syncthreads();
     PD_STAMP(3)
 
-    // ---- epilogue: thread e owns (row, 4 consecutive units) of every gate; K slices added in a fixed order.  The waves
-    // that have no part in it are already in the next phase (its weight loads, its sweep).
+    // ---- epilogue: thread e owns (row, 4 consecutive units) of every gate; K slices added in a fixed order
     if (tid < tpg * 64) {
         const int ew = tid >> 6, row = (tid >> 2) & 15, c4 = (tid & 3) * 4;
         const int cl = 16 * ew + c4;             // column inside this workgroup's unit block
@@ -283,7 +263,7 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, const __
         if (ph.epi == PD_ACT) {
             float4 o = v[0];
             o.x = apply_act(o.x, ph.act); o.y = apply_act(o.y, ph.act); o.z = apply_act(o.z, ph.act); o.w = apply_act(o.w, ph.act);
-            if (row_ok) pd_st_gran4(rs, (unsigned)(ph.out + b * ph.ldo + unit), o, ph.otag);
+            if (row_ok) pd_st4(pd_rsrc(ph.out), (unsigned)(b * ph.ldo + unit) * 4u, o);
         } else if (ph.epi == PD_GATES || ph.epi == PD_CUDNN_RU) {
             float4 rr4, uu4;
             rr4.x = sigmoidf_(v[0].x); rr4.y = sigmoidf_(v[0].y); rr4.z = sigmoidf_(v[0].z); rr4.w = sigmoidf_(v[0].w);
@@ -292,7 +272,7 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, const __
             if (ph.epi == PD_GATES) {                          // r*h is the candidate's K operand: hand it over
                 const float4 h4 = *reinterpret_cast<const float4*>(hl);
                 rr4.x *= h4.x; rr4.y *= h4.y; rr4.z *= h4.z; rr4.w *= h4.w;
-                if (row_ok) pd_st_gran4(rs, (unsigned)(ph.out + b * ph.ldo + unit), rr4, ph.otag);
+                if (row_ok) pd_st4(pd_rsrc(ph.out), (unsigned)(b * ph.ldo + unit) * 4u, rr4);
             } else {
                 *reinterpret_cast<float4*>(rl) = rr4;
             }
@@ -311,19 +291,17 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, const __
             hn.z = u4.z * h4.z + (1.0f - u4.z) * tanhf_(cin.z);
             hn.w = u4.w * h4.w + (1.0f - u4.w) * tanhf_(cin.w);
             *reinterpret_cast<float4*>(hl) = hn;
-            if (row_ok) pd_st_gran4(rs, (unsigned)(ph.out + b * ph.ldo + unit), hn, ph.otag);
-            if (ph.yout >= 0) {   // ResidualWrapper: y = x + h'; x is the first K segment of the staged tile
+            if (row_ok) pd_st4(pd_rsrc(ph.out), (unsigned)(b * ph.ldo + unit) * 4u, hn);
+            if (ph.yout) {   // ResidualWrapper: y = x + h'; x is the first K segment of the staged tile
                 const float4 x4 = *reinterpret_cast<const float4*>(As + row * PD_LDA + unit);
                 hn.x += x4.x; hn.y += x4.y; hn.z += x4.z; hn.w += x4.w;
-                if (row_ok) {
-                    pd_st_gran4(rs, (unsigned)(ph.yout + b * ph.ldy + unit), hn, ph.otag);
-                    if (ph.yplain) *reinterpret_cast<float4*>(ph.yplain + (size_t)b * ph.ldyp + unit) = hn;
-                }
+                if (row_ok) pd_st4(pd_rsrc(ph.yout), (unsigned)(b * ph.ldy + unit) * 4u, hn);
             }
         }
     }
     PD_STAMP(4)
     if (ph.more) __syncthreads();   // r / u are in LDS, the partial tiles may be overwritten
+    else pd_publish();
     PD_STAMP(5)
 }
 
@@ -339,9 +317,9 @@ struct PdLocal {
     int* err_flag;
 };
 template <bool LOCAL>   // the global form stays inline (one instance in the step loop); the windowed one is a call
-__device__ __forceinline__ void pd_attention_body(int query, unsigned qtag, const float* __restrict__ keys,
-                                             const float* __restrict__ values, int ctx, unsigned ctag, float* align_t, int Ts,
-                                             float* lds, const __amdgpu_buffer_rsrc_t& rs, int j, int b0, int B, int* status,
+__device__ __forceinline__ void pd_attention_body(const float* __restrict__ query, const float* __restrict__ keys,
+                                             const float* __restrict__ values, float* ctx, float* align_t, int Ts, float* lds,
+                                             int j, int b0, int B, unsigned* cnt, unsigned target, int* status,
                                              const PdLocal lc) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = wave >> 3, hw = wave & 7, t512 = tid & 511;
@@ -358,7 +336,7 @@ __device__ __forceinline__ void pd_attention_body(int query, unsigned qtag, cons
 
     // Scores: 16 lanes per key, 32 keys per pass of the row's 8 waves, PD_KB passes requested together (a pass per
     // round trip to L2 / the Infinity Cache was five dependent trips per step at Ts = 150).  The keys do not depend on
-    // the query: with the global form the first PD_KB passes are requested BEFORE the query is swept.
+    // the query: with the global form the first PD_KB passes are requested BEFORE the wait for the cluster.
     const int sub = lane >> 4, l16 = lane & 15;
     float4 kpre[PD_KB][4];
     auto load_keys = [&](const float* kbase, int j0, int n_pos) {
@@ -373,22 +351,10 @@ __device__ __forceinline__ void pd_attention_body(int query, unsigned qtag, cons
     if (!LOCAL) load_keys(keys + (size_t)rr * Ts * PD_D, 0, Ts);
 
     PD_STAMP(0)
-    // the query (this row's new attention-cell state): 128 chunks of two granules, swept by the row's first two waves
-    float4 qv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t512 < PD_D / 2) {   // (whole waves)
-        const unsigned off = (unsigned)(query + rr * PD_D + 2 * t512) * 8u;
-        const bool drain = pd_draining(ctrl);
-        unsigned spins = 0;
-        for (;;) {
-            qv4 = pd_ld4(rs, off);
-            const bool ok = drain || (__float_as_uint(qv4.y) == qtag && __float_as_uint(qv4.w) == qtag);
-            if (__all(ok)) break;
-            if (pd_spin_fail(spins, status, ctrl)) break;
-        }
-    }
+    pd_wait(cnt, target, status, ctrl);
     PD_STAMP(1)
-    __syncthreads();   // every wave is done with the previous phase's tile and partial sums
-    if (t512 < PD_D / 2) *reinterpret_cast<float2*>(qs + 2 * t512) = make_float2(qv4.x, qv4.z);
+
+    if (t512 < 64) *reinterpret_cast<float4*>(qs + 4 * t512) = pd_ld4(pd_rsrc(query), (unsigned)(rr * PD_D + 4 * t512) * 4u);
     __syncthreads();
 
     // scored positions [w_lo, w_lo + w_n): the whole memory, or the local window
@@ -510,7 +476,7 @@ __device__ __forceinline__ void pd_attention_body(int query, unsigned qtag, cons
             a.x += t4.x; a.y += t4.y; a.z += t4.z; a.w += t4.w;
         }
         a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
-        if (row_ok) pd_st_gran4(rs, (unsigned)(ctx + row * PD_D + 4 * t512), a, ctag);
+        if (row_ok) pd_st4(pd_rsrc(ctx), (unsigned)(row * PD_D + 4 * t512) * 4u, a);
     }
     if (align_t && row_ok) {
         // the reference pads the window back to the memory length (attention.py:85-92) and, with `gaussian`, weights
@@ -530,13 +496,13 @@ __device__ __forceinline__ void pd_attention_body(int query, unsigned qtag, cons
         }
     }
     PD_STAMP(4)
+    pd_publish();
     PD_STAMP(5)
 }
-__device__ __attribute__((noinline)) void pd_attention_local(int query, unsigned qtag, const float* keys, const float* values, int ctx,
-                                                             unsigned ctag, float* align_t, int Ts, float* lds,
-                                                             const __amdgpu_buffer_rsrc_t rs, int j, int b0, int B, int* status,
-                                                             const PdLocal lc) {
-    pd_attention_body<true>(query, qtag, keys, values, ctx, ctag, align_t, Ts, lds, rs, j, b0, B, status, lc);
+__device__ __attribute__((noinline)) void pd_attention_local(const float* query, const float* keys, const float* values, float* ctx,
+                                                             float* align_t, int Ts, float* lds, int j, int b0, int B, unsigned* cnt,
+                                                             unsigned target, int* status, const PdLocal lc) {
+    pd_attention_body<true>(query, keys, values, ctx, align_t, Ts, lds, j, b0, B, cnt, target, status, lc);
 }
 
 __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) {
@@ -544,6 +510,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
     const int tid = threadIdx.x;
     const int cluster = blockIdx.x / PD_W, j = blockIdx.x - cluster * PD_W;
     const int b0 = cluster * 16;
+    unsigned* cnt = p.counters + 64 * cluster;
     int* ctrl = reinterpret_cast<int*>(lds + PD_OFF_CTRL);
     for (int i = tid; i < 3 * 16 * 32 + 2 * 16 * 32; i += PD_THREADS) lds[PD_OFF_H + i] = 0.f;   // zero_state
     if (tid == 0) {
@@ -553,20 +520,16 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
         if (n + 1 == gridDim.x && p.hold_flag) __hip_atomic_store(p.hold_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rs = pd_rsrc(p.gran);
-    const int B = p.B;
-    const int o_att = (int)pd_buf_off(PB_ATT, B), o_p1 = (int)pd_buf_off(PB_P1, B), o_p2 = (int)pd_buf_off(PB_P2, B),
-              o_rh = (int)pd_buf_off(PB_RH, B), o_ctx = (int)pd_buf_off(PB_CTX, B), o_y0 = (int)pd_buf_off(PB_Y0, B),
-              o_yg = (int)pd_buf_off(PB_YG, B), o_hatt = (int)pd_buf_off(PB_HATT0, B), o_hd = (int)pd_buf_off(PB_HD00, B);
-    const int st = B * PD_D;   // granules of one state buffer: h_att[par] = o_hatt + par st, h_dec[l][par] = o_hd + (2 l + par) st
 
     const int yld = p.n_steps * PD_D;
+    unsigned g = 0;   // phases completed by the cluster
     for (int t = 0; t < p.n_steps; ++t) {
         // The recurrent states are double-buffered by step parity: step t reads h[t & 1] and writes h[(t + 1) & 1].
-        // In the CudnnCompatibleGRUCell form the candidate phase continues on the staged tile without a sweep, so a
-        // workgroup stores its slice of h' while a peer that is a little behind may still be sweeping the full previous h:
-        // with one buffer its sweep would wait for a tag that has just been overwritten.
-        const int h_att_old = o_hatt + (t & 1) * st, h_att_new = o_hatt + ((t + 1) & 1) * st;
+        // In the CudnnCompatibleGRUCell form the candidate phase continues on the staged tile without a wait, so a
+        // workgroup stores its slice of h' while a peer that left the previous wait a little later may still be staging
+        // the full previous h: with one buffer that peer would read a mix of h_{t-1} and h_t.
+        const float* h_att_old = p.h_att2[t & 1];
+        float* h_att_new = p.h_att2[(t + 1) & 1];
         // ONE instance of the phase body in a loop over the step's ten phases (ten inlined copies spill)
 #pragma nounroll
         for (int k = 0; k < 10; ++k) {
@@ -579,48 +542,44 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
                 lc.wp = p.local_wp; lc.vp = p.local_vp; lc.p_hist_t = p.p_hist ? p.p_hist + (size_t)t * p.B : nullptr;
                 lc.err_flag = p.err_flag;
                 float* align_t = p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr;
-                if (p.local_d > 0) pd_attention_local(h_att_new, pd_tag(t, 3), p.keys, p.memory, o_ctx, pd_tag(t, 4), align_t, p.Ts, lds, rs, j, b0, B, p.status, lc);
-                else pd_attention_body<false>(h_att_new, pd_tag(t, 3), p.keys, p.memory, o_ctx, pd_tag(t, 4), align_t, p.Ts, lds, rs, j, b0, B, p.status, lc);
+                if (p.local_d > 0) pd_attention_local(h_att_new, p.keys, p.memory, p.ctx, align_t, p.Ts, lds, j, b0, p.B, cnt, PD_W * g, p.status, lc);
+                else pd_attention_body<false>(h_att_new, p.keys, p.memory, p.ctx, align_t, p.Ts, lds, j, b0, p.B, cnt, PD_W * g, p.status, lc);
+                ++g;
                 continue;
             }
             PdPhase ph;
             ph.lda0 = PD_D; ph.k0 = PD_D; ph.lda1 = PD_D; ph.K = 2 * PD_D; ph.ub = 32; ph.act = ACT_NONE; ph.layer = 0;
-            ph.ldo = PD_D; ph.yout = -1; ph.ldy = PD_D; ph.yplain = nullptr; ph.ldyp = 0; ph.bias = nullptr; ph.row0 = 0; ph.cont = 0; ph.more = 0;
+            ph.ldo = PD_D; ph.yout = nullptr; ph.ldy = PD_D; ph.bias = nullptr; ph.row0 = 0; ph.cont = 0; ph.more = 0;
             ph.delay = p.dbg_delay;
-            ph.otag = pd_tag(t, k);
             switch (k) {
                 case 0:
                     // PrenetWrapper on concat([x_t, attention_{t-1}]) (wrappers.py:122-124); x_0 = GO frame = zeros
                     // (helpers.py:108), x_t = (y_{t-1} W_o + b_o)[-n_mels:] folded into the pre-net matrix (decoder.hip)
-                    ph.a0 = t == 0 ? -1 : o_yg; ph.tag0 = pd_tag(t - 1, 9); ph.k0 = t == 0 ? p.n_mels : PD_D;
-                    ph.a1 = o_att; ph.tag1 = pd_tag(t - 1, 5); ph.K = ph.k0 + PD_D;
+                    ph.a0 = t == 0 ? nullptr : p.yhist + (size_t)(t - 1) * PD_D; ph.lda0 = yld; ph.k0 = t == 0 ? p.n_mels : PD_D;
+                    ph.a1 = p.att; ph.K = ph.k0 + PD_D;
                     ph.Wt = t == 0 ? p.w1 : p.w1f; ph.bias = t == 0 ? p.b1 : p.b1f;
-                    ph.epi = PD_ACT; ph.act = ACT_RELU; ph.out = o_p1;
+                    ph.epi = PD_ACT; ph.act = ACT_RELU; ph.out = p.p1;
                     break;
                 case 1:
-                    ph.a0 = o_p1; ph.a1 = o_p1; ph.tag0 = ph.tag1 = pd_tag(t, 0); ph.K = PD_D; ph.Wt = p.w2; ph.bias = p.b2; ph.ub = 16;
-                    ph.epi = PD_ACT; ph.act = ACT_RELU; ph.out = o_p2; ph.ldo = PD_P2;
+                    ph.a0 = p.p1; ph.a1 = p.p1; ph.K = PD_D; ph.Wt = p.w2; ph.bias = p.b2; ph.ub = 16;
+                    ph.epi = PD_ACT; ph.act = ACT_RELU; ph.out = p.p2; ph.ldo = PD_P2;
                     break;
                 case 2:   // attention GRU (model.py:226-229): gates on [p2 ; h_att]
-                    ph.a0 = o_p2; ph.tag0 = pd_tag(t, 1); ph.lda0 = PD_P2; ph.k0 = PD_P2; ph.a1 = h_att_old; ph.tag1 = pd_tag(t - 1, 3);
-                    ph.K = PD_P2 + PD_D;
-                    ph.Wt = p.ag_w; ph.bias = p.ag_b; ph.epi = p.cudnn ? PD_CUDNN_RU : PD_GATES; ph.out = o_rh; ph.more = p.cudnn;
+                    ph.a0 = p.p2; ph.lda0 = PD_P2; ph.k0 = PD_P2; ph.a1 = h_att_old; ph.K = PD_P2 + PD_D;
+                    ph.Wt = p.ag_w; ph.bias = p.ag_b; ph.epi = p.cudnn ? PD_CUDNN_RU : PD_GATES; ph.out = p.rh; ph.more = p.cudnn;
                     break;
                 case 3:   // ... candidate (GRUCell: on [p2 ; r*h_att], after a hop); the new state is the attention query
-                    ph.a0 = o_p2; ph.tag0 = pd_tag(t, 1); ph.lda0 = PD_P2; ph.k0 = PD_P2; ph.a1 = o_rh; ph.tag1 = pd_tag(t, 2);
-                    ph.K = PD_P2 + PD_D;
+                    ph.a0 = p.p2; ph.lda0 = PD_P2; ph.k0 = PD_P2; ph.a1 = p.rh; ph.K = PD_P2 + PD_D;
                     ph.Wt = p.cudnn ? p.ag_w : p.ac_w; ph.bias = p.cudnn ? p.ag_b : p.ac_b; ph.out = h_att_new;
                     ph.epi = p.cudnn ? PD_CUDNN_HX : PD_CAND; ph.row0 = p.cudnn ? 2 * PD_D : 0; ph.cont = p.cudnn;
                     break;
                 case 5:   // attention_layer(concat([cell_output, context])), no bias
-                    ph.a0 = h_att_new; ph.tag0 = pd_tag(t, 3); ph.a1 = o_ctx; ph.tag1 = pd_tag(t, 4); ph.Wt = p.al_w; ph.epi = PD_ACT; ph.out = o_att;
+                    ph.a0 = h_att_new; ph.a1 = p.ctx; ph.Wt = p.al_w; ph.epi = PD_ACT; ph.out = p.att;
                     break;
                 default: {   // 6..9: two ResidualWrapper(GRU cell) layers (model.py:254-269); the top one writes the y history
                     const int l = (k - 6) >> 1;
                     const bool second = (k - 6) & 1;
-                    const int h_old = o_hd + (2 * l + (t & 1)) * st, h_new = o_hd + (2 * l + ((t + 1) & 1)) * st;
-                    ph.a0 = l == 0 ? o_att : o_y0; ph.tag0 = l == 0 ? pd_tag(t, 5) : pd_tag(t, 7);
-                    ph.a1 = (second && !p.cudnn) ? o_rh : h_old; ph.tag1 = (second && !p.cudnn) ? pd_tag(t, k - 1) : pd_tag(t - 1, 7 + 2 * l);
+                    ph.a0 = l == 0 ? p.att : p.y0; ph.a1 = (second && !p.cudnn) ? p.rh : p.h_dec2[l][t & 1];
                     ph.layer = 1 + l;
                     if (p.cudnn) {
                         ph.Wt = p.g_gw[l]; ph.bias = p.g_gb[l];
@@ -630,14 +589,12 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
                         ph.Wt = second ? p.g_cw[l] : p.g_gw[l]; ph.bias = second ? p.g_cb[l] : p.g_gb[l];
                         ph.epi = second ? PD_CAND : PD_GATES;
                     }
-                    ph.out = second ? h_new : o_rh;
-                    if (second) {
-                        ph.yout = l == 0 ? o_y0 : o_yg;
-                        if (l == 1) { ph.yplain = p.yhist + (size_t)t * PD_D; ph.ldyp = yld; }
-                    }
+                    ph.out = second ? p.h_dec2[l][(t + 1) & 1] : p.rh;
+                    if (second) { ph.yout = l == 0 ? p.y0 : p.yhist + (size_t)t * PD_D; ph.ldy = l == 0 ? PD_D : yld; }
                 } break;
             }
-            pd_phase(ph, lds, rs, j, b0, B, p.status);
+            pd_phase(ph, lds, j, b0, p.B, cnt, PD_W * g, p.status);
+            if (!ph.more) ++g;
         }
     }
 #ifdef PD_TIMELINE
@@ -651,29 +608,25 @@ bool decoder_persistent_supports(const DecoderWeights& w, int cudnn, int B, int 
     if (w.local_d > 0 && Ts < 2 * w.local_d + 1) return false;
     return w.n_layers == 2 && w.att_units == PD_D && w.dec_units == PD_D && w.mem_units == PD_D &&
            w.prenet1_units == PD_D && w.prenet2_units == PD_P2 && w.n_mels % 16 == 0 && w.n_mels <= PD_D && B >= 1 && Ts >= 1 &&
-           pd_lds_bytes(Ts) <= 160 * 1024 && (size_t)B * Ts * PD_D * 4 < 0xFFFFFFF0ull && pd_granules(B) * 8 < 0x7FFFFFF0ull;
+           pd_lds_bytes(Ts) <= 160 * 1024 && (size_t)B * Ts * PD_D * 4 < 0xFFFFFFF0ull;
 }
 
 int decoder_persistent_workgroups(int B) { return PD_W * ((B + 15) / 16); }
-size_t decoder_persistent_arena_bytes(int B) { return (pd_granules(B) * 8 + 15) & ~(size_t)15; }
 
 hipError_t decoder_persistent_configure() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024 - 64);
 }
 
-// Capturable: two memsets and one launch.  `sync` = 64 unsigned per cluster (unused since the granule hand-offs of round
-// 4; kept so that the status word stays where the host looks for it) + 1 (resident count) + 1 (status word, zeroed by the
-// caller when the buffer is created and after it has been read).  `arena`: decoder_persistent_arena_bytes(B) bytes, zeroed
-// here for every call: tag 0 = "before step 0", and the zeros are the cells' zero_state.
+// Capturable: two memsets and one launch.  `sync` = 64 unsigned per cluster + 1 (resident count) + 1 (status word,
+// zeroed by the caller when the buffer is created and after it has been read).
 hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, const DecoderScratch& sc, const float* memory,
                                       const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync,
-                                      int* hold_flag, int cudnn, void* arena, int dbg_delay) {
+                                      int* hold_flag, int cudnn, int dbg_delay) {
     const int clusters = (B + 15) / 16;
     hipError_t e;
-    if (n_steps > 0x0FFFFFF0 / 16) return hipErrorInvalidValue;   // tags are 32-bit
-    if ((e = hipMemsetAsync(arena, 0, decoder_persistent_arena_bytes(B), s)) != hipSuccess) return e;
-    // the resident count starts at zero for every launch; the status word behind it is sticky (the host
+    if ((e = hipMemsetAsync(sc.state, 0, sc.state_bytes, s)) != hipSuccess) return e;
+    // counters and resident count start at zero for every launch; the status word behind them is sticky (the host
     // clears it when it has read it, api.hip), so a timeout is not lost when several calls are queued before a sync
     if ((e = hipMemsetAsync(sync, 0, ((size_t)64 * clusters + 1) * sizeof(unsigned), s)) != hipSuccess) return e;
     PdParams p;
@@ -682,12 +635,14 @@ hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, co
     p.al_w = w.attn_layer_wt;
     for (int l = 0; l < 2; ++l) {
         p.g_gw[l] = w.gru[l].gates_wt; p.g_gb[l] = w.gru[l].gates_b; p.g_cw[l] = w.gru[l].cand_wt; p.g_cb[l] = w.gru[l].cand_b;
+        p.h_dec2[l][0] = sc.h_dec[l]; p.h_dec2[l][1] = sc.h_dec_alt[l];
     }
+    p.h_att2[0] = sc.h_att; p.h_att2[1] = sc.h_att_alt;
     p.dbg_delay = dbg_delay;
     p.memory = memory; p.keys = keys;
-    p.gran = arena;
+    p.att = sc.att; p.p1 = sc.p1; p.p2 = sc.p2; p.rh = sc.rh; p.ctx = sc.ctx_parts; p.y0 = sc.y0;
     p.yhist = sc.yhist; p.align = align;
-    p.resident = sync + 64 * clusters; p.status = reinterpret_cast<int*>(sync + 64 * clusters + 1);
+    p.counters = sync; p.resident = sync + 64 * clusters; p.status = reinterpret_cast<int*>(sync + 64 * clusters + 1);
     p.hold_flag = hold_flag;
     p.B = B; p.Ts = Ts; p.n_steps = n_steps; p.n_mels = w.n_mels; p.cudnn = cudnn;
     p.local_d = w.local_d; p.local_gaussian = w.local_gaussian; p.local_predictive = w.local_d > 0 && w.local_predictive;
