@@ -37,6 +37,44 @@ REF_DB, MAX_DB, POWER = 6.02, 99.89, 1.3
 SR = 22050
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA (v_mfma_f32_32x32x2_f32), same guide
+MFMA_BF16_PEAK_TFLOPS = 16 * 157.3   # dense bf16 MFMA = 16 x the f32 rate (same guide, matrix cores table): ~2.5 PFLOP/s
+GEMM_PRODUCTS = 6              # bf16 MFMAs per f32-equivalent product block (csrc/gemm_f32.hip: hi/mid/lo split, six products)
+DEC_MFLOP_PER_UTT_STEP = 3.02  # decoder loop, MFLOP per step and utterance
+DEC_PHASES_PER_STEP = 10       # hand-off phases of the persistent decoder per step (GRUCell form)
+
+
+def _sha16(paths):
+    import hashlib
+    h = hashlib.sha256()
+    for q in paths:
+        with open(q, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def gl_kernel_sha16():
+    """content hash of the sources the Griffin-Lim kernel is built from: what a counter file must have been measured on"""
+    c = os.path.join(ROOT, 'single-speaker-tts_amd', 'csrc')
+    return _sha16([os.path.join(c, 'griffin_lim.hip'), os.path.join(c, 'griffin_lim.h')])
+
+
+def _newest_profile(pattern, per_launch):
+    """newest profiles/<pattern> whose record was measured on the Griffin-Lim kernel of THIS tree (its `kernel_sha16`
+    equals gl_kernel_sha16()) at the same iterations per launch; (record or None, reason)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
+    if not files:
+        return None, 'no file profiles/' + pattern
+    with open(files[-1]) as f:
+        rec = json.load(f)
+    name = os.path.basename(files[-1])
+    if rec.get('iterations_per_launch', 1) != per_launch:
+        return None, name + ': measured at {} iterations per launch'.format(rec.get('iterations_per_launch'))
+    if rec.get('kernel_sha16') != gl_kernel_sha16():
+        return None, name + ': measured on other kernel sources (kernel_sha16 {} != {} of this tree)'.format(
+            rec.get('kernel_sha16'), gl_kernel_sha16())
+    rec = dict(rec, file='profiles/' + name)
+    return rec, None
 
 
 def synthetic_ids(B, Ts, seed):
@@ -69,12 +107,14 @@ def _blas_threads():
         return None
 
 
-def cpu_baseline(weights, hp, n_utts=6, repeats=3):
+def cpu_baseline(weights, hp, n_utts=6, repeats=5):
     """the numpy oracle (a restated CPU path -- NOT TensorFlow, which cannot run here) on a bounded
     sample of the bench workload, on this box's host cores: (i) the network on n_utts utterances in one process
     (float32, the BLAS library's default thread count, reported); (ii) Griffin-Lim the way the reference fans it out
     -- 6 worker processes, one utterance each (tacotron/inference.py:185-188, params/inference.py:34) -- and also
-    with os.cpu_count() workers on as many utterances.  One warm-up run each, then the median of `repeats`.
+    with one worker per CPU this process may run on (os.sched_getaffinity: os.cpu_count() on a host of its own; on a GPU box
+    one GPU's share, where more worker processes than that are refused) on as many utterances.  One warm-up run each, then
+    the median of `repeats` (>= 5).
     `value` = frames / (network + Griffin-Lim with the reference's 6 workers)."""
     from multiprocessing import get_context
     from oracle import tacotron_oracle as O
@@ -93,12 +133,17 @@ def cpu_baseline(weights, hp, n_utts=6, repeats=3):
         return t
 
     t_gl6 = gl(n_utts)
-    # "all cores": one GPU's share of the host (16 worker processes on the GPU boxes, which report 256 logical CPUs for
-    # eight GPUs), never more than the host has
-    share = min(cores, 16)
+    # "all cores": every CPU this process may run on -- os.cpu_count() unless the box restricts the process (the GPU boxes
+    # report 256 logical CPUs for eight GPUs and give one GPU's job 16 of them; worker pools beyond a job's share are
+    # killed there)
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = cores
+    share = max(1, min(cores, usable, int(os.environ.get('SSTTS_CPU_WORKERS', '16' if cores > 64 else str(cores)))))
     t_glc = gl(share) if share != n_utts else t_gl6
     frames = n_utts * N_STEPS * hp.reduction
-    return dict(value=frames / (t_net + t_gl6), unit='mel-frames/s', cores=cores, kind='port',
+    return dict(value=frames / (t_net + t_gl6), unit='mel-frames/s', cores=cores, cpus_usable=usable, repeats=repeats, kind='port',
                 sample='{} utterances end-to-end (Ts={}, {} decoder steps, {} GL iterations), numpy oracle = a restated CPU '
                        'path, not TensorFlow; 1 warm-up + median of {}: network {:.2f} s in 1 process (BLAS threads: {}), '
                        'Griffin-Lim {:.2f} s in the reference\'s {}-process pool; with {} workers (one GPU\'s share of the {} host CPUs) on {} '
@@ -253,7 +298,8 @@ def main():
         blob = Wm.pack_blob(weights, hp)
     else:
         blob = np.empty(n_floats, np.float32)
-    broadcast_ms = None
+    broadcast_ms = None          # first broadcast: includes the communicator set-up of the first collective
+    broadcast_ms_steady = None   # the same broadcast again, communicator up: what the 27.4 MB cost on the wire
     if dist is not None:
         # the ONE collective of the path (RCCL over xGMI under "nccl"); nothing is exchanged afterwards
         if dist.get_world_size() != args.gpus:
@@ -263,7 +309,13 @@ def main():
         t0 = time.perf_counter()
         blob = shard.broadcast_blob(blob, src=0, device=bdev)
         dist.barrier()
-        broadcast_ms = 1e3 * (time.perf_counter() - t0)   # includes the communicator set-up of the first collective
+        broadcast_ms = 1e3 * (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        again = shard.broadcast_blob(blob, src=0, device=bdev)
+        dist.barrier()
+        broadcast_ms_steady = 1e3 * (time.perf_counter() - t0)
+        if not np.array_equal(again, blob):
+            raise SystemExit('rank {}: the second weight broadcast differs from the first'.format(rank))
     eng = sstts.Engine(hp, device_id=local_rank)
     if dist is not None and dist.get_backend() == 'nccl':
         import torch
@@ -271,6 +323,16 @@ def main():
         if eng.device_id != local_rank or torch.cuda.current_device() != local_rank:
             raise SystemExit('rank {}: handle on device {}, communicator on {}, LOCAL_RANK {}'.format(
                 rank, eng.device_id, torch.cuda.current_device(), local_rank))
+    dev_uuid, dev_cus = eng.device_info()
+    rank_devices = None
+    if dist is not None:
+        # every rank's (host, device uuid): under "nccl" no two ranks of one host may sit on one device (one process per GPU);
+        # under gloo (rehearsals on a box with fewer GPUs than ranks) sharing is allowed and reported
+        import socket
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, (socket.gethostname(), dev_uuid, dev_cus))
+        if dist.get_backend() == 'nccl' and len(set(rank_devices)) != world:
+            raise SystemExit('rank {}: two ranks share a device: {}'.format(rank, rank_devices))
     eng.load_weights_blob(blob)
     if args.pipeline is not None:
         eng.set_option('pipeline', args.pipeline)
@@ -288,6 +350,12 @@ def main():
     ids_all = synthetic_ids(world * B_PER_GPU, TS, 1234)
     ids = eng.to_device(ids_all[lo:hi])
     B = hi - lo
+    if dist is not None:
+        # every shard is padded to the GLOBAL sentence length (the reference masks nothing: sharding.py): same on all ranks
+        shapes = [None] * world
+        dist.all_gather_object(shapes, (int(ids_all[lo:hi].shape[1]), int(B)))
+        if len({sh[0] for sh in shapes}) != 1 or any(sh[1] != B_PER_GPU for sh in shapes):
+            raise SystemExit('rank {}: shards differ in padded length or size: {}'.format(rank, shapes))
     T = N_STEPS * hp.reduction
     F = 1 + N_FFT // 2
     init = eng.to_device(np.random.default_rng(42 + rank).random((B, F, T), dtype=np.float32))
@@ -310,8 +378,12 @@ def main():
         eng.synthesize(ids, N_STEPS, REF_DB, MAX_DB, POWER, N_ITER, WIN, HOP, seed=1000 * (rank + 1) + calls[0],
                        peak_normalize=True, wav=wav, want_linear=lin_out, want_alignments=ali_out)
 
+    own_elapsed = [0.0]
+    t_start = [0.0]
+
     def barrier():
         eng.synchronize()
+        own_elapsed[0] = time.perf_counter() - t_start[0]   # (meaningful for the closing barrier: own work done)
         if dist is not None:
             dist.barrier()
         eng.synchronize()
@@ -322,12 +394,19 @@ def main():
     eng.profile_reset()
     barrier()
     t0 = time.perf_counter()
+    t_start[0] = t0
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = None
     if dist is not None:
         import torch
+        # this rank's own time: the clock stopped when ITS device was idle, before the closing barrier (what `elapsed`
+        # includes); gathered so that a straggler is named, not just suffered
+        own = [None] * world
+        dist.all_gather_object(own, 1e3 * own_elapsed[0] / args.steps)
+        rank_ms = own
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device='cuda:{}'.format(local_rank) if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -402,16 +481,15 @@ def main():
         gl_launch_ms = gl_iter_ms * per_launch
         alg_bytes = 20.0 * F * T * B_PER_GPU * per_launch
         achieved = alg_bytes / (gl_launch_ms * 1e-3) / 1e9 if gl_launch_ms > 0 else 0.0
-        # HBM bytes per launch from the PMC passes of the same build (FETCH_SIZE / WRITE_SIZE cannot be read
-        # inside this process): newest profiles/*gl_iter_hbm_bytes_per_launch.json
-        traffic = None
-        import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*gl_iter_hbm_bytes_per_launch.json')))
-        if pmcs:
-            with open(pmcs[-1]) as f:
-                rec = json.load(f)
-            if rec.get('iterations_per_launch', 1) == per_launch:
-                traffic = rec.get('hbm_bytes_per_launch')
+        # HBM bytes per launch and the SQ counters of the kernel come from PMC passes (rocprofv3 cannot run inside this
+        # process): the newest profiles/*gl_iter_hbm_bytes_per_launch.json / *gl_iter_valu.json -- used ONLY when the record
+        # says it was measured on the Griffin-Lim kernel sources of this tree (kernel_sha16), reported as stale otherwise
+        traffic_rec, traffic_why = _newest_profile('*gl_iter_hbm_bytes_per_launch.json', per_launch)
+        traffic = traffic_rec.get('hbm_bytes_per_launch') if traffic_rec else None
+        valu_rec, valu_why = _newest_profile('*gl_iter_valu.json', per_launch)
+        dec_ms = stage_ms['decoder']
+        dec_flop = DEC_MFLOP_PER_UTT_STEP * 1e6 * B_PER_GPU * N_STEPS
+        gemm_tflops = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         out = {
             'metric': 'mel-frames/sec (end-to-end text->waveform incl. 60-iter Griffin-Lim, 64-utt LJ-Speech-shaped batch per GPU)',
             'value': frames_total * args.steps / elapsed,
@@ -419,12 +497,25 @@ def main():
             'n_gpus': world,
             'world_size_seen': dist.get_world_size() if dist is not None else 1,
             'weight_broadcast_ms': broadcast_ms,
+            # N > 1 diagnostics: the first broadcast (communicator set-up included) against the same 27.4 MB again; every
+            # rank's own ms per step (clock stopped when its device was idle, before the closing barrier) and the slowest
+            # rank; the devices the ranks sat on
+            'weight_broadcast_ms_steady': broadcast_ms_steady,
+            'rank_ms_per_step': rank_ms,
+            'rank_ms_per_step_min': min(rank_ms) if rank_ms else None,
+            'rank_ms_per_step_max': max(rank_ms) if rank_ms else None,
+            'straggler_rank': int(np.argmax(rank_ms)) if rank_ms else None,
+            'rank_devices': [{'host': d[0], 'uuid': d[1], 'compute_units': d[2]} for d in rank_devices] if rank_devices else
+                            [{'host': None, 'uuid': dev_uuid, 'compute_units': dev_cus}],
+            'padded_sentence_length': TS,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': ms_per_step,
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
+            # f32 throughout; the GEMMs form their f32 products from exact three-way bf16 splits of both operands (6 bf16 MFMAs,
+            # f32 accumulation: same error against the float64 oracle as the f32 MFMA, tests/test_gpu_gemm.py)
             'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': 'end-to-end Tacotron inference, B=64/GPU, T_sent=150, 200 decoder steps (r=5, 1000 frames), '
@@ -437,23 +528,63 @@ def main():
             'facade_ms_per_step': facade_ms,
             'outputs_per_step': 'wav (peak-normalised)' + ('' if args.no_aux_outputs else ', linear spectrograms, alignments') +
                                 ', mel (library-owned double buffer); all resident in HBM, none copied to the host in the timed region',
+            # SURVEY.md 8(d) / the bench contract: `achieved` = ALGORITHMIC bytes (20 B per bin and iteration) / launch time.
+            # The kernel no longer moves those bytes (three iterations per launch pass the spectrum on in registers): what
+            # the memory system really carries is `traffic` / `achieved_traffic` / `frac_traffic`, and what bounds the launch
+            # is VALU issue (`limiter`, `roofline_valu`), neither roof.
             'roofline': {'kernel': 'gl_stream_kernel<0, 1102, 275, false, {0}> ({0} Griffin-Lim iterations per launch: iSTFT + STFT '
                                    'of every iteration fused, the spectrum passed from one iteration to the next in registers)'.format(per_launch),
                          'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'launch_ms': gl_launch_ms, 'iterations_per_launch': per_launch,
+                         'traffic': traffic,
+                         'traffic_source': ({'file': traffic_rec['file'], 'commit': traffic_rec.get('commit'),
+                                             'kernel_sha16': traffic_rec.get('kernel_sha16')} if traffic_rec else None),
+                         'traffic_stale': traffic_why,
+                         'achieved_traffic': (traffic / (gl_launch_ms * 1e-3) / 1e9) if (traffic and gl_launch_ms > 0) else None,
+                         'frac_traffic': (traffic / (gl_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and gl_launch_ms > 0) else None,
+                         'limiter': 'VALU issue (roofline_valu), not HBM: the launch moves about a third of the algorithmic bytes',
+                         'launch_ms': gl_launch_ms, 'iterations_per_launch': per_launch,
                          'iteration_ms': gl_iter_ms, 'iteration_ms_alone': gl_alone_ms,
                          'algorithmic_bytes_per_launch': alg_bytes,
-                         # the same launch priced on the measured HBM traffic (what the memory system really carries)
-                         'frac_traffic': (traffic / (gl_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and gl_launch_ms > 0) else None,
-                         'note': 'achieved = algorithmic bytes (20 B per bin and iteration, SURVEY.md 8(d)) / launch time.  A launch '
-                                 'requests 4 B phasor code + 4 B |S| per bin in its first iteration, 4 B |S| in each further one '
-                                 '(rows other waves read microseconds earlier) and writes 4 B code in its last; the kernel is bound by '
-                                 'the power budget, not by either roof: DESIGN.md section 5'},
-            'roofline_mfma': {'kernel': 'gemm_f32_kernel (post-net projection 1: conv1d k=3, 1024 -> 256, max-pool in the loader, M = {})'.format(M),
-                              'bound': 'mfma', 'achieved': gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
-                              'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                              'frac': (gemm_flop / (gemm_ms * 1e-3) / 1e12) / MFMA_F32_PEAK_TFLOPS if gemm_ms > 0 else 0.0,
+                         'note': 'achieved / frac = algorithmic bytes (20 B per bin and iteration, SURVEY.md 8(d)) / launch time, as the '
+                                 'contract defines them; achieved_traffic / frac_traffic = measured HBM bytes of the same launch (a launch '
+                                 'requests 4 B phasor code + 4 B |S| per bin in its first iteration, 4 B |S| in each further one and writes '
+                                 '4 B code in its last)'},
+            # what bounds the dominant kernel: SQ counters of the same kernel sources (separate --pmc passes, tools/gl_pmc.sh)
+            'roofline_valu': ({'kernel': 'gl_stream_kernel<0, 1102, 275, false, {}>'.format(per_launch),
+                               'valu_wave_insts_per_launch': valu_rec.get('valu_wave_insts_per_launch'),
+                               'valu_busy_frac': valu_rec.get('valu_busy_frac'),
+                               'fp_share': valu_rec.get('fp_share'),
+                               'shader_clock_mhz': valu_rec.get('shader_clock_mhz'),
+                               'lds_bank_conflict_frac': valu_rec.get('lds_bank_conflict_frac'),
+                               'source': {'file': valu_rec['file'], 'commit': valu_rec.get('commit'),
+                                          'kernel_sha16': valu_rec.get('kernel_sha16')}} if valu_rec else
+                              {'kernel': 'gl_stream_kernel', 'stale': valu_why}),
+            # the latency-bound loop ("report achieved MFMA fraction and steps/s")
+            'roofline_decoder': {'kernel': 'dec_persistent_kernel (200 steps x {} hand-off phases, clusters of 8 workgroups x 16 '
+                                           'utterances)'.format(DEC_PHASES_PER_STEP),
+                                 'bound': 'latency',
+                                 'ms': dec_ms,
+                                 'steps_per_s': N_STEPS / (dec_ms * 1e-3) if dec_ms > 0 else None,
+                                 'utterance_steps_per_s': B_PER_GPU * N_STEPS / (dec_ms * 1e-3) if dec_ms > 0 else None,
+                                 'tflops': dec_flop / (dec_ms * 1e-3) / 1e12 if dec_ms > 0 else None,
+                                 'mfma_frac': (dec_flop / (dec_ms * 1e-3) / 1e12) / MFMA_F32_PEAK_TFLOPS if dec_ms > 0 else None,
+                                 'mfma_peak': MFMA_F32_PEAK_TFLOPS,
+                                 'us_per_step': 1e3 * dec_ms / N_STEPS,
+                                 'us_per_phase': 1e3 * dec_ms / (N_STEPS * DEC_PHASES_PER_STEP),
+                                 'flop_per_call': dec_flop,
+                                 'note': 'measured beside the Griffin-Lim launches of the previous call (stage_ms.decoder)'},
+            # f32 GEMM on the bf16 matrix pipe: every f32 operand split exactly into three bf16 terms, six bf16 MFMAs per
+            # product block, f32 accumulation (csrc/gemm_f32.hip).  `achieved` counts the f32-equivalent flops 2 M N K;
+            # `peak` = dense bf16 MFMA peak / 6; `frac_of_f32_mfma_peak` prices the same flops against the f32-input MFMA
+            # the kernel used until round 3 (> 1 is possible: that is the point of the split)
+            'roofline_mfma': {'kernel': 'gemm_f32_pool_kernel (post-net projection 1: conv1d k=3, 1024 -> 256, max-pool in the loader, '
+                                        'M = {}; f32 operands as 3 x bf16, 6 x v_mfma_f32_32x32x16_bf16 per 16 k)'.format(M),
+                              'bound': 'mfma', 'achieved': gemm_tflops,
+                              'peak': MFMA_BF16_PEAK_TFLOPS / GEMM_PRODUCTS, 'unit': 'TFLOP/s (f32-equivalent)',
+                              'frac': gemm_tflops / (MFMA_BF16_PEAK_TFLOPS / GEMM_PRODUCTS),
+                              'frac_of_f32_mfma_peak': gemm_tflops / MFMA_F32_PEAK_TFLOPS,
+                              'bf16_mfma_tflops': gemm_tflops * GEMM_PRODUCTS, 'bf16_mfma_peak': MFMA_BF16_PEAK_TFLOPS,
                               'traffic': None, 'launch_ms': gemm_ms, 'flop_per_launch': gemm_flop},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -107,6 +107,11 @@ int tts_set_stream(tts_handle_t h, void* hip_stream);
  * "gl_pair" (Griffin-Lim iterations per launch, 1..3, default 3: the spectrum passes from one iteration to the next in
  * registers; identical arithmetic per iteration), "fused_tail" (default 1: lifter + highway stack + GRU input
  * projections of a CBHG as one launch; 0 = layer by layer).
+ * Test and diagnostic hooks -- per handle, inert (and refused with a non-zero value) until "debug_hooks" has been set to 1
+ * on the same handle; nothing in the process environment changes what a call computes: "pd_debug_delay" (workgroup 3 of
+ * every persistent-decoder cluster stages its tile that many x ~3.4 us late), "gl_runs" / "gl_run_len" (force the cut of
+ * an utterance's frames into Griffin-Lim runs: runs per utterance / frames per run; the cut is part of the waveform's
+ * rounding), "timeline" (tts_profile_get prints the absolute times of every profiled span); tts_debug_hold.
  * Initial phases of Griffin-Lim: `init_phase` (a (B, F, T) array of U[0,1) numbers, angle = 2 pi u) or, when it is NULL,
  * a counter-based draw from `seed` made inside the first iteration's launch (the reference draws np.random.rand per call,
  * audio/synthesis.py:91). */
@@ -242,9 +247,14 @@ int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_worker
 /* Diagnostic: one GEMM / conv1d launch on device buffers (A [M][Cin] rows of sequences of length T, Wt [N][ktaps*Cin]). */
 int tts_debug_gemm(tts_handle_t h, const float* A, const float* Wt, float* C, int M, int N, int Cin, int ktaps, int T,
                    int pool);
-/* Diagnostic: keep n_wgs workgroup slots of lds_kb KB LDS busy for ms milliseconds on a private stream. */
+/* Diagnostic (needs the option "debug_hooks" = 1 on the handle): keep n_wgs workgroup slots of lds_kb KB LDS busy for ms
+ * milliseconds on a private stream. */
 int tts_debug_hold(tts_handle_t h, int n_wgs, int lds_kb, double ms);
 int tts_profile_get(tts_handle_t h, const char* stage, float* ms_total, int64_t* launches);
+/* The UUID of the handle's device as 32 hex digits + NUL (hipDeviceGetUuid) and its compute-unit count: what the
+ * multi-GPU bench compares across ranks (no two ranks of one node on the same device; no reference counterpart --
+ * the reference is a one-process TensorFlow session, tacotron/inference.py:44-55). */
+int tts_device_info(tts_handle_t h, char uuid_hex[33], int* n_compute_units);
 
 #ifdef __cplusplus
 }

@@ -98,6 +98,7 @@ _PROTOTYPES = {
     'tts_debug_hold': (c_int, [c_void_p, c_int, c_int, ctypes.c_double]),
     'tts_debug_gemm': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
     'tts_debug_gl_plan': (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    'tts_device_info': (c_int, [c_void_p, c_char_p, POINTER(c_int)]),
 }
 
 _lib = None
@@ -462,6 +463,13 @@ class Engine(object):
     # ------------------------------------------------------------------ profiling / debug
     def profile_reset(self):
         self._check(self.lib.tts_profile_reset(self.handle))
+
+    def device_info(self):
+        """(uuid as 32 hex digits, compute units) of the handle's device"""
+        buf = ctypes.create_string_buffer(33)
+        n = c_int()
+        self._check(self.lib.tts_device_info(self.handle, buf, byref(n)))
+        return buf.value.decode(), n.value
 
     def profile_get(self, stage):
         ms = c_float()

@@ -102,7 +102,13 @@ struct tts_handle_s {
     int gl_pair = 3;                 // Griffin-Lim iterations per launch (1..3) where nothing per-iteration is asked for
     int n_cus_dev = 0;
     bool pd_configured = false;
-    int pd_debug_delay = 0;   // tests only (tts_set_option "pd_debug_delay"): PdParams::dbg_delay
+    // Test / diagnostic hooks, all per handle and all inert unless the option "debug_hooks" has been set to 1 on THIS handle
+    // (include/sstts_hip.h): nothing in the environment and no other handle can change what a call computes.
+    int debug_hooks = 0;
+    int pd_debug_delay = 0;   // PdParams::dbg_delay: workgroup 3 of every decoder cluster stages late
+    int gl_runs = 0;          // Griffin-Lim run cut: runs per utterance (0 = planned)
+    int gl_run_len = 0;       // ... or frames per full run (0 = planned)
+    int timeline = 0;         // print the absolute stage times of every profiled span (prof_collect)
     bool pd_used = false;            // a persistent launch has been enqueued since the last status check
     unsigned* pd_sync = nullptr;     // counters + status word of the last persistent launch
     int pd_clusters = 0;
@@ -629,7 +635,7 @@ struct ProfScope {
 
 void prof_collect(tts_handle_t h) {
     sync_all(h);
-    if (!h->spans.empty() && getenv("SSTTS_TIMELINE")) {   // diagnostic: absolute stage times of every span
+    if (!h->spans.empty() && h->debug_hooks && h->timeline) {   // diagnostic (option "timeline"): absolute stage times of every span
         for (auto& s : h->spans) {
             float t0 = 0.f, t1 = 0.f;
             if (hipEventElapsedTime(&t0, h->spans[0].a, s.a) == hipSuccess &&
@@ -948,7 +954,8 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     int per_launch = h->gl_pair;
     per_launch = per_launch < 1 ? 1 : (per_launch > 3 ? 3 : per_launch);
     while (per_launch > 1 && gl_stream_ring_frames(win, hop, per_launch) <= 0) --per_launch;
-    gl_plan_stream(p, n_cus - held > 16 ? n_cus - held : n_cus, per_launch);
+    gl_plan_stream(p, n_cus - held > 16 ? n_cus - held : n_cus, per_launch, h->debug_hooks ? h->gl_runs : 0,
+                   h->debug_hooks ? h->gl_run_len : 0);
     const int nchunks = p.slots_per_utt;
     WS(h, "gl.mse_partial", float, (size_t)B * nchunks, msep);
     // one zeroed work counter per launch (the persistent workgroups draw their item ids from it)
@@ -1210,7 +1217,16 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     else if (!std::strcmp(key, "fused_tail")) h->fused_tail = value;
     else if (!std::strcmp(key, "persistent_decoder")) h->persistent_decoder = value;
     else if (!std::strcmp(key, "gl_pair")) h->gl_pair = value;
-    else if (!std::strcmp(key, "pd_debug_delay")) h->pd_debug_delay = value;   // tests only (decoder_persistent.hip), per handle
+    else if (!std::strcmp(key, "debug_hooks")) h->debug_hooks = value;
+    else if (!std::strcmp(key, "pd_debug_delay") || !std::strcmp(key, "gl_runs") || !std::strcmp(key, "gl_run_len") ||
+             !std::strcmp(key, "timeline")) {
+        if (!h->debug_hooks && value != 0)
+            return fail(h, TTS_ERR_INVALID, std::string(key) + ": a test hook; set the option \"debug_hooks\" to 1 on this handle first");
+        if (!std::strcmp(key, "pd_debug_delay")) h->pd_debug_delay = value;
+        else if (!std::strcmp(key, "gl_runs")) h->gl_runs = value;
+        else if (!std::strcmp(key, "gl_run_len")) h->gl_run_len = value;
+        else h->timeline = value;
+    }
     else if (!std::strcmp(key, "reserve_cus")) {
         h->reserve_cus = value;
     } else if (!std::strcmp(key, "hold_lds_kb")) {
@@ -1551,7 +1567,7 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
         if (pd_sync != h->pd_sync || clusters != h->pd_clusters)   // new buffer / new layout: the sticky status word starts clean
             HIPCHK(h, hipMemsetAsync(pd_sync + 64 * clusters + 1, 0, sizeof(unsigned), h->stream));
         HIPCHK(h, decoder_persistent_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, alignments, pd_sync,
-                                             h->cur_hold_flag, c.force_cudnn, h->pd_debug_delay));
+                                             h->cur_hold_flag, c.force_cudnn, h->debug_hooks ? h->pd_debug_delay : 0));
         h->pd_sync = pd_sync;
         h->pd_clusters = clusters;
         h->pd_used = true;
@@ -2035,9 +2051,19 @@ int tts_wait_host(tts_handle_t h, int ticket, const float** wav_host, size_t* n_
     const int par = ticket & 1;
     HIPCHK(h, hipEventSynchronize(io.ev_d2h[par]));
     // the download is behind everything the call launched: a timed-out persistent kernel must not pass for a result
-    if (io.status_pinned[2 * par + 1])
-        return fail(h, TTS_ERR_HIP, "persistent decoder: a wait for the cluster timed out; the outputs of that call are invalid -- "
-                                     "tts_set_option(h, \"persistent_decoder\", 0) selects the launch-per-layer path");
+    if (io.status_pinned[2 * par + 1]) {
+        // what check_status does at a synchronisation: the sticky device word is cleared (behind the downloads already
+        // queued: a call in flight behind this one may still be reported once, conservatively), the handle leaves the
+        // persistent path by itself and stops carrying the word along
+        io.status_pinned[2 * par + 1] = 0;
+        if (h->pd_sync) HIPCHK(h, hipMemsetAsync(h->pd_sync + 64 * h->pd_clusters + 1, 0, sizeof(int), io.out));
+        h->persistent_decoder = 0;
+        h->pd_used = false;
+        return fail(h, TTS_ERR_HIP,
+                    "persistent decoder: a workgroup waited for its cluster longer than the bound (not all "
+                    "workgroups were co-resident); the outputs of that call are invalid -- the handle has "
+                    "switched to the launch-per-layer path (tts_set_option(h, \"persistent_decoder\", 1) switches back)");
+    }
     *wav_host = io.wav_pinned[par];
     if (n_floats) *n_floats = io.n_floats[par];
     return TTS_OK;
@@ -2098,6 +2124,7 @@ int tts_debug_gemm(tts_handle_t h, const float* A, const float* Wt, float* C, in
 int tts_debug_hold(tts_handle_t h, int n_wgs, int lds_kb, double ms) {
     DeviceScope dev_scope(h);
     if (!h || n_wgs < 1 || lds_kb < 1 || lds_kb > 160) return TTS_ERR_INVALID;
+    if (!h->debug_hooks) return fail(h, TTS_ERR_INVALID, "tts_debug_hold: a diagnostic; set the option \"debug_hooks\" to 1 on this handle first");
     static hipStream_t dbg = nullptr;
     static int* never = nullptr;
     static std::mutex dbg_mutex;
@@ -2134,6 +2161,23 @@ int tts_profile_get(tts_handle_t h, const char* stage, float* ms_total, int64_t*
             return TTS_OK;
         }
     return fail(h, TTS_ERR_INVALID, std::string("unknown stage ") + stage);
+}
+
+int tts_device_info(tts_handle_t h, char uuid_hex[33], int* n_compute_units) {
+    DeviceScope dev_scope(h);
+    if (!h) return TTS_ERR_INVALID;
+    if (uuid_hex) {
+        hipUUID id;
+        HIPCHK(h, hipDeviceGetUuid(&id, h->device));
+        static const char* hex = "0123456789abcdef";
+        for (int i = 0; i < 16; ++i) {
+            uuid_hex[2 * i] = hex[((unsigned char)id.bytes[i]) >> 4];
+            uuid_hex[2 * i + 1] = hex[((unsigned char)id.bytes[i]) & 15];
+        }
+        uuid_hex[32] = 0;
+    }
+    if (n_compute_units) *n_compute_units = h->n_cus_dev;
+    return TTS_OK;
 }
 
 }  // extern "C"

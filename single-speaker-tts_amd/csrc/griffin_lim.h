@@ -44,7 +44,7 @@ struct GlParams {
 void gl_build_wlane(const float* window, const float* rwss, int win, int hop, int T, float* out);
 // streaming form of the iteration / final iSTFT (gl_stream_kernel): no chunks, a run is one stream through an LDS ring
 int gl_stream_ring_frames(int win, int hop, int n_stage = 1);   // 0: the window / hop pair does not fit
-void gl_plan_stream(GlParams& p, int n_workers, int n_stage = 1);  // needs T, B, win, hop, ncol; sets the item classes (cut for launches of n_stage iterations)
+void gl_plan_stream(GlParams& p, int n_workers, int n_stage = 1, int force_runs = 0, int force_run_len = 0);  // needs T, B, win, hop, ncol; sets the item classes (cut for launches of n_stage iterations)
 hipError_t launch_gl_stream(hipStream_t s, const GlParams& p, int n_cus, int final_istft, int n_stage = 1);
 hipError_t gl_configure();
 hipError_t launch_gl_mse_reduce(hipStream_t s, const float* partial, int B, int nchunks, float denom, float* mse);

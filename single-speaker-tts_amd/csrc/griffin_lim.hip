@@ -1000,7 +1000,7 @@ size_t gl_stream_lds_bytes(const GlParams& p) {
 // Work items of the streaming form: every utterance is cut into nr runs of (almost) equal length, a multiple of the
 // eight waves; a run costs its frames plus the 2 halo indices that are only inverse-transformed plus a constant for
 // filling and draining the stream.  nr is chosen by simulating the list schedule on the workgroups that really run.
-void gl_plan_stream(GlParams& p, int n_workers, int n_stage) {
+void gl_plan_stream(GlParams& p, int n_workers, int n_stage, int force_runs, int force_run_len) {
     const int halo = p.ncol - 1;
     n_stage = n_stage < 1 ? 1 : (n_stage > 3 ? 3 : n_stage);
     // ONE cut for all launches of a call (single and double iterations alike: the overlap-add order, hence the waveform
@@ -1009,20 +1009,17 @@ void gl_plan_stream(GlParams& p, int n_workers, int n_stage) {
     struct Cut { int L, n_full, rem; };
     Cut best{p.T, 1, 0};
     bool forced = false;
-    if (const char* ov = getenv("SSTTS_GL_RUNS")) {   // experiments: runs per utterance
-        const int nr = atoi(ov);
-        if (nr >= 1 && nr <= p.T) {
-            const int L = ((p.T + nr - 1) / nr + GL_NW - 1) / GL_NW * GL_NW;
-            best = Cut{L, p.T / L, p.T - (p.T / L) * L};
-            forced = true;
-        }
+    // tests / experiments only (per-handle options "gl_runs" / "gl_run_len" behind "debug_hooks", api.hip): a forced cut.
+    // Nothing in the process environment reaches this function: the cut is part of the waveform's bits.
+    if (force_runs >= 1 && force_runs <= p.T) {   // runs per utterance
+        const int L = ((p.T + force_runs - 1) / force_runs + GL_NW - 1) / GL_NW * GL_NW;
+        best = Cut{L, p.T / L, p.T - (p.T / L) * L};
+        forced = true;
     }
-    if (const char* ov = getenv("SSTTS_GL_RUN_LEN")) {   // experiments: frames per (full) run
-        const int L = atoi(ov) / GL_NW * GL_NW;
-        if (L >= GL_NW) {
-            best = Cut{L, p.T / L, p.T - (p.T / L) * L};
-            forced = true;
-        }
+    if (force_run_len >= GL_NW) {   // frames per (full) run
+        const int L = force_run_len / GL_NW * GL_NW;
+        best = Cut{L, p.T / L, p.T - (p.T / L) * L};
+        forced = true;
     }
     if (!forced) {
         static std::map<std::vector<int>, Cut> cache;

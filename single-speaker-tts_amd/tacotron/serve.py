@@ -38,9 +38,15 @@ def post_process_spectrograms(_spectrograms, engine, init_phase=None, seed=0):
     return [wav[b] for b in range(wav.shape[0])]
 
 
-def serve(sentence_generator, weights, dataset=None, device_id=0, pipelined=True):
+def serve(sentence_generator, weights, dataset=None, device_id=0, pipelined=False):
     """Generator: for each batch of raw sentences yield the list of synthesized waveforms
-    (reference tacotron/serve.py:89-126, with the SavedModel session replaced by the engine)."""
+    (reference tacotron/serve.py:89-126, with the SavedModel session replaced by the engine).
+
+    Default: the reference's request/response order -- every batch is answered before the next one is pulled from
+    ``sentence_generator`` (reference serve.py:108-124 blocks on a live generator, and a client may wait for its answer
+    before it sends more).  ``pipelined=True`` keeps two batches in flight for OFFLINE streams whose batches are all
+    available: batch k is then yielded only after batch k + 1 has been pulled from the generator (the last one when the
+    generator ends), which on a request-driven generator would hold every answer back by one request."""
     from ..datasets.lj_speech import LJSpeechDatasetHelper
     dataset = dataset or LJSpeechDatasetHelper(dataset_folder=dataset_params.dataset_folder,
                                                 char_dict=dataset_params.vocabulary_dict, fill_dict=False)

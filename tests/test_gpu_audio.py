@@ -187,13 +187,15 @@ def test_griffin_lim_forced_run_cuts(engine, run_len, per_launch, n_iter, want_m
     mag = synth_mag(rng, B, T)
     init = rng.random(mag.shape).astype(np.float32)
     engine.set_option('gl_pair', per_launch)
-    os.environ['SSTTS_GL_RUN_LEN'] = str(run_len)
+    engine.set_option('debug_hooks', 1)
+    engine.set_option('gl_run_len', run_len)
     try:
         wav, mse = engine.griffin_lim(mag, n_iter, WIN, HOP, N_FFT, init_phase=init, want_mse=want_mse)
         wav = wav.to_host()
         mse = mse.to_host() if want_mse else None
     finally:
-        del os.environ['SSTTS_GL_RUN_LEN']
+        engine.set_option('gl_run_len', 0)
+        engine.set_option('debug_hooks', 0)
         engine.set_option('gl_pair', 3)
     for b in range(B):
         ref_wav, ref_mse = A.griffin_lim_v2(mag[b], WIN, HOP, N_FFT, n_iter, init_phase=init[b])

@@ -103,12 +103,14 @@ def test_persistent_cudnn_decoder_with_a_late_stager(cudnn_setup, B, Ts, S, dela
         mel1, al1 = eng.decoder_forward(memory, S)
         eng.synchronize()
         mel1, al1 = mel1.to_host(), al1.to_host()
+        eng.set_option('debug_hooks', 1)
         eng.set_option('pd_debug_delay', delay)
         mel2, al2 = eng.decoder_forward(memory, S)
         eng.synchronize()
         mel2, al2 = mel2.to_host(), al2.to_host()
     finally:
         eng.set_option('pd_debug_delay', 0)
+        eng.set_option('debug_hooks', 0)
         eng.set_option('persistent_decoder', 1)
     print('cudnn persistent vs launch path: mel rel-L2 {:.3e}; late stager vs undelayed: equal = {}'.format(
         rel_l2(mel1, mel0), np.array_equal(mel1, mel2)))

@@ -14,6 +14,7 @@ mel, al = eng.decoder_forward(mem, 200)
 eng.synchronize()
 for hold, lds in [(0, 0), (224, 152), (228, 152), (248, 100)]:
     if hold:
+        eng.set_option('debug_hooks', 1)
         eng._check(eng.lib.tts_debug_hold(eng.handle, hold, lds, 80.0))
         time.sleep(0.005)
     t0 = time.perf_counter()
