@@ -212,7 +212,11 @@ typedef struct tts_synth_params {
     int32_t win_length, hop_length;  /* 1102, 275 */
     uint64_t seed;          /* random initial phase when init_phase == NULL */
     int32_t peak_normalize; /* save_wav(norm=True) */
+    int32_t host_outputs;   /* tts_synthesize_host only: TTS_HOST_* flags of what travels to host memory besides the
+                               waveforms (0 = nothing); ignored by tts_synthesize, whose optional outputs are pointers */
 } tts_synth_params_t;
+#define TTS_HOST_LINEAR 1       /* linear spectrograms [B*T*F]: what the reference's inference() hands back (tacotron/inference.py:75-101) */
+#define TTS_HOST_ALIGNMENTS 2   /* alignments [n_steps*B*Ts] (tacotron/model.py:552-598 dumps them) */
 int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_synth_params_t* p,
                    const float* init_phase /* [B*F*T] or NULL */, float* wav, float* mel,
                    float* alignments, float* linear);
@@ -229,6 +233,12 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
 int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, const tts_synth_params_t* p,
                         int* ticket);
 int tts_wait_host(tts_handle_t h, int ticket, const float** wav_host, size_t* n_floats);
+/* The optional outputs of the same call (p->host_outputs), in pinned memory of the handle with the lifetime of the
+ * waveform buffer: linear spectrograms [B][T][F] as the network emits them (normalised dB, before the de-normalisation),
+ * alignments [n_steps][B][Ts].  Pointers are NULL / counts 0 for outputs the call did not ask for.  Waits like
+ * tts_wait_host (and reports what it reports); the waveforms are fetched with tts_wait_host itself. */
+int tts_wait_host_outputs(tts_handle_t h, int ticket, const float** linear_host, size_t* n_linear, const float** align_host,
+                          size_t* n_align);
 
 /* ---- profiling -------------------------------------------------------------------------- */
 /* With option "profile"=1 the library brackets its stages with HIP events on the handle's

@@ -51,7 +51,7 @@ class TtsSynthParams(ctypes.Structure):
     _fields_ = [
         ('n_steps', c_int32), ('ref_db', c_float), ('max_db', c_float), ('power', c_float),
         ('n_iter', c_int32), ('win_length', c_int32), ('hop_length', c_int32), ('seed', c_uint64),
-        ('peak_normalize', c_int32),
+        ('peak_normalize', c_int32), ('host_outputs', c_int32),
     ]
 
 
@@ -92,6 +92,7 @@ _PROTOTYPES = {
                                c_void_p, c_void_p, c_void_p]),
     'tts_synthesize_host': (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(TtsSynthParams), POINTER(c_int)]),
     'tts_wait_host': (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_size_t)]),
+    'tts_wait_host_outputs': (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_void_p), POINTER(c_size_t)]),
     'tts_profile_reset': (c_int, [c_void_p]),
     'tts_profile_get': (c_int, [c_void_p, c_char_p, POINTER(c_float), POINTER(c_int64)]),
     'tts_debug_workspace': (c_int, [c_void_p, c_char_p, POINTER(c_void_p), POINTER(c_size_t)]),
@@ -404,19 +405,37 @@ class Engine(object):
         return dict(wav=wav, mel=mel, alignments=ali, linear=lin)
 
     def synthesize_host(self, ids, n_steps, ref_db, max_db, power, n_iter, win_length, hop_length, seed=0,
-                        peak_normalize=True):
+                        peak_normalize=True, want_linear=False, want_alignments=False):
         """Asynchronous end-to-end call on HOST ids (int32 (B, T_sent)): returns a ticket at once; the upload, the
         network, Griffin-Lim and the download of the waveforms into pinned memory overlap with the neighbouring
         calls.  Keep at most two calls in flight: submit k + 1, then ``wait_host(ticket_k)``."""
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         self._check_ids(ids)
         B, Ts = ids.shape
-        sp = TtsSynthParams(n_steps, ref_db, max_db, power, n_iter, win_length, hop_length, seed, 1 if peak_normalize else 0)
+        sp = TtsSynthParams(n_steps, ref_db, max_db, power, n_iter, win_length, hop_length, seed, 1 if peak_normalize else 0,
+                            (1 if want_linear else 0) | (2 if want_alignments else 0))
         t = c_int(-1)
         self._check(self.lib.tts_synthesize_host(self.handle, ids.ctypes.data, B, Ts, byref(sp), byref(t)))
         self._host_shapes = getattr(self, '_host_shapes', {})
         self._host_shapes[t.value] = (B, hop_length * (n_steps * self.cfg.reduction - 1))
+        self._host_out_shapes = getattr(self, '_host_out_shapes', {})
+        self._host_out_shapes[t.value] = ((B, n_steps * self.cfg.reduction, 1 + self.cfg.n_fft // 2), (n_steps, B, Ts))
         return t.value
+
+    def wait_host_outputs(self, ticket, copy=True):
+        """(linear (B, T, F) or None, alignments (n_steps, B, Ts) or None) of a ``synthesize_host`` call made with
+        ``want_linear`` / ``want_alignments``; views of pinned buffers with the waveform buffer's lifetime unless ``copy``.
+        Call it BEFORE ``wait_host`` of the same ticket or keep the shapes yourself (it does not consume the ticket)."""
+        pl, pa = c_void_p(), c_void_p()
+        nl, na = c_size_t(0), c_size_t(0)
+        self._check(self.lib.tts_wait_host_outputs(self.handle, int(ticket), byref(pl), byref(nl), byref(pa), byref(na)))
+        shl, sha = self._host_out_shapes.pop(ticket, ((nl.value,), (na.value,)))
+        lin = np.ctypeslib.as_array(ctypes.cast(pl, POINTER(c_float)), shape=(nl.value,)).reshape(shl) if nl.value else None
+        ali = np.ctypeslib.as_array(ctypes.cast(pa, POINTER(c_float)), shape=(na.value,)).reshape(sha) if na.value else None
+        if copy:
+            lin = None if lin is None else lin.copy()
+            ali = None if ali is None else ali.copy()
+        return lin, ali
 
     def wait_host(self, ticket, copy=True):
         """Waveforms (B, hop*(T-1)) float32 of a ``synthesize_host`` call.  ``copy=False`` returns a view of the library's

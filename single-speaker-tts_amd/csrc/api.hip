@@ -131,6 +131,14 @@ struct tts_handle_s {
         hipEvent_t ev_d2h[2] = {nullptr, nullptr};      // waveforms have arrived in pinned memory
         bool d2h_pending[2] = {false, false}, enc_pending[2] = {false, false};
         size_t n_floats[2] = {0, 0};
+        // optional outputs of a host call (tts_synth_params_t::host_outputs): linear spectrograms and alignments
+        float* lin_dev[2] = {nullptr, nullptr};
+        float* lin_pinned[2] = {nullptr, nullptr};
+        size_t lin_bytes = 0;
+        float* ali_dev[2] = {nullptr, nullptr};
+        float* ali_pinned[2] = {nullptr, nullptr};
+        size_t ali_bytes = 0;
+        size_t n_lin[2] = {0, 0}, n_ali[2] = {0, 0};
         int* status_pinned = nullptr;   // [2][2]: the persistent decoder's sticky status word ([.][1]) as it stood behind
                                         // each call's download
         int tickets = 0;
@@ -1163,6 +1171,10 @@ int tts_destroy(tts_handle_t h) {
         if (h->hio.ids_dev[i]) hipFree(h->hio.ids_dev[i]);
         if (h->hio.wav_pinned[i]) hipHostFree(h->hio.wav_pinned[i]);
         if (h->hio.wav_dev[i]) hipFree(h->hio.wav_dev[i]);
+        if (h->hio.lin_pinned[i]) hipHostFree(h->hio.lin_pinned[i]);
+        if (h->hio.lin_dev[i]) hipFree(h->hio.lin_dev[i]);
+        if (h->hio.ali_pinned[i]) hipHostFree(h->hio.ali_pinned[i]);
+        if (h->hio.ali_dev[i]) hipFree(h->hio.ali_dev[i]);
         if (h->hio.ev_h2d[i]) hipEventDestroy(h->hio.ev_h2d[i]);
         if (h->hio.ev_enc[i]) hipEventDestroy(h->hio.ev_enc[i]);
         if (h->hio.ev_ready[i]) hipEventDestroy(h->hio.ev_ready[i]);
@@ -1970,6 +1982,9 @@ int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, 
     const int T = sp->n_steps * h->cfg.reduction;
     const size_t ids_bytes = (size_t)B * Ts * sizeof(int32_t);
     const size_t n_wav = (size_t)B * sp->hop_length * (size_t)(T - 1);
+    const bool want_lin = (sp->host_outputs & TTS_HOST_LINEAR) != 0, want_ali = (sp->host_outputs & TTS_HOST_ALIGNMENTS) != 0;
+    const size_t n_lin = want_lin ? (size_t)B * T * (size_t)(1 + h->cfg.n_fft / 2) : 0;
+    const size_t n_ali = want_ali ? (size_t)sp->n_steps * B * Ts : 0;
     if (!io.in) {
         // The copy streams get the LOWEST priority: streams of one priority share a few hardware queues in creation order
         // (whatever else the process has created counts), and a copy stream that lands on the main stream's queue holds the
@@ -1986,7 +2001,8 @@ int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, 
         }
         HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&io.status_pinned), 4 * sizeof(int), hipHostMallocDefault));
     }
-    if (ids_bytes > io.ids_bytes || n_wav * sizeof(float) > io.wav_bytes) {
+    if (ids_bytes > io.ids_bytes || n_wav * sizeof(float) > io.wav_bytes || n_lin * sizeof(float) > io.lin_bytes ||
+        n_ali * sizeof(float) > io.ali_bytes) {
         // growing the buffers: nothing of an earlier call may be in flight
         if ((rc = sync_all(h))) return rc;
         HIPCHK(h, hipStreamSynchronize(io.in));
@@ -2004,10 +2020,24 @@ int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, 
                 HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&io.wav_pinned[i]), n_wav * sizeof(float), hipHostMallocDefault));
                 HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&io.wav_dev[i]), n_wav * sizeof(float)));
             }
+            if (n_lin * sizeof(float) > io.lin_bytes) {
+                if (io.lin_pinned[i]) HIPCHK(h, hipHostFree(io.lin_pinned[i]));
+                if (io.lin_dev[i]) HIPCHK(h, hipFree(io.lin_dev[i]));
+                HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&io.lin_pinned[i]), n_lin * sizeof(float), hipHostMallocDefault));
+                HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&io.lin_dev[i]), n_lin * sizeof(float)));
+            }
+            if (n_ali * sizeof(float) > io.ali_bytes) {
+                if (io.ali_pinned[i]) HIPCHK(h, hipHostFree(io.ali_pinned[i]));
+                if (io.ali_dev[i]) HIPCHK(h, hipFree(io.ali_dev[i]));
+                HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&io.ali_pinned[i]), n_ali * sizeof(float), hipHostMallocDefault));
+                HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&io.ali_dev[i]), n_ali * sizeof(float)));
+            }
             io.d2h_pending[i] = io.enc_pending[i] = false;
         }
         io.ids_bytes = std::max(io.ids_bytes, ids_bytes);
         io.wav_bytes = std::max(io.wav_bytes, n_wav * sizeof(float));
+        io.lin_bytes = std::max(io.lin_bytes, n_lin * sizeof(float));
+        io.ali_bytes = std::max(io.ali_bytes, n_ali * sizeof(float));
     }
     const int t = io.tickets++;
     const int par = t & 1;
@@ -2021,7 +2051,9 @@ int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, 
     if (io.d2h_pending[par]) HIPCHK(h, hipStreamWaitEvent(h->stream, io.ev_d2h[par], 0));
     h->input_event = io.ev_h2d[par];
     h->enc_done_event = io.ev_enc[par];
-    rc = tts_synthesize(h, io.ids_dev[par], B, Ts, sp, nullptr, io.wav_dev[par], nullptr, nullptr, nullptr);
+    // (the optional outputs of this parity were last read by the download of the call two back: same event as the waveforms)
+    rc = tts_synthesize(h, io.ids_dev[par], B, Ts, sp, nullptr, io.wav_dev[par], nullptr, want_ali ? io.ali_dev[par] : nullptr,
+                        want_lin ? io.lin_dev[par] : nullptr);
     h->input_event = nullptr;
     h->enc_done_event = nullptr;
     if (rc) return rc;
@@ -2029,6 +2061,10 @@ int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, 
     HIPCHK(h, hipEventRecord(io.ev_ready[par], h->stream));
     HIPCHK(h, hipStreamWaitEvent(io.out, io.ev_ready[par], 0));
     HIPCHK(h, hipMemcpyAsync(io.wav_pinned[par], io.wav_dev[par], n_wav * sizeof(float), hipMemcpyDeviceToHost, io.out));
+    if (want_lin) HIPCHK(h, hipMemcpyAsync(io.lin_pinned[par], io.lin_dev[par], n_lin * sizeof(float), hipMemcpyDeviceToHost, io.out));
+    if (want_ali) HIPCHK(h, hipMemcpyAsync(io.ali_pinned[par], io.ali_dev[par], n_ali * sizeof(float), hipMemcpyDeviceToHost, io.out));
+    io.n_lin[par] = n_lin;
+    io.n_ali[par] = n_ali;
     // the sticky status words of the persistent kernels travel with the waveforms (tts_wait_host must not wait for
     // anything but this call: a stream synchronisation there would wait for the NEXT call's download as well)
     io.status_pinned[2 * par] = io.status_pinned[2 * par + 1] = 0;
@@ -2066,6 +2102,22 @@ int tts_wait_host(tts_handle_t h, int ticket, const float** wav_host, size_t* n_
     }
     *wav_host = io.wav_pinned[par];
     if (n_floats) *n_floats = io.n_floats[par];
+    return TTS_OK;
+}
+
+int tts_wait_host_outputs(tts_handle_t h, int ticket, const float** linear_host, size_t* n_linear, const float** align_host,
+                          size_t* n_align) {
+    DeviceScope dev_scope(h);
+    if (!h) return TTS_ERR_INVALID;
+    const float* wav = nullptr;
+    const int rc = tts_wait_host(h, ticket, &wav, nullptr);   // same event, same checks (ticket range, decoder status)
+    if (rc) return rc;
+    auto& io = h->hio;
+    const int par = ticket & 1;
+    if (linear_host) *linear_host = io.n_lin[par] ? io.lin_pinned[par] : nullptr;
+    if (n_linear) *n_linear = io.n_lin[par];
+    if (align_host) *align_host = io.n_ali[par] ? io.ali_pinned[par] : nullptr;
+    if (n_align) *n_align = io.n_ali[par];
     return TTS_OK;
 }
 

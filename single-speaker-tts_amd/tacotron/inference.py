@@ -65,12 +65,18 @@ def synthesize_batch(model, sentences, n_steps=None, n_iter=None, init_phase=Non
     return out['wav'].to_host()
 
 
-def synthesize_stream(model, batches, n_steps=None, n_iter=None, seed=0, peak_normalize=False, copy=False):
+def synthesize_stream(model, batches, n_steps=None, n_iter=None, seed=0, peak_normalize=False, copy=False, want_linear=False,
+                      want_alignments=False):
     """Generator over batches of padded id sequences (each (B, T_sent) int32, HOST arrays) -> per batch the waveforms
     (B, hop*(T-1)) float32 in host memory, with TWO batches in flight: batch k + 1 is uploaded and its encoder /
     decoder run while batch k is in its post-net / Griffin-Lim and batch k - 1 is being downloaded (the reference
     runs the batches one after the other, tacotron/inference.py:75-101,185-200).  The arrays yielded are views of the
-    library's pinned buffers unless ``copy``: valid until the next-but-one batch has been requested."""
+    library's pinned buffers unless ``copy``: valid until the next-but-one batch has been requested.
+
+    With ``want_linear`` / ``want_alignments`` every item is a tuple ``(wavs, linear, alignments)``: the normalised linear
+    spectrograms (B, T, 1025) -- what ``model.output_linear_spec`` is, the thing the reference's ``inference()`` fetches
+    (:75-92) -- and the alignments (n_steps, B, T_sent) of the same call, downloaded behind the waveforms (None where not
+    asked for)."""
     hp = model.hparams
     loader = dataset_params.dataset_loader
     win_len = ms_to_samples(hp.win_len, hp.sampling_rate)
@@ -78,15 +84,45 @@ def synthesize_stream(model, batches, n_steps=None, n_iter=None, seed=0, peak_no
     S = n_steps or model.n_steps()
     it = hp.reconstruction_iterations if n_iter is None else n_iter
     eng = model.engine
+    extra = want_linear or want_alignments
+
+    def collect(ticket):
+        if not extra:
+            return eng.wait_host(ticket, copy=copy)
+        lin, ali = eng.wait_host_outputs(ticket, copy=copy)
+        return eng.wait_host(ticket, copy=copy), lin, ali
+
     pending = None
     for k, ids in enumerate(batches):
         t = eng.synthesize_host(ids, S, loader.mel_mag_ref_db, loader.mel_mag_max_db, hp.magnitude_power, it, win_len,
-                                win_hop, seed=seed + k, peak_normalize=peak_normalize)
+                                win_hop, seed=seed + k, peak_normalize=peak_normalize, want_linear=want_linear,
+                                want_alignments=want_alignments)
         if pending is not None:
-            yield eng.wait_host(pending, copy=copy)
+            yield collect(pending)
         pending = t
     if pending is not None:
-        yield eng.wait_host(pending, copy=copy)
+        yield collect(pending)
+
+
+def inference_stream(model, batches, n_steps=None, n_iter=None, seed=0):
+    """``inference()`` over a stream of batches with two calls in flight: per batch ``(spectrograms, waveforms)`` where
+    ``spectrograms`` is what the reference's ``inference()`` returns for that batch -- per utterance the (1025, T) linear
+    magnitude spectrogram ``decibel_to_magnitude(inv_normalize_decibel(spec.T, mel_ref_db, mel_max_db))``
+    (tacotron/inference.py:93-101; computed on the host from the downloaded network output with the conversions of
+    ``audio.conversion``) -- and ``waveforms`` the Griffin-Lim reconstructions the reference's ``__main__`` makes of them
+    (:170-188)."""
+    loader = dataset_params.dataset_loader
+    ref_db, max_db = np.float32(loader.mel_mag_ref_db), np.float32(loader.mel_mag_max_db)
+    rng_db = np.float32(abs(float(ref_db)) + abs(float(max_db)))
+    for wavs, lin, _ in synthesize_stream(model, batches, n_steps=n_steps, n_iter=n_iter, seed=seed, copy=True, want_linear=True):
+        specs = []
+        for b in range(lin.shape[0]):
+            # inv_normalize_decibel, decibel_to_magnitude (reference audio/conversion.py:81-102, 32-53) in host arithmetic:
+            # the device versions of audio.conversion would synchronise the stream that the next batch is running on
+            db = (np.clip(lin[b].T, np.float32(0), np.float32(1)) - np.float32(1)) * rng_db + ref_db
+            assert not (db < -100.0).any(), 'decibel_to_magnitude: values below -100 dB'
+            specs.append(np.power(np.float32(10), db / np.float32(20)).astype(np.float32))
+        yield specs, wavs
 
 
 def synthesize_sentences(raw_sentences, weights, dataset=None, out_dir=None, device_id=0, seed=0):

@@ -72,6 +72,14 @@ def test_bench_self_launches_n_ranks(tmp_path):
     rec = json.loads(line)
     assert rec['n_gpus'] == 2 and rec['world_size_seen'] == 2 and rec['ok'] is True
 
+    # the N > 1 diagnostics of the JSON line (bench.rank_fields), rehearsed on stand-in values: per-rank times with the
+    # straggler named, the first broadcast against the steady one, one device record per rank, the global padded length
+    assert rec['rank_ms_per_step'] == [1.0, 2.0] and rec['straggler_rank'] == 1
+    assert rec['rank_ms_per_step_min'] == 1.0 and rec['rank_ms_per_step_max'] == 2.0
+    assert rec['weight_broadcast_ms'] > 0 and rec['weight_broadcast_ms_steady'] > 0
+    assert [d['uuid'] for d in rec['rank_devices']] == ['selftest-rank0', 'selftest-rank1']
+    assert rec['padded_sentence_length'] == 150
+
 
 def test_bench_under_torch_distributed_run():
     """The driver's own launch line for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
@@ -94,3 +102,11 @@ def test_bench_under_torch_distributed_run():
     assert len(lines) == 1, out.stdout.decode()
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['world_size_seen'] == 2 and rec['ok'] is True
+
+    # the N > 1 diagnostics of the JSON line (bench.rank_fields), rehearsed on stand-in values: per-rank times with the
+    # straggler named, the first broadcast against the steady one, one device record per rank, the global padded length
+    assert rec['rank_ms_per_step'] == [1.0, 2.0] and rec['straggler_rank'] == 1
+    assert rec['rank_ms_per_step_min'] == 1.0 and rec['rank_ms_per_step_max'] == 2.0
+    assert rec['weight_broadcast_ms'] > 0 and rec['weight_broadcast_ms_steady'] > 0
+    assert [d['uuid'] for d in rec['rank_devices']] == ['selftest-rank0', 'selftest-rank1']
+    assert rec['padded_sentence_length'] == 150

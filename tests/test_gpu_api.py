@@ -290,14 +290,33 @@ def test_host_facade_two_calls_in_flight_equals_serial_calls(engine, hparams):
     engine.synthesize(reset, *args, seed=1)
     got = [w.copy() for w in Inf.synthesize_stream(model, iter(batches), n_steps=S, n_iter=n_iter, seed=100, peak_normalize=True)]
     assert len(got) == len(batches)
+    # ... and with the linear spectrograms and the alignments of every call travelling to host memory behind its waveforms
+    # (tts_synth_params_t::host_outputs, tts_wait_host_outputs): what the reference's inference() hands back (inference.py:75-101)
+    engine.synthesize(reset, *args, seed=1)
+    got_x = [(w.copy(), l.copy(), a.copy()) for w, l, a in
+             Inf.synthesize_stream(model, iter(batches), n_steps=S, n_iter=n_iter, seed=100, peak_normalize=True,
+                                   want_linear=True, want_alignments=True)]
+    assert len(got_x) == len(batches)
     # the same calls on device-resident ids, each waited for before the next is made
     engine.synthesize(reset, *args, seed=1)
     for k, ids in enumerate(batches):
-        ref = engine.synthesize(engine.to_device(ids), *args, seed=100 + k, peak_normalize=True)
+        ref = engine.synthesize(engine.to_device(ids), *args, seed=100 + k, peak_normalize=True, want_linear=True, want_alignments=True)
         want = ref['wav'].to_host()
         assert got[k].shape == want.shape == (ids.shape[0], 275 * (S * hparams.reduction - 1))
         assert np.isfinite(got[k]).all() and np.abs(got[k]).max() > 0
         assert np.array_equal(got[k], want), k
+        w, lin, ali = got_x[k]
+        assert np.array_equal(w, want), k
+        assert lin.shape == (ids.shape[0], S * hparams.reduction, 1025) and np.array_equal(lin, ref['linear'].to_host()), k
+        assert ali.shape == (S, ids.shape[0], ids.shape[1]) and np.array_equal(ali, ref['alignments'].to_host()), k
+    # inference_stream: per batch what the reference's inference() returns (de-normalised (1025, T) magnitudes) and the waveforms
+    engine.synthesize(reset, *args, seed=1)
+    for k, (specs, wavs) in enumerate(Inf.inference_stream(model, iter(batches[:2]), n_steps=S, n_iter=n_iter, seed=100)):
+        one = Inf.inference(model, batches[k], n_steps=S)
+        assert len(specs) == len(one) == batches[k].shape[0]
+        for a, b in zip(specs, one):
+            assert a.shape == b.shape == (1025, S * hparams.reduction) and np.allclose(a, b, rtol=1e-5, atol=0)
+        assert wavs.shape[0] == batches[k].shape[0]
     # tickets of calls whose buffers have been handed on are refused
     sstts = pkg()
     with pytest.raises(sstts.TtsError):
