@@ -1511,8 +1511,9 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
     const tts_config_t& c = h->cfg;
     if (h->dec.local_d > 0 && Ts < 2 * h->dec.local_d + 1)
         return fail(h, TTS_ERR_UNSUPPORTED,
-                    "LocalLuongAttention: the memory must hold at least 2*D+1 positions (the reference's window "
-                    "padding for shorter inputs is not implemented)");
+                    "LocalLuongAttention: the memory must hold at least 2*D+1 positions (for shorter inputs the reference pads "
+                    "the window's 2D+1 alignments to 4D+2-T_s entries, tacotron/attention.py:294-299,85-92: its attention state "
+                    "changes shape and TensorFlow fails)");
     const int A = c.n_attention_units, U = c.n_decoder_gru_units, mem = 2 * c.n_gru_units;
     const int NL = c.n_decoder_gru_layers;
     WS(h, "dec.keys", float, (size_t)B * Ts * A, keys);

@@ -195,3 +195,68 @@ def test_cudnn_checkpoints_load_in_both_saved_forms(tmp_path):
     # the GRUCell configuration cannot take such a checkpoint: the error says why
     with pytest.raises(KeyError, match='force_cudnn'):
         C.load_checkpoint(str(tmp_path / 'opaque'), pkg('tacotron.params').ModelParams())
+
+
+# ---- byte-level known answer of the bundle layout: literal bytes, laid out by hand from the published formats (LevelDB
+# table_format.md; tensorflow/core/protobuf/tensor_bundle.proto; tensorflow/core/lib/io/table_builder.cc for what TensorFlow's
+# builder emits: restart interval 16, no compression, the index key a short successor of the block's last key, an empty
+# metaindex block, 48-byte footer).  tests/tf_bundle_writer.py has no part in it.
+_KAT_INDEX = bytes.fromhex(
+    # data block, entry 1: key "" -> BundleHeaderProto {num_shards: 1, version {producer: 1}}
+    '00' '00' '06'                               # shared 0, non-shared 0, value 6 bytes
+    '0801' '1a02' '0801'                         # field 1 varint 1; field 3 (VersionDef) len 2 {field 1 varint 1}
+    # entry 2: key "dense/bias" -> BundleEntryProto {dtype DT_FLOAT, shape [2], size 8, crc32c}
+    '00' '0a' '0f' '64656e73652f62696173'        # shared 0, non-shared 10, value 15 bytes, "dense/bias"
+    '0801' '1204' '1202' '0802' '2808' '35' '593ce535'   # dtype 1; shape{dim{size 2}}; size 8; masked crc32c (fixed32, LE)
+    # entry 3: key "dense/kernel": shares "dense/" (6 bytes) with its predecessor -> only "kernel" is stored
+    '06' '06' '15' '6b65726e656c'                # shared 6, non-shared 6, value 21 bytes
+    '0801' '1208' '1202' '0802' '1202' '0802' '2008' '2810' '35' '17be60c6'   # dtype 1; shape [2][2]; offset 8; size 16; crc
+    '00000000' '01000000'                        # restart array: one restart at offset 0; number of restarts
+    '00' '24ff6942'                              # block trailer: no compression; masked crc32c of block + type byte
+    # metaindex block: empty (one restart at 0) + trailer
+    '00000000' '01000000' '00' 'c0f2a1b0'
+    # index block: key "dense/l" (shortest successor of "dense/kernel") -> BlockHandle {offset 0, size 0x4b} + trailer
+    '00' '07' '02' '64656e73652f6c' '004b' '00000000' '01000000' '00' '1281424c'
+    # footer: metaindex handle {0x50, 8}, index handle {0x5d, 0x14}, zero padding to 40 bytes, magic 0xdb4775248b80fb57 (LE)
+    '5008' '5d14' + '00' * 36 + '57fb808b247547db')
+_KAT_DATA = bytes.fromhex('0000803f00000040' '0000003f000080bf0000404000008040')   # bias [1, 2]; kernel [[0.5, -1], [3, 4]]
+
+
+def test_bundle_layout_known_answer(tmp_path):
+    C = pkg('tacotron.checkpoint')
+    """The importer reads a bundle whose every byte is written out above: prefix-compressed keys, the block trailers' masked
+    CRC32Cs, the index block's successor key, the footer -- and rejects it when one payload byte or one index byte changes."""
+    assert len(_KAT_INDEX) == 166 and _KAT_INDEX[-8:] == bytes.fromhex('57fb808b247547db')
+    prefix = str(tmp_path / 'model.ckpt-7')
+    with open(prefix + '.index', 'wb') as f:
+        f.write(_KAT_INDEX)
+    with open(prefix + '.data-00000-of-00001', 'wb') as f:
+        f.write(_KAT_DATA)
+    got = C.read_tensor_bundle(prefix)
+    assert sorted(got) == ['dense/bias', 'dense/kernel']
+    assert got['dense/bias'].dtype == np.float32 and got['dense/bias'].tolist() == [1.0, 2.0]
+    assert got['dense/kernel'].shape == (2, 2) and got['dense/kernel'].tolist() == [[0.5, -1.0], [3.0, 4.0]]
+    # the masked CRC32C of the literal (what TensorFlow stores: rotate right 15, add 0xa282ead8): known answers of the entries
+    assert C.crc32c(_KAT_DATA[:8]) == C.unmask_crc(0x35e53c59) and C.crc32c(_KAT_DATA[8:]) == C.unmask_crc(0xc660be17)
+    # a flipped payload bit: the tensor's CRC32C no longer matches
+    bad = bytearray(_KAT_DATA)
+    bad[9] ^= 0x10
+    with open(prefix + '.data-00000-of-00001', 'wb') as f:
+        f.write(bytes(bad))
+    with pytest.raises(C.ChecksumError):
+        C.read_tensor_bundle(prefix)
+    assert C.read_tensor_bundle(prefix, verify=False)['dense/kernel'].shape == (2, 2)
+    # a flipped byte inside the data block of the index: the block trailer's CRC32C no longer matches
+    with open(prefix + '.data-00000-of-00001', 'wb') as f:
+        f.write(_KAT_DATA)
+    badi = bytearray(_KAT_INDEX)
+    badi[12] ^= 0x01
+    with open(prefix + '.index', 'wb') as f:
+        f.write(bytes(badi))
+    with pytest.raises(ValueError):
+        C.read_tensor_bundle(prefix)
+    # a wrong magic number is not a table
+    with open(prefix + '.index', 'wb') as f:
+        f.write(_KAT_INDEX[:-1] + b'\x00')
+    with pytest.raises(ValueError):
+        C.read_tensor_bundle(prefix)

@@ -85,13 +85,25 @@ def test_local_window_equal_memory_matches_global_context(hparams, weights, engi
         eng.close()
 
 
-def test_local_short_memory_is_refused(hparams, weights):
-    hp, eng = _setup(hparams, weights, 10, True)
+@pytest.mark.parametrize('gaussian', [True, False])
+def test_local_short_memory_is_refused(hparams, weights, weights64, gaussian):
+    """T_s < 2D+1 in monotonic mode.  The reference computes a CONTEXT for it (the window is zero-padded in front,
+    tacotron/attention.py:288-321) but not alignments it can carry: the window's 2D+1 alignments are padded with
+    abs(start) + abs(stop - T_s) = 2D+1 - T_s zeros (:294-299, :85-92) to 4D+2 - T_s != T_s entries -- the state of the
+    attention wrapper changes shape between steps -- and with luong_force_gaussian the 2D+1 alignments meet T_s gaussian
+    weights (:73-80).  TensorFlow fails there; the oracle's restatement raises on the same shapes (both settings), and the
+    library refuses the call instead of inventing alignments: same error behaviour."""
+    hp, eng = _setup(hparams, weights, 10, gaussian)
     try:
-        memory = np.zeros((1, 20, 256), np.float32)          # < 2D+1 = 21
-        with pytest.raises(pkg('_hip').TtsError) as ei:
-            eng.decoder_forward(memory, 3)
-        assert ei.value.code == -5
+        ids = np.random.default_rng(3).integers(2, 39, (1, 20)).astype(np.int32)   # 20 < 2D+1 = 21
+        with pytest.raises(ValueError):
+            O.tacotron_predict(ids, weights64, hp, n_steps=3)
+        memory = np.zeros((1, 20, 256), np.float32)
+        for pd in (0, 2):
+            eng.set_option('persistent_decoder', pd)
+            with pytest.raises(pkg('_hip').TtsError) as ei:
+                eng.decoder_forward(memory, 3)
+            assert ei.value.code == -5
     finally:
         eng.close()
 
