@@ -195,6 +195,15 @@ struct tts_handle_s {
         int n_cus = 0;
     } gl;
 
+    // general power-of-two path (griffin_lim_generic.hip): twiddles per n_fft, window tables of the last configuration
+    struct {
+        std::map<int, float2*> tw;          // n_fft -> exp(-2 pi i k / n_fft), k < n_fft / 2
+        int n_fft = 0, win = 0, hop = 0, T = 0;
+        float* window = nullptr;
+        float* rwss = nullptr;
+        bool configured = false;
+    } glg;
+
     // analysis-side tables (STFT window, mel basis)
     struct {
         int win = 0;
@@ -837,8 +846,12 @@ int gl_tables(tts_handle_t h) {
 
 static inline int device_cus(tts_handle_t h) { return h->gl.n_cus; }
 
+static inline int gl_fp(int n_fft);
+int glg_prepare(tts_handle_t h, int T, int win, int hop, int n_fft);
+int glg_twiddles(tts_handle_t h, int n_fft, const float2** out);
+
 int stft_prepare(tts_handle_t h, int n, int win, int hop, int n_fft) {
-    if (n_fft != TTS_GL_NFFT) return fail(h, TTS_ERR_UNSUPPORTED, "stft: only n_fft == 2048 is implemented");
+    if (n_fft != TTS_GL_NFFT) return fail(h, TTS_ERR_UNSUPPORTED, "stft: n_fft != 2048 takes the general kernels (stft_run)");
     if (win < 2 || win > n_fft || hop < 1) return fail(h, TTS_ERR_INVALID, "stft: need 2 <= win_length <= n_fft, hop >= 1");
     if (n <= n_fft / 2) return fail(h, TTS_ERR_INVALID, "stft: signal shorter than n_fft/2 (reflect padding undefined)");
     int rc = gl_tables(h);
@@ -858,6 +871,19 @@ int stft_prepare(tts_handle_t h, int n, int win, int hop, int n_fft) {
 }
 
 int stft_run(tts_handle_t h, const float* wav, int B, int n, int n_fft, int win, int hop, float2** out, int* Tf_out) {
+    if (n_fft != TTS_GL_NFFT) {   // the general kernels: one workgroup per frame, FFT in LDS (griffin_lim_generic.hip)
+        if (n <= n_fft / 2) return fail(h, TTS_ERR_INVALID, "stft: signal shorter than n_fft/2 (reflect padding undefined)");
+        int rc = glg_prepare(h, 0, win, hop, n_fft);
+        if (rc) return rc;
+        const float2* tw = nullptr;
+        if ((rc = glg_twiddles(h, n_fft, &tw))) return rc;
+        const int Tf = 1 + n / hop, Fp = gl_fp(n_fft);
+        WS(h, "an.stft", float2, (size_t)B * Tf * Fp, buf);
+        HIPCHK(h, launch_glg_stft(h->stream, wav, n, h->glg.window, tw, buf, B, Tf, Fp, n_fft, win, hop, 1, nullptr, nullptr));
+        *out = buf;
+        *Tf_out = Tf;
+        return TTS_OK;
+    }
     int rc = stft_prepare(h, n, win, hop, n_fft);
     if (rc) return rc;
     const int Tf = 1 + n / hop;
@@ -868,8 +894,125 @@ int stft_run(tts_handle_t h, const float* wav, int B, int n, int n_fft, int win,
     return TTS_OK;
 }
 
+// ---- general path: any power-of-two n_fft, any window / hop (griffin_lim_generic.hip)
+static inline int gl_fp(int n_fft) { return ((n_fft / 2 + 1) + 31) & ~31; }   // padded row length (TTS_GL_FP for 2048)
+// The streaming kernel is specialised to the model's configuration; everything else takes the general kernels.
+static inline bool gl_is_streaming(int n_fft, int win, int hop) { return n_fft == TTS_GL_NFFT && win == 1102 && hop == 275; }
+
+// periodic hann (scipy get_window('hann', win, fftbins=True)), float64 then float32
+static void hann_window(int win, std::vector<double>& wd, std::vector<float>& wf) {
+    wd.resize(win);
+    wf.resize(win);
+    for (int i = 0; i < win; ++i) {
+        wd[i] = 0.5 - 0.5 * std::cos(2.0 * M_PI * i / win);
+        wf[i] = (float)wd[i];
+    }
+}
+// librosa window_sumsquare (float32 buffer, sequential += of the padded squared window) as its RECIPROCAL where librosa's
+// istft divides (wss > tiny(float32)), 1 elsewhere
+static void recip_window_sumsquare(const std::vector<double>& wd, int n_fft, int hop, int T, std::vector<float>& wss) {
+    const int win = (int)wd.size();
+    const size_t n = (size_t)n_fft + (size_t)hop * (T - 1);
+    wss.assign(n, 0.f);
+    const int lpad = (n_fft - win) / 2;
+    for (int i = 0; i < T; ++i) {
+        const size_t s0 = (size_t)i * hop;
+        for (int j = 0; j < win; ++j) {
+            const size_t idx = s0 + lpad + j;
+            if (idx < n) wss[idx] = (float)((double)wss[idx] + wd[j] * wd[j]);
+        }
+    }
+    for (size_t i = 0; i < n; ++i) wss[i] = wss[i] > 1.17549435e-38f ? (float)(1.0 / (double)wss[i]) : 1.0f;
+}
+
+int glg_twiddles(tts_handle_t h, int n_fft, const float2** out) {
+    auto& g = h->glg;
+    if (!g.configured) {
+        HIPCHK(h, glg_configure());
+        g.configured = true;
+    }
+    auto it = g.tw.find(n_fft);
+    if (it == g.tw.end()) {
+        std::vector<float2> t(n_fft / 2);
+        for (int k = 0; k < n_fft / 2; ++k) {
+            const double a = -2.0 * M_PI * k / (double)n_fft;
+            t[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        float2* d = nullptr;
+        HIPCHK(h, hipMalloc(&d, t.size() * sizeof(float2)));
+        HIPCHK(h, hipMemcpy(d, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice));
+        it = g.tw.emplace(n_fft, d).first;
+    }
+    *out = it->second;
+    return TTS_OK;
+}
+
+// window tables of a configuration (T = 0: the analysis side needs the window only)
+int glg_prepare(tts_handle_t h, int T, int win, int hop, int n_fft) {
+    if (!glg_supports(n_fft))
+        return fail(h, TTS_ERR_UNSUPPORTED, "n_fft must be a power of two between 256 and 4096");
+    if (win < 2 || win > n_fft || hop < 1) return fail(h, TTS_ERR_INVALID, "need 2 <= win_length <= n_fft, hop_length >= 1");
+    auto& g = h->glg;
+    if (g.n_fft == n_fft && g.win == win && g.hop == hop && (T == 0 || g.T == T)) return TTS_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (g.window) hipFree(g.window);
+    if (g.rwss) hipFree(g.rwss);
+    g.window = g.rwss = nullptr;
+    g.n_fft = 0;
+    std::vector<double> wd;
+    std::vector<float> wf;
+    hann_window(win, wd, wf);
+    HIPCHK(h, hipMalloc(&g.window, win * sizeof(float)));
+    HIPCHK(h, hipMemcpy(g.window, wf.data(), win * sizeof(float), hipMemcpyHostToDevice));
+    if (T > 0) {
+        std::vector<float> wss;
+        recip_window_sumsquare(wd, n_fft, hop, T, wss);
+        HIPCHK(h, hipMalloc(&g.rwss, wss.size() * sizeof(float)));
+        HIPCHK(h, hipMemcpy(g.rwss, wss.data(), wss.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    g.n_fft = n_fft; g.win = win; g.hop = hop; g.T = T;
+    return TTS_OK;
+}
+
+// mag_int: [B][T][Fp] (Fp = gl_fp(n_fft)); init_ft: reference-layout U[0,1) numbers or null (then the seed)
+int gl_run_generic(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t seed, int B, int T, int n_iter, int win,
+                   int hop, int n_fft, float* wav, float* mse, bool peak_normalize) {
+    if (T < 1) return fail(h, TTS_ERR_INVALID, "griffin_lim: T >= 1");
+    if ((long long)hop * (T - 1) <= n_fft / 2)
+        return fail(h, TTS_ERR_INVALID, "griffin_lim: signal shorter than n_fft/2 (reflect padding undefined)");
+    int rc = glg_prepare(h, T, win, hop, n_fft);
+    if (rc) return rc;
+    const float2* tw = nullptr;
+    if ((rc = glg_twiddles(h, n_fft, &tw))) return rc;
+    const int F = 1 + n_fft / 2, Fp = gl_fp(n_fft), L = hop * (T - 1);
+    WS(h, "glg.phase", float2, (size_t)B * T * Fp, ph);
+    WS(h, "glg.frames", float, (size_t)B * T * win, frames);
+    WS(h, "glg.mse_partial", float, (size_t)B * T, msep);
+    float* sig = wav;   // every iteration's signal estimate lives in the caller's buffer: the last one is the result
+    HIPCHK(h, launch_glg_phase_init(h->stream, init_ft, seed, ph, B, F, T, Fp));
+    {
+        ProfScope ps(h, ST_GL_ITER, 3 * (int64_t)n_iter);
+        for (int it = 0; it < n_iter; ++it) {
+            HIPCHK(h, launch_glg_istft(h->stream, mag_int, ph, h->glg.window, h->glg.rwss, tw, frames, sig, B, T, Fp, n_fft, win, hop));
+            const bool want_mse = mse && it == n_iter - 1;
+            HIPCHK(h, launch_glg_stft(h->stream, sig, L, h->glg.window, tw, ph, B, T, Fp, n_fft, win, hop, 0, mag_int,
+                                      want_mse ? msep : nullptr));
+        }
+    }
+    if (mse) {
+        if (n_iter > 0) HIPCHK(h, launch_gl_mse_reduce(h->stream, msep, B, T, (float)((double)F * T), mse));
+        else HIPCHK(h, hipMemsetAsync(mse, 0, B * sizeof(float), h->stream));
+    }
+    {
+        ProfScope ps(h, ST_GL_FINAL, 2);
+        HIPCHK(h, launch_glg_istft(h->stream, mag_int, ph, h->glg.window, h->glg.rwss, tw, frames, wav, B, T, Fp, n_fft, win, hop));
+    }
+    if (peak_normalize) HIPCHK(h, launch_peak_normalize(h->stream, wav, B, L));
+    return TTS_OK;
+}
+
 int gl_prepare(tts_handle_t h, int T, int win, int hop, int n_fft) {
-    if (n_fft != TTS_GL_NFFT) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: only n_fft == 2048 is implemented");
+    if (!gl_is_streaming(n_fft, win, hop)) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: the streaming kernel runs the model's configuration only");
     if (win < 2 || win > n_fft || hop < 1 || T < 1)
         return fail(h, TTS_ERR_INVALID, "griffin_lim: need 2 <= win_length <= n_fft, hop_length >= 1, T >= 1");
     const int ncol = (win + hop - 1) / hop;
@@ -1171,6 +1314,11 @@ int tts_destroy(tts_handle_t h) {
         if (h->hio.ids_dev[i]) hipFree(h->hio.ids_dev[i]);
         if (h->hio.wav_pinned[i]) hipHostFree(h->hio.wav_pinned[i]);
         if (h->hio.wav_dev[i]) hipFree(h->hio.wav_dev[i]);
+        if (i == 0) {
+            for (auto& kv : h->glg.tw) hipFree(kv.second);
+            if (h->glg.window) hipFree(h->glg.window);
+            if (h->glg.rwss) hipFree(h->glg.rwss);
+        }
         if (h->hio.lin_pinned[i]) hipHostFree(h->hio.lin_pinned[i]);
         if (h->hio.lin_dev[i]) hipFree(h->hio.lin_dev[i]);
         if (h->hio.ali_pinned[i]) hipHostFree(h->hio.ali_pinned[i]);
@@ -1718,6 +1866,16 @@ int tts_griffin_lim(tts_handle_t h, const float* mag, const float* init_phase, u
                     int win_length, int hop_length, int n_fft, float* wav, float* mse) {
     DeviceScope dev_scope(h);
     if (!h || !mag || !wav || B < 1 || n_iter < 0) return fail(h, TTS_ERR_INVALID, "griffin_lim: bad arguments");
+    if (!gl_is_streaming(n_fft, win_length, hop_length)) {
+        // any other power-of-two n_fft / window / hop: the general kernels (griffin_lim_generic.hip)
+        if (!glg_supports(n_fft)) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: n_fft must be a power of two between 256 and 4096");
+        if (T < 1 || win_length < 2 || win_length > n_fft || hop_length < 1)
+            return fail(h, TTS_ERR_INVALID, "griffin_lim: need 2 <= win_length <= n_fft, hop_length >= 1, T >= 1");
+        const int Fg = 1 + n_fft / 2, Fp = gl_fp(n_fft);
+        WS(h, "gl.mag", float, (size_t)B * T * Fp, magg);
+        HIPCHK(h, launch_mag_ft_to_tf(h->stream, mag, magg, B, Fg, T, Fp));
+        return gl_run_generic(h, magg, init_phase, seed, B, T, n_iter, win_length, hop_length, n_fft, wav, mse, false);
+    }
     int rc = gl_prepare(h, T, win_length, hop_length, n_fft);
     if (rc) return rc;
     const int F = 1 + n_fft / 2, FP = TTS_GL_FP;
@@ -1740,7 +1898,7 @@ int tts_stft(tts_handle_t h, const float* wav, int B, int n, int n_fft, int win_
     int Tf;
     int rc = stft_run(h, wav, B, n, n_fft, win_length, hop_length, &buf, &Tf);
     if (rc) return rc;
-    HIPCHK(h, launch_cplx_tf_to_ft(h->stream, buf, out, B, 1 + n_fft / 2, Tf, TTS_GL_FP, 0, 1.0f));
+    HIPCHK(h, launch_cplx_tf_to_ft(h->stream, buf, out, B, 1 + n_fft / 2, Tf, gl_fp(n_fft), 0, 1.0f));
     return TTS_OK;
 }
 
@@ -1752,7 +1910,7 @@ int tts_stft_magnitude(tts_handle_t h, const float* wav, int B, int n, int n_fft
     int Tf;
     int rc = stft_run(h, wav, B, n, n_fft, win_length, hop_length, &buf, &Tf);
     if (rc) return rc;
-    HIPCHK(h, launch_cplx_tf_to_ft(h->stream, buf, lin, B, 1 + n_fft / 2, Tf, TTS_GL_FP, 1, power));
+    HIPCHK(h, launch_cplx_tf_to_ft(h->stream, buf, lin, B, 1 + n_fft / 2, Tf, gl_fp(n_fft), 1, power));
     return TTS_OK;
 }
 
@@ -1761,8 +1919,8 @@ int tts_mel_spectrogram(tts_handle_t h, const float* lin, int B, int n_frames, i
     DeviceScope dev_scope(h);
     if (!h || !lin || !mel || B < 1 || n_frames < 1 || n_mels < 1 || sr < 1)
         return fail(h, TTS_ERR_INVALID, "mel_spectrogram: bad arguments");
-    if (n_fft != TTS_GL_NFFT) return fail(h, TTS_ERR_UNSUPPORTED, "mel_spectrogram: only n_fft == 2048 is implemented");
-    const int F = 1 + n_fft / 2, FP = TTS_GL_FP;
+    if (n_fft < 2 || (n_fft & 1)) return fail(h, TTS_ERR_INVALID, "mel_spectrogram: n_fft must be even");
+    const int F = 1 + n_fft / 2, FP = gl_fp(n_fft);
     auto& a = h->an;
     if (!a.mel_wt || a.sr != sr || a.n_fft != n_fft || a.n_mels != n_mels || a.fmin != fmin || a.fmax != fmax) {
         // librosa.filters.mel(htk=True, norm=1) [librosa-0.6]; reference audio/features.py:75-80
@@ -1828,7 +1986,14 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     const tts_config_t& c = h->cfg;
     const int T = sp->n_steps * c.reduction;
     const int F = 1 + c.n_fft / 2, FP = TTS_GL_FP;
-    if ((rc = gl_prepare(h, T, sp->win_length, sp->hop_length, c.n_fft))) return rc;
+    if (c.n_fft != TTS_GL_NFFT)
+        return fail(h, TTS_ERR_UNSUPPORTED, "synthesize: the network's final Dense / de-normalisation epilogue is laid out for n_fft == 2048 "
+                                             "(the audio entry points tts_griffin_lim / tts_stft* take other sizes)");
+    // the model's window / hop run in the streaming kernel; any other pair in the general kernels (same results to rounding)
+    const bool gl_streaming = gl_is_streaming(c.n_fft, sp->win_length, sp->hop_length);
+    if (gl_streaming && (rc = gl_prepare(h, T, sp->win_length, sp->hop_length, c.n_fft))) return rc;
+    if (!gl_streaming && (sp->win_length < 2 || sp->win_length > c.n_fft || sp->hop_length < 1))
+        return fail(h, TTS_ERR_INVALID, "synthesize: need 2 <= win_length <= n_fft, hop_length >= 1");
     WS(h, "syn.memory", float, (size_t)B * Ts * 2 * c.n_gru_units, memory);
     // The decoder output is double-buffered by call parity: the encoder / decoder of call j+1 (second
     // stream) may then run while the post-net of call j still reads its mel spectrogram.
@@ -1937,7 +2102,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         return rc;
     }
     // (a seeded start with iterations needs no initial codes at all: gl_run)
-    const bool phase_on_front = pipelined && sp->n_iter >= 0 && (init_phase != nullptr || sp->n_iter == 0);
+    const bool phase_on_front = gl_streaming && pipelined && sp->n_iter >= 0 && (init_phase != nullptr || sp->n_iter == 0);
     if (pipelined) {
         if (hold_flag) HIPCHK(h, hipMemsetAsync(hold_flag, 1, sizeof(int), h->front));   // release the held CUs
         if (phase_on_front) {
@@ -1961,8 +2126,12 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         HIPCHK(h, hipEventRecord(h->ev_post_done[parity], h->stream));
         h->post_pending[parity] = true;
     }
-    rc = gl_run(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav, nullptr,
-                sp->peak_normalize != 0, pipelined, phase_pair, phase_on_front);
+    if (gl_streaming)
+        rc = gl_run(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav, nullptr,
+                    sp->peak_normalize != 0, pipelined, phase_pair, phase_on_front);
+    else
+        rc = gl_run_generic(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav, nullptr,
+                            sp->peak_normalize != 0);
     if (h->front && !rc) {
         HIPCHK(h, hipEventRecord(h->ev_gl_done[parity], h->stream));
         h->gl_pending[parity] = true;

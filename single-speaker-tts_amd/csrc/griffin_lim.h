@@ -62,4 +62,17 @@ hipError_t launch_cplx_tf_to_ft(hipStream_t s, const float2* in, float* out, int
 hipError_t launch_db_convert(hipStream_t s, const float* in, float* out, size_t n, int mode, float ref_db, float max_db);
 hipError_t launch_any_below(hipStream_t s, const float* in, size_t n, float lim, int* flag);
 
+// general power-of-two path (griffin_lim_generic.hip): one workgroup per frame, FFT in LDS; spectra [B][T][Fp], state =
+// float2 unit phasors; tw = exp(-2 pi i k / n_fft), k < n_fft / 2
+bool glg_supports(int n_fft);   // power of two, 256 .. 4096
+hipError_t glg_configure();
+hipError_t launch_glg_phase_init(hipStream_t s, const float* init_ft, uint64_t seed, float2* out, int B, int F, int T, int Fp);
+// frames [B][T][win] scratch; wav [B][hop (T - 1)]: inverse transform of every frame, then the overlap-add (a gather in frame order)
+hipError_t launch_glg_istft(hipStream_t s, const float* mag, const float2* ph, const float* window, const float* rwss, const float2* tw,
+                            float* frames, float* wav, int B, int T, int Fp, int n_fft, int win, int hop);
+// mode 0: out = unit phasors of the spectrum (+ per-frame squared magnitude error against mag when mse_partial != null);
+// mode 1: out = the complex spectrum
+hipError_t launch_glg_stft(hipStream_t s, const float* wav, int n, const float* window, const float2* tw, float2* out, int B, int Tf, int Fp,
+                           int n_fft, int win, int hop, int mode, const float* mag, float* mse_partial);
+
 }  // namespace tts

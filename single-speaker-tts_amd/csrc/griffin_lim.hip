@@ -1108,29 +1108,22 @@ hipError_t launch_gl_stream(hipStream_t s, const GlParams& p_in, int n_cus, int 
         else hipLaunchKernelGGL((gl_stream_kernel<MODE, W, H, M, N, false>), grid, dim3(GL_THREADS), lds, s, p);        \
     }
 #define GLS_LAUNCH(MODE, W, H, M) GLS_LAUNCH_N(MODE, W, H, M, 1)
+    // only the model's window / hop pair is instantiated (both windows in registers, every span bound static): any other
+    // pair takes the general kernels of griffin_lim_generic.hip (api.hip: gl_is_streaming).  The run-time (WIN_CT = HOP_CT = 0)
+    // form of the kernel body stays in the source for the tools; it needed ~100 spilled registers per lane.
+    if (!ref_cfg) return hipErrorInvalidValue;
 #ifdef GL_FAST_BUILD
-    if (!ref_cfg || mse) return hipErrorInvalidValue;
+    if (mse) return hipErrorInvalidValue;
     if (final_istft) GLS_LAUNCH(1, 1102, 275, false)
     else if (n_stage == 2) GLS_LAUNCH_N(0, 1102, 275, false, 2)
     else if (n_stage == 3) GLS_LAUNCH_N(0, 1102, 275, false, 3)
     else GLS_LAUNCH(0, 1102, 275, false)
 #else
-    if (n_stage == 3) {
-        if (ref_cfg) GLS_LAUNCH_N(0, 1102, 275, false, 3)
-        else GLS_LAUNCH_N(0, 0, 0, false, 3)
-    } else if (n_stage == 2) {
-        if (ref_cfg) GLS_LAUNCH_N(0, 1102, 275, false, 2)
-        else GLS_LAUNCH_N(0, 0, 0, false, 2)
-    } else if (final_istft) {
-        if (ref_cfg) GLS_LAUNCH(1, 1102, 275, false)
-        else GLS_LAUNCH(1, 0, 0, false)
-    } else if (mse) {
-        if (ref_cfg) GLS_LAUNCH(0, 1102, 275, true)
-        else GLS_LAUNCH(0, 0, 0, true)
-    } else {
-        if (ref_cfg) GLS_LAUNCH(0, 1102, 275, false)
-        else GLS_LAUNCH(0, 0, 0, false)
-    }
+    if (n_stage == 3) GLS_LAUNCH_N(0, 1102, 275, false, 3)
+    else if (n_stage == 2) GLS_LAUNCH_N(0, 1102, 275, false, 2)
+    else if (final_istft) GLS_LAUNCH(1, 1102, 275, false)
+    else if (mse) GLS_LAUNCH(0, 1102, 275, true)
+    else GLS_LAUNCH(0, 1102, 275, false)
 #endif
 #undef GLS_LAUNCH_N
 #undef GLS_LAUNCH
@@ -1140,12 +1133,7 @@ hipError_t launch_gl_stream(hipStream_t s, const GlParams& p_in, int n_cus, int 
 hipError_t gl_stream_configure() {
     hipError_t e;
 #ifndef GL_FAST_BUILD
-    if ((e = gl_stream_set_attr<0, 0, 0, false>()) != hipSuccess) return e;
-    if ((e = gl_stream_set_attr<0, 0, 0, true>()) != hipSuccess) return e;
-    if ((e = gl_stream_set_attr<1, 0, 0, false>()) != hipSuccess) return e;
     if ((e = gl_stream_set_attr<0, 1102, 275, true>()) != hipSuccess) return e;
-    if ((e = gl_stream_set_attr<0, 0, 0, false, 2>()) != hipSuccess) return e;
-    if ((e = gl_stream_set_attr<0, 0, 0, false, 3>()) != hipSuccess) return e;
 #endif
     if ((e = gl_stream_set_attr<0, 1102, 275, false>()) != hipSuccess) return e;
     if ((e = gl_stream_set_attr<0, 1102, 275, false, 2>()) != hipSuccess) return e;

@@ -63,8 +63,11 @@ def test_unsupported_configs_are_rejected(hparams):
         sstts.Engine(hp)
     assert e.value.code == -5
     eng = sstts.Engine(hparams)
+    with pytest.raises(sstts.TtsError) as e:   # n_fft must be a power of two between 256 and 4096
+        eng.griffin_lim(np.ones((1, 501, 20), np.float32), 1, 400, 100, 1000)
+    assert e.value.code == -5
     with pytest.raises(sstts.TtsError) as e:
-        eng.griffin_lim(np.ones((1, 513, 8), np.float32), 1, 400, 100, 1024)
+        eng.griffin_lim(np.ones((1, 4097, 20), np.float32), 1, 400, 100, 8192)
     assert e.value.code == -5
     eng.close()
 

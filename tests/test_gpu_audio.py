@@ -202,3 +202,75 @@ def test_griffin_lim_forced_run_cuts(engine, run_len, per_launch, n_iter, want_m
         assert rel_l2(wav[b], ref_wav) < 1e-4 * n_iter
         if want_mse:
             assert abs(mse[b] - ref_mse) <= 1e-3 * abs(ref_mse) + 1e-9
+
+
+# ---- every power-of-two n_fft / window / hop on the audio surface (csrc/griffin_lim_generic.hip): the reference passes
+# n_fft, win_length and hop_length as arguments (audio/synthesis.py:5-40, 43-125; audio/features.py:5-86, 116-145)
+@pytest.mark.parametrize('n_fft,win,hop,B,T', [
+    (1024, 800, 200, 3, 60),
+    (4096, 2400, 600, 2, 40),
+    (512, 512, 128, 2, 50),        # win == n_fft, hop = win / 4 (librosa's defaults)
+    (256, 200, 50, 1, 45),
+    (2048, 1200, 300, 2, 40),      # the model's n_fft with another window / hop: the general kernels as well
+    (2048, 2048, 512, 1, 30),
+])
+def test_griffin_lim_other_sizes_one_iteration(engine, n_fft, win, hop, B, T):
+    """One iteration and the final iSTFT from identical phases against the oracle, sample by sample (<= 1e-4 of the peak),
+    with the mse of the iteration."""
+    rng = np.random.default_rng(n_fft + win)
+    F = 1 + n_fft // 2
+    mag = ((rng.random((B, F, T)) ** 4) * 10).astype(np.float32)
+    init = rng.random((B, F, T)).astype(np.float32)
+    wav, mse = engine.griffin_lim(mag, 1, win, hop, n_fft, init_phase=init, want_mse=True)
+    wav, mse = wav.to_host(), mse.to_host()
+    assert wav.shape == (B, hop * (T - 1))
+    for b in range(B):
+        ref_wav, ref_mse = A.griffin_lim_v2(mag[b], win, hop, n_fft, 1, init_phase=init[b])
+        assert np.abs(wav[b] - ref_wav).max() <= 1e-4 * max(1e-6, np.abs(ref_wav).max()), (n_fft, b)
+        assert rel_l2(wav[b], ref_wav) < 2e-5
+        assert abs(mse[b] - ref_mse) <= 1e-4 * ref_mse
+    # no iteration at all: the iSTFT of the initial estimate
+    wav0, _ = engine.griffin_lim(mag, 0, win, hop, n_fft, init_phase=init, want_mse=False)
+    ref0, _ = A.griffin_lim_v2(mag[0], win, hop, n_fft, 0, init_phase=init[0])
+    assert rel_l2(wav0.to_host()[0], ref0) < 2e-5
+
+
+@pytest.mark.parametrize('n_fft,win,hop', [(1024, 800, 200), (4096, 2400, 600)])
+def test_griffin_lim_other_sizes_30_iterations(engine, n_fft, win, hop):
+    """30 iterations: the mse (the reference's convergence measure, audio/synthesis.py:115) within 1 % of the oracle's and the
+    same spectral convergence of the result; a seeded start is reproducible."""
+    B, T, n_iter = 2, 50, 30
+    rng = np.random.default_rng(n_fft)
+    F = 1 + n_fft // 2
+    mag = ((rng.random((B, F, T)) ** 4) * 10).astype(np.float32)
+    init = rng.random((B, F, T)).astype(np.float32)
+    wav, mse = engine.griffin_lim(mag, n_iter, win, hop, n_fft, init_phase=init, want_mse=True)
+    wav, mse = wav.to_host(), mse.to_host()
+    for b in range(B):
+        ref_wav, ref_mse = A.griffin_lim_v2(mag[b], win, hop, n_fft, n_iter, init_phase=init[b])
+        assert abs(mse[b] - ref_mse) <= 0.01 * ref_mse, (mse[b], ref_mse)
+        sc = lambda y: np.linalg.norm(np.abs(A.stft(y, n_fft, hop, win)) - mag[b]) / np.linalg.norm(mag[b])   # noqa: E731
+        assert abs(sc(wav[b]) - sc(ref_wav)) <= 0.01 * sc(ref_wav)
+    w1, _ = engine.griffin_lim(mag, 3, win, hop, n_fft, seed=77, want_mse=False)
+    w2, _ = engine.griffin_lim(mag, 3, win, hop, n_fft, seed=77, want_mse=False)
+    w3, _ = engine.griffin_lim(mag, 3, win, hop, n_fft, seed=78, want_mse=False)
+    assert np.array_equal(w1.to_host(), w2.to_host()) and not np.array_equal(w1.to_host(), w3.to_host())
+
+
+@pytest.mark.parametrize('n_fft,win,hop', [(1024, 800, 200), (4096, 2400, 600), (512, 400, 100)])
+def test_stft_and_mel_other_sizes(engine, n_fft, win, hop):
+    """tts_stft / tts_stft_magnitude / tts_mel_spectrogram at other transform sizes against the oracle (librosa.stft,
+    HTK mel basis with Slaney normalisation: audio/features.py:5-86, 116-145)."""
+    rng = np.random.default_rng(n_fft)
+    n = hop * 37
+    y = (0.3 * np.sin(2 * np.pi * 330 * np.arange(n) / 22050) + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    Fm = pkg('audio.features')
+    S = Fm.linear_scale_spectrogram(y, n_fft, hop, win, engine=engine)
+    ref = A.stft(y, n_fft, hop, win)
+    assert S.dtype == np.complex64 and S.shape == ref.shape == (1 + n_fft // 2, 38)
+    assert np.linalg.norm(S - ref) / np.linalg.norm(ref) < 1e-5
+    mel = Fm.mel_scale_spectrogram(y, n_fft, 22050, 80, 0, 8000, hop, win, 1.0, engine=engine)
+    rmel, _ = A.mel_scale_spectrogram(y, n_fft, 22050, 80, 0, 8000, hop, win, 1.0)
+    assert mel.shape == rmel.shape == (80, 38) and rel_l2(mel, rmel) < 1e-5
+    p2 = engine.stft_magnitude(y[None], n_fft, win, hop, 2.0).to_host()[0]
+    assert rel_l2(p2, np.abs(ref) ** 2) < 1e-5
