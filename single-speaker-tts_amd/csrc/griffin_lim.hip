@@ -296,6 +296,20 @@ __device__ __forceinline__ void mirror_bins(const cf (&z)[16], cf (&m)[16], cf* 
 }
 
 // ------------------------------------------------------------------------------------ GL iteration
+// PAIR-OWNER layout of a spectrum row inside the streaming kernel (round 4).  The real-FFT merge and split passes couple bin
+// k with bin MH - k: X[k] and X[MH - k] come from the same (Z[k], Z[MH - k]) with ONE twiddle product,
+//     E = Z[k] + conj Z[MH-k],  o = W^k (Z[k] - conj Z[MH-k]):   2 X[k] = E - i o,   2 X[MH-k] = conj(E + i o)
+// and likewise the two inputs of the inverse transform from (G[k], G[MH-k]).  So a lane OWNS the eight pairs of its bins
+// k = lane + 64 c, c < 8 (k < 512): slot c of a row register set holds bin k, slot 8 + c bin MH - k (for lane 0, c = 0 that
+// is the Nyquist bin MH; bin 512, its own mirror, is lane 0's extra `mid` value).  Magnitudes and phasor codes are loaded
+// and stored straight in this layout (the mirrored half is a descending, still contiguous 256-byte access), the
+// normalisation works on it unchanged, and only half of a transform's values cross lanes: the forward FFT's upper
+// registers (bins >= 512) go to their owners, the owners send the inverse FFT's upper inputs back.  6 VALU instructions per
+// PAIR and 8 + 8 LDS accesses per pass instead of 5 per BIN and 16 + 16 (every lane fetching the mirror of each of its 16
+// bins and multiplying by its twiddle): -64 VALU and -32 LDS instructions per frame and iteration.
+#define GL_BIN(lane, j) ((j) < 8 ? (lane) + 64 * (j) : MH - (lane) - 64 * ((j) - 8))
+// element j of a row through its two lane bases LO = row + lane, HI = row + (MH - lane): the offsets are instruction constants
+#define GL_ROW(LO, HI, j) ((j) < 8 ? (LO)[64 * (j)] : (HI)[-64 * ((j) - 8)])
 #define GL_NW 8            // waves per workgroup
 #define GL_THREADS 512
 #define NFFT 2048
@@ -496,7 +510,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         slot = p.cls_slot0[k] + jc;
     };
 
-    // prefetch registers of one spectrum row: phasor codes and magnitudes of bins lane + 64 j, and the Nyquist bin
+    // prefetch registers of one spectrum row in the pair-owner layout: phasor codes and magnitudes of bins lane + 64 j
+    // (j < 8) and MH - lane - 64 (j - 8) (j >= 8), and of bin 512 (`nyq_*`: the name is older than the layout; only lane 0's is used)
     unsigned gc[16];
     float gs[16];
     unsigned nyq_c;
@@ -506,14 +521,16 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
     {                                                                                           \
         int tf_ = (TF);                                                                         \
         tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                       \
-        const unsigned* prow_ = (BASE_C) + (size_t)tf_ * p.FP + lane;                           \
-        const float* srow_ = (BASE_M) + (size_t)tf_ * p.FP + lane;                              \
+        const unsigned* prow_ = (BASE_C) + (size_t)tf_ * p.FP;                                  \
+        const float* srow_ = (BASE_M) + (size_t)tf_ * p.FP;                                     \
+        const unsigned* plo_ = prow_ + lane; const unsigned* phi_ = prow_ + (MH - lane);        \
+        const float* slo_ = srow_ + lane; const float* shi_ = srow_ + (MH - lane);              \
         if (!seeded) {                                                                          \
-            _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = GL_ABL_LD(prow_[64 * j_], (unsigned)(tf_ * 64 + j_) * 0x9E3779B9u);          \
-            nyq_c = prow_[MH - lane];                                                           \
+            _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = GL_ABL_LD(GL_ROW(plo_, phi_, j_), (unsigned)(tf_ * 64 + j_) * 0x9E3779B9u); \
+            nyq_c = prow_[MH / 2];                                                              \
         }                                                                                       \
-        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_ABL_LD(GL_STREAM_LOAD(srow_ + 64 * j_), (float)(tf_ + j_ + lane)); \
-        nyq_s = srow_[MH - lane];                                                               \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_ABL_LD(GL_STREAM_LOAD(j_ < 8 ? slo_ + 64 * j_ : shi_ - 64 * (j_ - 8)), (float)(tf_ + j_ + lane)); \
+        nyq_s = srow_[MH / 2];                                                                  \
     }
     // vmcnt counts loads and stores together, in issue order.  The row for the next iteration is requested early in
     // this one and the new row is stored at its end, so at the top of the loop the loads are OLDER than 17 stores: the
@@ -559,21 +576,27 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
 #endif
 
     // ---------------- the pieces of an iteration (all inlined; `v` is the wave's FFT register set)
-    // X[k] (bins lane + 64 j, Nyquist bin apart) -> input of the inverse transform (real-FFT split pass)
-    auto split_pass = [&](cf (&gk)[16], cf nyq, cf (&v)[16]) __attribute__((always_inline)) {
-        cf gm[16];   // the mirrored bins X[MH - k]
-        mirror_bins(gk, gm, ex, lane, nyq);
+    // G in the pair-owner layout (gk[c] = G[k], gk[8 + c] = G[MH - k], k = lane + 64 c; mid = G[512], lane 0's) -> input of
+    // the inverse transform, v[j] = Zin[lane + 64 j] (real-FFT split pass): Zin[k] = conj(E + i O), Zin[MH-k] = E - i O with
+    // E = G[k] + conj G[MH-k], O = conj(W^k) (G[k] - conj G[MH-k]) (the transform is fed conj(Zin), the two 1/2 are in the
+    // window); the owner keeps Zin[k] and sends Zin[MH-k] to the lane that transforms it
+    auto split_pass = [&](cf (&gk)[16], cf mid, cf (&v)[16]) __attribute__((always_inline)) {
+        cf* wr = ex + (MH - lane);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            cf xk = gk[j];
-            cf xr = gm[j];                                         // xm = conj(xr)
-            if (j == 0 && lane == 0) { xk.y = 0.f; xr.y = 0.f; }   // DC and Nyquist bins are real
-            // Zin = E + i O, E = (xk + xm)/2, O = conj(tw) (xk - xm)/2; the transform is fed conj(Zin), the
-            // two 1/2 are in the window.  For j >= 8, conj(tw) = i conj(twr[j - 8]): conj(E + i i O') = conj(E - O')
-            const cf e = cadd_conj(xk, xr);
-            const cf o = cmul_conj(csub_conj(xk, xr), twr[j & 7]);
-            v[j] = j < 8 ? cconj_add_pi(e, o) : cconj_sub(e, o);
+        for (int c = 0; c < 8; ++c) {
+            cf xk = gk[c];
+            cf xm = gk[8 + c];
+            if (c == 0 && lane == 0) { xk.y = 0.f; xm.y = 0.f; }   // DC and Nyquist bins are real
+            const cf e = cadd_conj(xk, xm);
+            const cf o = cmul_conj(csub_conj(xk, xm), twr[c]);
+            v[c] = cconj_add_pi(e, o);
+            wr[-64 * c] = cadd_mi(e, o);          // (lane 0, c = 0: slot MH, read by nobody)
         }
+        if (lane == 0) ex[MH / 2] = cscale(mid, 2.0f);   // bin 512 is its own mirror: Zin = 2 G
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 8; j < 16; ++j) v[j] = ex[lane + 64 * j];
+        wave_lds_sync();
     };
     // z[m] = conj(v) / MH, m = lane + 64 c: x[2m] = Re, x[2m+1] = Im; synthesis window (with 1 / window-sum-square)
     auto synth_window = [&](int t, cf (&v)[16]) __attribute__((always_inline)) {
@@ -693,23 +716,27 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
             }
         }
     };
-    // forward transform output (v, after fft1024) -> X[k] / MH per bin (real-FFT merge pass); sink(c, x) gets bin lane + 64 c
-    auto merge_pass = [&](const cf (&v)[16], auto&& sink) __attribute__((always_inline)) {
+    // forward transform output (v[j] = Z[lane + 64 j], after fft1024) -> X / MH in the pair-owner layout (real-FFT merge pass):
+    // sink(c, X[k]) and sink(8 + c, X[MH - k]) for k = lane + 64 c, c < 8; returns X[512] (meaningful in lane 0).  The upper
+    // registers travel to their owners through the wave's exchange buffer; Z[MH] := Z[0] gives lane 0 its Nyquist bin.
+    auto merge_pass = [&](const cf (&v)[16], auto&& sink) __attribute__((always_inline)) -> cf {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) ex[lane + 64 * c] = v[c];
+        for (int j = 8; j < 16; ++j) ex[lane + 64 * j] = v[j];
+        if (lane == 0) ex[MH] = v[0];
         wave_lds_sync();
-        cf zmr[16];   // all mirrored bins first: one LDS latency for the pass instead of one per bin
+        cf zm[8];   // all mirrored values first: one LDS latency for the pass instead of one per pair
+        const cf* rd = ex + (MH - lane);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) zmr[c] = ex[(MH - (lane + 64 * c)) & (MH - 1)];
+        for (int c = 0; c < 8; ++c) zm[c] = rd[-64 * c];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const cf zk = v[c];
-            // zm = conj(zmr); 2 X[k] = (zk + zm) - i tw (zk - zm); for c >= 8, tw = -i twr[c - 8]: X = E - O'
-            const cf e = cadd_conj(zk, zmr[c]);
-            const cf o = cmul(csub_conj(zk, zmr[c]), twr[c & 7]);
-            sink(c, c < 8 ? cadd_mi(e, o) : csub(e, o));
+        for (int c = 0; c < 8; ++c) {
+            const cf e = cadd_conj(v[c], zm[c]);
+            const cf o = cmul(csub_conj(v[c], zm[c]), twr[c]);
+            sink(c, cadd_mi(e, o));               // 2 X[k] = E - i o
+            sink(8 + c, cconj_add_pi(e, o));      // 2 X[MH - k] = conj(E + i o)
         }
         wave_lds_sync();
+        return cscale(cconj(v[8]), 2.0f);         // 2 X[512] = 2 conj(Z[512])
     };
 
     const int lead = NST * halo;   // frames the first index (of stage 0) lies before the run
@@ -770,15 +797,15 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     const unsigned long long row0 = (unsigned long long)b * p.F * p.T + (unsigned long long)t;   // bin f: + f T
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
-                        const cf e = gl_seed_phasor(p.seed, row0 + (unsigned long long)(lane + 64 * j) * p.T);
+                        const cf e = gl_seed_phasor(p.seed, row0 + (unsigned long long)GL_BIN(lane, j) * p.T);
                         gk[j] = cmk(gs[j] * e.x, gs[j] * e.y);
                     }
-                    const cf en = gl_seed_phasor(p.seed, row0 + (unsigned long long)(MH - lane) * p.T);
-                    split_pass(gk, cmk(nyq_s * en.x, 0.f), v);
+                    const cf en = gl_seed_phasor(p.seed, row0 + (unsigned long long)(MH / 2) * p.T);
+                    split_pass(gk, cmk(nyq_s * en.x, nyq_s * en.y), v);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) gk[j] = gl_unpack_phasor(gc[j], gs[j]);
-                    split_pass(gk, cmk(gl_unpack_phasor(nyq_c, nyq_s).x, 0.f), v);
+                    split_pass(gk, gl_unpack_phasor(nyq_c, nyq_s), v);
                 }
             } else {
 #pragma unroll
@@ -800,10 +827,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
             } else {
                 // (|S| of the frame that goes from this stage to the next: the magnitude registers are free until the next row is requested)
                 const int tq = t - lag < 0 ? 0 : (t - lag >= p.T ? p.T - 1 : t - lag);
-                const float* mrow_ = magb + (size_t)tq * p.FP + lane;
+                const float* mrow_ = magb + (size_t)tq * p.FP;
+                const float* mlo_ = mrow_ + lane; const float* mhi_ = mrow_ + (MH - lane);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) gs[j] = mrow_[64 * j];
-                nyq_s = mrow_[MH - lane];
+                for (int j = 0; j < 16; ++j) gs[j] = GL_ROW(mlo_, mhi_, j);
+                nyq_s = mrow_[MH / 2];
             }
             if (valid) {
                 fft1024(v, ex, tw, lane);
@@ -846,24 +874,25 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     cf gk[16];
                     // |S| e^{i phi}: x * (|S| / |x|), and (|S|, 0) for a zero bin (numpy's exp(1j * angle(0)) = 1); the
                     // bins are X / MH of a windowed signal, far from both ends of the float range
-                    merge_pass(v, [&](int c, cf x) {
+                    auto normalise = [&](cf x, float mag_) __attribute__((always_inline)) {
                         const float s2 = fmaf(x.x, x.x, x.y * x.y);
-                        const float g = gs[c] * __builtin_amdgcn_rsqf(s2);
+                        const float g = mag_ * __builtin_amdgcn_rsqf(s2);
                         const bool nz = s2 > 1.0e-37f;
-                        gk[c] = cmk(nz ? x.x * g : gs[c], nz ? x.y * g : 0.f);
-                    });
-                    const float xn = v[0].x - v[0].y;   // Nyquist bin (lane 0), real: phasor (-1, 0) / (1, 0)
-                    split_pass(gk, cmk(xn < 0.f ? -nyq_s : nyq_s, 0.f), v);
+                        return cmk(nz ? x.x * g : mag_, nz ? x.y * g : 0.f);
+                    };
+                    const cf xmid = merge_pass(v, [&](int c, cf x) { gk[c] = normalise(x, gs[c]); });
+                    split_pass(gk, normalise(xmid, nyq_s), v);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) v[j] = cmk(0.f, 0.f);
                 }
                 if (k + 1 < NST) {
                     const int tq = tk - lag < 0 ? 0 : (tk - lag >= p.T ? p.T - 1 : tk - lag);
-                    const float* mrow_ = magb + (size_t)tq * p.FP + lane;
+                    const float* mrow_ = magb + (size_t)tq * p.FP;
+                    const float* mlo_ = mrow_ + lane; const float* mhi_ = mrow_ + (MH - lane);
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) gs[j] = mrow_[64 * j];
-                    nyq_s = mrow_[MH - lane];
+                    for (int j = 0; j < 16; ++j) gs[j] = GL_ROW(mlo_, mhi_, j);
+                    nyq_s = mrow_[MH / 2];
                 } else {
                     GLS_NEXT_ROW()
                 }
@@ -887,18 +916,20 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                 float mg[16];
                 if (MSE) {
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) mg[c] = fabsf(GL_STREAM_LOAD(mrow + lane + 64 * c));
+                    for (int c = 0; c < 16; ++c) mg[c] = fabsf(GL_STREAM_LOAD(c < 8 ? mrow + lane + 64 * c : mrow + (MH - lane) - 64 * (c - 8)));
                 }
                 fft_input(ring_k, jj, sm, tm, yb_k, v);
                 fft1024(v, ex, tw, lane);
                 GLS_STAMP()   // 5: forward FFT done
                 GLS_URGENCY(i + GL_NW)
                 unsigned* orow = x_out + ((size_t)b * p.T + tm) * p.FP;
-                merge_pass(v, [&](int c, cf x) {
+                unsigned* olo = orow + lane;
+                unsigned* ohi = orow + (MH - lane);
+                const cf xmid = merge_pass(v, [&](int c, cf x) {
 #ifdef GL_ABL_NOSTORE
-                    if (__float_as_uint(x.x) == 0x12345678u) __builtin_nontemporal_store(gl_pack_phasor(x), orow + lane + 64 * c);
+                    if (__float_as_uint(x.x) == 0x12345678u) __builtin_nontemporal_store(gl_pack_phasor(x), c < 8 ? olo + 64 * c : ohi - 64 * (c - 8));
 #else
-                    __builtin_nontemporal_store(gl_pack_phasor(x), orow + lane + 64 * c);
+                    __builtin_nontemporal_store(gl_pack_phasor(x), c < 8 ? olo + 64 * c : ohi - 64 * (c - 8));
 #endif
                     if (MSE) {
                         const float d = mg[c] - (float)MH * sqrtf(fmaf(x.x, x.x, x.y * x.y));   // x = X / MH
@@ -906,11 +937,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     }
                 });
                 if (lane == 0) {
-                    const cf z0 = v[0];
-                    const float xn = z0.x - z0.y;   // Nyquist bin, real
-                    __builtin_nontemporal_store(xn < 0.f ? 1u : 0u, orow + MH);   // phasor (-1, 0) / (1, 0)
+                    __builtin_nontemporal_store(gl_pack_phasor(xmid), orow + MH / 2);   // bin 512
                     if (MSE) {
-                        const float d = fabsf(mrow[MH]) - (2.0f * MH) * fabsf(xn);   // xn = X[MH] / (2 MH)
+                        const float d = fabsf(mrow[MH / 2]) - (float)MH * sqrtf(fmaf(xmid.x, xmid.x, xmid.y * xmid.y));
                         mse_acc += d * d;
                     }
                 }
