@@ -310,6 +310,7 @@ def main():
     ap.add_argument('--hold-lds-kb', type=int, default=None)
     ap.add_argument('--persistent-decoder', type=int, default=None, help='override the library default (0 never, 1 pipelined, 2 always)')
     ap.add_argument('--gl-pair', type=int, default=None, help='override the library default (Griffin-Lim iterations per launch, 1..3)')
+    ap.add_argument('--enc-stream', type=int, default=None, help='override the library default (1: the encoder on a stream of its own, a gap ahead of its decoder)')
     ap.add_argument('--through-facade', action='store_true',
                     help='also time the reference-shaped host API (tacotron.inference.synthesize_stream: host ids in, host '
                          'waveforms out, upload and download inside the timed region) and report facade_ms_per_step')
@@ -393,6 +394,8 @@ def main():
         eng.set_option('persistent_decoder', args.persistent_decoder)
     if args.gl_pair is not None:
         eng.set_option('gl_pair', args.gl_pair)
+    if args.enc_stream is not None:
+        eng.set_option('enc_stream', args.enc_stream)
 
     # ---- this rank's shard of the synthetic batch, resident in HBM
     lo, hi = shard.shard_range(world * B_PER_GPU, world, rank)

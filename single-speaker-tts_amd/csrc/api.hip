@@ -81,6 +81,19 @@ struct tts_handle_s {
     // loop but HALVES the throughput of tts_synthesize_host -- streams of one priority share a few hardware queues, and with
     // the two copy streams of the host path the front stream lands on the main stream's queue.
     hipStream_t front = nullptr;
+    // The encoder of a pipelined call runs on a stream of its own (round 4): it depends on the ids only, so it need not
+    // queue behind the previous call's decoder on the front stream -- it runs as soon as the decoder of the call TWO back
+    // has finished with this parity's `memory` buffer, i.e. one inter-Griffin-Lim gap earlier, and the decoders follow
+    // each other back to back (the step was enc + dec = 17.2 ms against 15.6 ms of post-net + Griffin-Lim).
+    hipStream_t encs = nullptr;
+    int enc_stream = 1;   // option "enc_stream": 0 = the encoder on the front stream in front of its decoder (round 3)
+    hipEvent_t ev_enc_ready[2] = {nullptr, nullptr};   // encoder of the last call of this parity done (enc stream)
+    hipEvent_t ev_dec_done[2] = {nullptr, nullptr};    // decoder of the last call of this parity done (front stream)
+    // ... and not before the main stream has reached the post-net of that call (the Griffin-Lim phase before it is over):
+    // an encoder let loose during a Griffin-Lim phase gets its compute units one launch boundary at a time (3 ms for 0.75 ms
+    // of work) and slows those launches by 15 %; in the gap it shares the chip with the post-net, as before
+    hipEvent_t ev_gap[2] = {nullptr, nullptr};
+    bool enc_ready_pending[2] = {false, false}, dec_done_pending[2] = {false, false}, gap_pending[2] = {false, false};
     hipEvent_t ev_front_done = nullptr;
     hipEvent_t ev_post_done[2] = {nullptr, nullptr};   // post-net of the calls of even / odd parity
     bool post_pending[2] = {false, false};
@@ -594,6 +607,7 @@ int sync_all(tts_handle_t h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->front && h->front != h->stream) HIPCHK(h, hipStreamSynchronize(h->front));
     if (h->aux) HIPCHK(h, hipStreamSynchronize(h->aux));
+    if (h->encs) HIPCHK(h, hipStreamSynchronize(h->encs));
     if (h->hio.in) HIPCHK(h, hipStreamSynchronize(h->hio.in));
     if (h->hio.out) HIPCHK(h, hipStreamSynchronize(h->hio.out));
     return check_status(h);
@@ -1333,6 +1347,12 @@ int tts_destroy(tts_handle_t h) {
     if (h->hio.out) hipStreamDestroy(h->hio.out);
     if (h->ev_aux) hipEventDestroy(h->ev_aux);
     if (h->ev_front_done) hipEventDestroy(h->ev_front_done);
+    for (int i = 0; i < 2; ++i) {
+        if (h->ev_enc_ready[i]) hipEventDestroy(h->ev_enc_ready[i]);
+        if (h->ev_dec_done[i]) hipEventDestroy(h->ev_dec_done[i]);
+        if (h->ev_gap[i]) hipEventDestroy(h->ev_gap[i]);
+    }
+    if (h->encs) hipStreamDestroy(h->encs);
     if (h->ev_serial_done) hipEventDestroy(h->ev_serial_done);
     for (int i = 0; i < 2; ++i) {
         if (h->ev_post_done[i]) hipEventDestroy(h->ev_post_done[i]);
@@ -1377,6 +1397,11 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     else if (!std::strcmp(key, "fused_tail")) h->fused_tail = value;
     else if (!std::strcmp(key, "persistent_decoder")) h->persistent_decoder = value;
     else if (!std::strcmp(key, "gl_pair")) h->gl_pair = value;
+    else if (!std::strcmp(key, "enc_stream")) {
+        int rc = sync_all(h);
+        if (rc) return rc;
+        h->enc_stream = value;
+    }
     else if (!std::strcmp(key, "debug_hooks")) h->debug_hooks = value;
     else if (!std::strcmp(key, "pd_debug_delay") || !std::strcmp(key, "gl_runs") || !std::strcmp(key, "gl_run_len") ||
              !std::strcmp(key, "timeline")) {
@@ -1994,7 +2019,10 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     if (gl_streaming && (rc = gl_prepare(h, T, sp->win_length, sp->hop_length, c.n_fft))) return rc;
     if (!gl_streaming && (sp->win_length < 2 || sp->win_length > c.n_fft || sp->hop_length < 1))
         return fail(h, TTS_ERR_INVALID, "synthesize: need 2 <= win_length <= n_fft, hop_length >= 1");
-    WS(h, "syn.memory", float, (size_t)B * Ts * 2 * c.n_gru_units, memory);
+    // (one encoder output per call parity: the encoder of call k + 1 writes one while the decoder of call k reads the other)
+    WS(h, "syn.memory.even", float, (size_t)B * Ts * 2 * c.n_gru_units, memory_e);
+    WS(h, "syn.memory.odd", float, (size_t)B * Ts * 2 * c.n_gru_units, memory_o);
+    float* memory = ((h->syn_calls & 1) ? memory_o : memory_e);   // (syn_calls is advanced below: this call's parity)
     // The decoder output is double-buffered by call parity: the encoder / decoder of call j+1 (second
     // stream) may then run while the post-net of call j still reads its mel spectrogram.
     const int parity = (int)(h->syn_calls++ & 1);
@@ -2031,6 +2059,15 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
             HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
             HIPCHK(h, hipStreamCreateWithPriority(&h->front, hipStreamNonBlocking, prio_greatest));
             HIPCHK(h, hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, prio_greatest));
+            // (lowest priority: at the front stream's priority the encoder takes more from the post-net beside it than the
+            //  decoder's head start is worth -- 17.11 against 16.87 ms per step on one box; a third queue costs the
+            //  Griffin-Lim launches 3-4 % whatever its priority, which is why the step is not the decoder's 15.6 ms)
+            HIPCHK(h, hipStreamCreateWithPriority(&h->encs, hipStreamNonBlocking, prio_least));
+            for (int i = 0; i < 2; ++i) {
+                HIPCHK(h, hipEventCreateWithFlags(&h->ev_enc_ready[i], hipEventDisableTiming));
+                HIPCHK(h, hipEventCreateWithFlags(&h->ev_dec_done[i], hipEventDisableTiming));
+                HIPCHK(h, hipEventCreateWithFlags(&h->ev_gap[i], hipEventDisableTiming));
+            }
             HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->hold_flags), 2 * sizeof(int)));
             HIPCHK(h, cu_hold_configure());
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming));
@@ -2043,6 +2080,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
             // everything that is on the main stream now
             HIPCHK(h, hipEventRecord(h->ev_aux, h->stream));
             HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_aux, 0));
+            HIPCHK(h, hipStreamWaitEvent(h->encs, h->ev_aux, 0));
         }
     }
     hipStream_t main_stream = h->stream;
@@ -2062,6 +2100,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         // call's encoder and decoder are about to use on the front stream
         if (h->serial_pending) {
             HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_serial_done, 0));
+            HIPCHK(h, hipStreamWaitEvent(h->encs, h->ev_serial_done, 0));
             h->serial_pending = false;
         }
         if (mel_out && h->post_pending[parity ^ 1])
@@ -2076,18 +2115,46 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
             HIPCHK(h, hipEventRecord(h->ev_aux, h->aux));
             HIPCHK(h, launch_cu_hold(h->aux, h->reserve_cus, hold_flag, 100.0, h->hold_lds_kb));
             HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_aux, 0));
+            HIPCHK(h, hipStreamWaitEvent(h->encs, h->ev_aux, 0));
         }
-        h->stream = h->front;
+        // the encoder: on its own stream, behind the decoder that last read this parity's `memory` (the call two back) and
+        // behind the encoder before it (stream order: the encoder's scratch is one set)
+        if (h->enc_stream) {
+            if (h->dec_done_pending[parity]) HIPCHK(h, hipStreamWaitEvent(h->encs, h->ev_dec_done[parity], 0));
+            if (h->gap_pending[parity]) HIPCHK(h, hipStreamWaitEvent(h->encs, h->ev_gap[parity], 0));
+            h->stream = h->encs;
+        } else {
+            h->stream = h->front;
+        }
+    } else if (h->encs) {
+        // an unpipelined call runs its encoder and decoder on the main stream in the same scratch: behind whatever the
+        // pipelined calls before it still have on the encoder and front streams
+        for (int i = 0; i < 2; ++i) {
+            if (h->enc_ready_pending[i]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_enc_ready[i], 0));
+            if (h->dec_done_pending[i]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_dec_done[i], 0));
+        }
     }
     if (h->input_event) HIPCHK(h, hipStreamWaitEvent(h->stream, h->input_event, 0));   // (tts_synthesize_host: the ids' upload)
     rc = tts_encoder_forward(h, ids, B, Ts, memory);
     if (!rc && h->enc_done_event) HIPCHK(h, hipEventRecord(h->enc_done_event, h->stream));
+    if (pipelined) {
+        if (!rc && h->enc_stream) {
+            HIPCHK(h, hipEventRecord(h->ev_enc_ready[parity], h->encs));
+            h->enc_ready_pending[parity] = true;
+            HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_enc_ready[parity], 0));
+        }
+        h->stream = h->front;
+    }
     h->cur_hold_flag = hold_flag;
     h->cur_cu_budget = (pipelined && h->reserve_cus > 0) ? h->reserve_cus : 0;
     h->defer_projection = pipelined;
     h->defer_parity = parity;
     h->has_pending_proj = false;
     if (!rc) rc = tts_decoder_forward(h, memory, B, Ts, sp->n_steps, mel, align_out);
+    if (!rc && pipelined) {
+        HIPCHK(h, hipEventRecord(h->ev_dec_done[parity], h->front));
+        h->dec_done_pending[parity] = true;
+    }
     h->defer_projection = false;
     h->cur_hold_flag = nullptr;
     h->cur_cu_budget = 0;
@@ -2117,6 +2184,10 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     if (h->has_pending_proj) {   // the decoder's output projection, on the main stream (see defer_projection)
         h->has_pending_proj = false;
         if ((rc = run_single(h, h->pending_proj))) return rc;
+    }
+    if (h->encs) {   // the gap between two Griffin-Lim phases opens: the encoder of the next call of this parity may run
+        HIPCHK(h, hipEventRecord(h->ev_gap[parity], h->stream));
+        h->gap_pending[parity] = true;
     }
     int* db_flag = nullptr;
     if (denorm_can_assert(sp->ref_db, sp->max_db) && (rc = denorm_flag_arm(h, &db_flag))) return rc;
