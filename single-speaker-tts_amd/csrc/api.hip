@@ -2121,7 +2121,14 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         // behind the encoder before it (stream order: the encoder's scratch is one set)
         if (h->enc_stream) {
             if (h->dec_done_pending[parity]) HIPCHK(h, hipStreamWaitEvent(h->encs, h->ev_dec_done[parity], 0));
-            if (h->gap_pending[parity]) HIPCHK(h, hipStreamWaitEvent(h->encs, h->ev_gap[parity], 0));
+            // The HOST waits for the gap (the call returns at most ~2.5 calls ahead of the device: back-pressure), and the
+            // encoder is enqueued into an idle queue.  As a stream wait, enqueued two calls early, the barrier packet sat at
+            // the head of the third queue through a whole Griffin-Lim phase, and every kernel boundary of that phase took
+            // ~18 us longer (13.16 against 12.67 ms per call on one box, whatever the queue's priority).
+            if (h->gap_pending[parity]) {
+                if (h->enc_stream == 2) HIPCHK(h, hipStreamWaitEvent(h->encs, h->ev_gap[parity], 0));
+                else HIPCHK(h, hipEventSynchronize(h->ev_gap[parity]));
+            }
             h->stream = h->encs;
         } else {
             h->stream = h->front;
