@@ -227,9 +227,10 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
  * call is enqueued behind that upload (the initial phases are drawn on the device from p->seed, as the reference
  * draws them with np.random), and the waveforms are downloaded into pinned memory of the handle on a second copy
  * stream as soon as they are complete.  The call returns at once with a ticket; tts_wait_host blocks until that
- * call's waveforms have arrived and hands out the pinned buffer, [B * hop*(T-1)] floats, valid until the second
- * tts_synthesize_host call after the one that produced it (two buffers alternate).  Keep at most two calls in
- * flight: submit k + 1, then wait for k.  Bit-identical to tts_synthesize + tts_memcpy_d2h. */
+ * call's waveforms have arrived and hands out the pinned buffer, [B * hop*(T-1)] floats, valid until the THIRD
+ * tts_synthesize_host call after the one that produced it (three buffer sets rotate: the device holds three calls at
+ * once -- the encoder of call k + 2, the decoder of k + 1, the post-net / Griffin-Lim of k).  Keep at most three calls in
+ * flight: submit k + 2, then wait for k.  Bit-identical to tts_synthesize + tts_memcpy_d2h. */
 int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, const tts_synth_params_t* p,
                         int* ticket);
 int tts_wait_host(tts_handle_t h, int ticket, const float** wav_host, size_t* n_floats);

@@ -408,7 +408,7 @@ class Engine(object):
                         peak_normalize=True, want_linear=False, want_alignments=False):
         """Asynchronous end-to-end call on HOST ids (int32 (B, T_sent)): returns a ticket at once; the upload, the
         network, Griffin-Lim and the download of the waveforms into pinned memory overlap with the neighbouring
-        calls.  Keep at most two calls in flight: submit k + 1, then ``wait_host(ticket_k)``."""
+        calls.  Keep at most three calls in flight: submit k + 2, then ``wait_host(ticket_k)``."""
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         self._check_ids(ids)
         B, Ts = ids.shape

@@ -129,30 +129,31 @@ struct tts_handle_s {
     int cur_cu_budget = 0;           // ... and the compute units the front stream may count on (0 = the whole chip)
 
     // host-memory calls (tts_synthesize_host): pinned staging of the ids, device copies, pinned waveform buffers and the
-    // device buffers they are copied from, all per call parity; two copy streams
+    // device buffers they are copied from, one set per call in flight (ticket mod 3: the device pipeline holds three calls
+    // at once since round 4 -- encoder of k + 2, decoder of k + 1, Griffin-Lim of k); two copy streams
     struct {
         hipStream_t in = nullptr, out = nullptr;
-        int32_t* ids_pinned[2] = {nullptr, nullptr};
-        int32_t* ids_dev[2] = {nullptr, nullptr};
+        int32_t* ids_pinned[3] = {nullptr, nullptr, nullptr};
+        int32_t* ids_dev[3] = {nullptr, nullptr, nullptr};
         size_t ids_bytes = 0;
-        float* wav_dev[2] = {nullptr, nullptr};
-        float* wav_pinned[2] = {nullptr, nullptr};
+        float* wav_dev[3] = {nullptr, nullptr, nullptr};
+        float* wav_pinned[3] = {nullptr, nullptr, nullptr};
         size_t wav_bytes = 0;
-        hipEvent_t ev_h2d[2] = {nullptr, nullptr};      // upload of the ids done
-        hipEvent_t ev_enc[2] = {nullptr, nullptr};      // encoder done with the ids buffer
-        hipEvent_t ev_ready[2] = {nullptr, nullptr};    // waveforms complete on the device
-        hipEvent_t ev_d2h[2] = {nullptr, nullptr};      // waveforms have arrived in pinned memory
-        bool d2h_pending[2] = {false, false}, enc_pending[2] = {false, false};
-        size_t n_floats[2] = {0, 0};
+        hipEvent_t ev_h2d[3] = {nullptr, nullptr, nullptr};      // upload of the ids done
+        hipEvent_t ev_enc[3] = {nullptr, nullptr, nullptr};      // encoder done with the ids buffer
+        hipEvent_t ev_ready[3] = {nullptr, nullptr, nullptr};    // waveforms complete on the device
+        hipEvent_t ev_d2h[3] = {nullptr, nullptr, nullptr};      // waveforms have arrived in pinned memory
+        bool d2h_pending[3] = {false, false, false}, enc_pending[3] = {false, false, false};
+        size_t n_floats[3] = {0, 0, 0};
         // optional outputs of a host call (tts_synth_params_t::host_outputs): linear spectrograms and alignments
-        float* lin_dev[2] = {nullptr, nullptr};
-        float* lin_pinned[2] = {nullptr, nullptr};
+        float* lin_dev[3] = {nullptr, nullptr, nullptr};
+        float* lin_pinned[3] = {nullptr, nullptr, nullptr};
         size_t lin_bytes = 0;
-        float* ali_dev[2] = {nullptr, nullptr};
-        float* ali_pinned[2] = {nullptr, nullptr};
+        float* ali_dev[3] = {nullptr, nullptr, nullptr};
+        float* ali_pinned[3] = {nullptr, nullptr, nullptr};
         size_t ali_bytes = 0;
-        size_t n_lin[2] = {0, 0}, n_ali[2] = {0, 0};
-        int* status_pinned = nullptr;   // [2][2]: the persistent decoder's sticky status word ([.][1]) as it stood behind
+        size_t n_lin[3] = {0, 0, 0}, n_ali[3] = {0, 0, 0};
+        int* status_pinned = nullptr;   // [3][2]: the persistent decoder's sticky status word ([.][1]) as it stood behind
                                         // each call's download
         int tickets = 0;
     } hio;
@@ -1323,7 +1324,7 @@ int tts_destroy(tts_handle_t h) {
         hipStreamDestroy(h->aux);
     }
     if (h->hold_flags) hipFree(h->hold_flags);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         if (h->hio.ids_pinned[i]) hipHostFree(h->hio.ids_pinned[i]);
         if (h->hio.ids_dev[i]) hipFree(h->hio.ids_dev[i]);
         if (h->hio.wav_pinned[i]) hipHostFree(h->hio.wav_pinned[i]);
@@ -2241,13 +2242,13 @@ int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, 
         HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         HIPCHK(h, hipStreamCreateWithPriority(&io.in, hipStreamNonBlocking, prio_least));
         HIPCHK(h, hipStreamCreateWithPriority(&io.out, hipStreamNonBlocking, prio_least));
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 3; ++i) {
             HIPCHK(h, hipEventCreateWithFlags(&io.ev_h2d[i], hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&io.ev_enc[i], hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&io.ev_ready[i], hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&io.ev_d2h[i], hipEventDisableTiming));
         }
-        HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&io.status_pinned), 4 * sizeof(int), hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&io.status_pinned), 6 * sizeof(int), hipHostMallocDefault));
     }
     if (ids_bytes > io.ids_bytes || n_wav * sizeof(float) > io.wav_bytes || n_lin * sizeof(float) > io.lin_bytes ||
         n_ali * sizeof(float) > io.ali_bytes) {
@@ -2255,7 +2256,7 @@ int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, 
         if ((rc = sync_all(h))) return rc;
         HIPCHK(h, hipStreamSynchronize(io.in));
         HIPCHK(h, hipStreamSynchronize(io.out));
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 3; ++i) {
             if (ids_bytes > io.ids_bytes) {
                 if (io.ids_pinned[i]) HIPCHK(h, hipHostFree(io.ids_pinned[i]));
                 if (io.ids_dev[i]) HIPCHK(h, hipFree(io.ids_dev[i]));
@@ -2288,18 +2289,18 @@ int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, 
         io.ali_bytes = std::max(io.ali_bytes, n_ali * sizeof(float));
     }
     const int t = io.tickets++;
-    const int par = t & 1;
-    // the pinned staging buffer and the device copy of the ids were last used by the call two back
+    const int par = t % 3;   // (buffer set of this call; the device-side pipeline keeps its own parity)
+    // the pinned staging buffer and the device copy of the ids were last used by the call three back
     if (io.d2h_pending[par]) HIPCHK(h, hipEventSynchronize(io.ev_h2d[par]));
     std::memcpy(io.ids_pinned[par], ids_host, ids_bytes);
     if (io.enc_pending[par]) HIPCHK(h, hipStreamWaitEvent(io.in, io.ev_enc[par], 0));
     HIPCHK(h, hipMemcpyAsync(io.ids_dev[par], io.ids_pinned[par], ids_bytes, hipMemcpyHostToDevice, io.in));
     HIPCHK(h, hipEventRecord(io.ev_h2d[par], io.in));
-    // the waveform buffer of this parity is free once the download of the call two back has left it
+    // the waveform buffer of this set is free once the download of the call three back has left it
     if (io.d2h_pending[par]) HIPCHK(h, hipStreamWaitEvent(h->stream, io.ev_d2h[par], 0));
     h->input_event = io.ev_h2d[par];
     h->enc_done_event = io.ev_enc[par];
-    // (the optional outputs of this parity were last read by the download of the call two back: same event as the waveforms)
+    // (the optional outputs of this set were last read by the download of the call three back: same event as the waveforms)
     rc = tts_synthesize(h, io.ids_dev[par], B, Ts, sp, nullptr, io.wav_dev[par], nullptr, want_ali ? io.ali_dev[par] : nullptr,
                         want_lin ? io.lin_dev[par] : nullptr);
     h->input_event = nullptr;
@@ -2330,9 +2331,9 @@ int tts_wait_host(tts_handle_t h, int ticket, const float** wav_host, size_t* n_
     DeviceScope dev_scope(h);
     if (!h || !wav_host) return TTS_ERR_INVALID;
     auto& io = h->hio;
-    if (ticket < 0 || ticket >= io.tickets || ticket < io.tickets - 2)
-        return fail(h, TTS_ERR_INVALID, "wait_host: this ticket's buffer has been handed to a later call (at most two calls in flight)");
-    const int par = ticket & 1;
+    if (ticket < 0 || ticket >= io.tickets || ticket < io.tickets - 3)
+        return fail(h, TTS_ERR_INVALID, "wait_host: this ticket's buffer has been handed to a later call (at most three calls in flight)");
+    const int par = ticket % 3;
     HIPCHK(h, hipEventSynchronize(io.ev_d2h[par]));
     // the download is behind everything the call launched: a timed-out persistent kernel must not pass for a result
     if (io.status_pinned[2 * par + 1]) {
@@ -2361,7 +2362,7 @@ int tts_wait_host_outputs(tts_handle_t h, int ticket, const float** linear_host,
     const int rc = tts_wait_host(h, ticket, &wav, nullptr);   // same event, same checks (ticket range, decoder status)
     if (rc) return rc;
     auto& io = h->hio;
-    const int par = ticket & 1;
+    const int par = ticket % 3;
     if (linear_host) *linear_host = io.n_lin[par] ? io.lin_pinned[par] : nullptr;
     if (n_linear) *n_linear = io.n_lin[par];
     if (align_host) *align_host = io.n_ali[par] ? io.ali_pinned[par] : nullptr;

@@ -68,10 +68,10 @@ def synthesize_batch(model, sentences, n_steps=None, n_iter=None, init_phase=Non
 def synthesize_stream(model, batches, n_steps=None, n_iter=None, seed=0, peak_normalize=False, copy=False, want_linear=False,
                       want_alignments=False):
     """Generator over batches of padded id sequences (each (B, T_sent) int32, HOST arrays) -> per batch the waveforms
-    (B, hop*(T-1)) float32 in host memory, with TWO batches in flight: batch k + 1 is uploaded and its encoder /
-    decoder run while batch k is in its post-net / Griffin-Lim and batch k - 1 is being downloaded (the reference
-    runs the batches one after the other, tacotron/inference.py:75-101,185-200).  The arrays yielded are views of the
-    library's pinned buffers unless ``copy``: valid until the next-but-one batch has been requested.
+    (B, hop*(T-1)) float32 in host memory, with THREE batches in flight: batch k + 2 is uploaded and encoded, batch k + 1
+    is in its decoder, batch k in its post-net / Griffin-Lim while batch k - 1 is being downloaded (the reference runs the
+    batches one after the other, tacotron/inference.py:75-101,185-200).  The arrays yielded are views of the library's
+    pinned buffers unless ``copy``: valid until two more batches have been requested.
 
     With ``want_linear`` / ``want_alignments`` every item is a tuple ``(wavs, linear, alignments)``: the normalised linear
     spectrograms (B, T, 1025) -- what ``model.output_linear_spec`` is, the thing the reference's ``inference()`` fetches
@@ -92,20 +92,21 @@ def synthesize_stream(model, batches, n_steps=None, n_iter=None, seed=0, peak_no
         lin, ali = eng.wait_host_outputs(ticket, copy=copy)
         return eng.wait_host(ticket, copy=copy), lin, ali
 
-    pending = None
+    # three batches in flight (the library's three buffer sets): the encoder of batch k + 2 runs one inter-Griffin-Lim gap
+    # ahead of its decoder, which follows the decoder of batch k + 1 without a pause, beside the Griffin-Lim of batch k
+    pending = []
     for k, ids in enumerate(batches):
-        t = eng.synthesize_host(ids, S, loader.mel_mag_ref_db, loader.mel_mag_max_db, hp.magnitude_power, it, win_len,
-                                win_hop, seed=seed + k, peak_normalize=peak_normalize, want_linear=want_linear,
-                                want_alignments=want_alignments)
-        if pending is not None:
-            yield collect(pending)
-        pending = t
-    if pending is not None:
-        yield collect(pending)
+        pending.append(eng.synthesize_host(ids, S, loader.mel_mag_ref_db, loader.mel_mag_max_db, hp.magnitude_power, it, win_len,
+                                           win_hop, seed=seed + k, peak_normalize=peak_normalize, want_linear=want_linear,
+                                           want_alignments=want_alignments))
+        if len(pending) == 3:
+            yield collect(pending.pop(0))
+    while pending:
+        yield collect(pending.pop(0))
 
 
 def inference_stream(model, batches, n_steps=None, n_iter=None, seed=0):
-    """``inference()`` over a stream of batches with two calls in flight: per batch ``(spectrograms, waveforms)`` where
+    """``inference()`` over a stream of batches with three calls in flight: per batch ``(spectrograms, waveforms)`` where
     ``spectrograms`` is what the reference's ``inference()`` returns for that batch -- per utterance the (1025, T) linear
     magnitude spectrogram ``decibel_to_magnitude(inv_normalize_decibel(spec.T, mel_ref_db, mel_max_db))``
     (tacotron/inference.py:93-101; computed on the host from the downloaded network output with the conversions of

@@ -44,9 +44,9 @@ def serve(sentence_generator, weights, dataset=None, device_id=0, pipelined=Fals
 
     Default: the reference's request/response order -- every batch is answered before the next one is pulled from
     ``sentence_generator`` (reference serve.py:108-124 blocks on a live generator, and a client may wait for its answer
-    before it sends more).  ``pipelined=True`` keeps two batches in flight for OFFLINE streams whose batches are all
-    available: batch k is then yielded only after batch k + 1 has been pulled from the generator (the last one when the
-    generator ends), which on a request-driven generator would hold every answer back by one request."""
+    before it sends more).  ``pipelined=True`` keeps three batches in flight for OFFLINE streams whose batches are all
+    available: batch k is then yielded only after batch k + 2 has been pulled from the generator (the last one when the
+    generator ends), which on a request-driven generator would hold every answer back by two requests."""
     from ..datasets.lj_speech import LJSpeechDatasetHelper
     dataset = dataset or LJSpeechDatasetHelper(dataset_folder=dataset_params.dataset_folder,
                                                 char_dict=dataset_params.vocabulary_dict, fill_dict=False)
@@ -57,7 +57,7 @@ def serve(sentence_generator, weights, dataset=None, device_id=0, pipelined=Fals
             spectrograms = model.run(model.output_linear_spec, {model.inp_sentences: ids})
             yield post_process_spectrograms(spectrograms, model.engine)
         return
-    # two batches in flight, nothing but ids and waveforms crosses the host boundary (inference.synthesize_stream)
+    # three batches in flight, nothing but ids and waveforms crosses the host boundary (inference.synthesize_stream)
     from .inference import synthesize_stream
     batches = (pre_process_sentences(sentences, dataset) for sentences in sentence_generator)
     for wavs in synthesize_stream(model, batches, peak_normalize=False, copy=True):

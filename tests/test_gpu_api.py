@@ -271,7 +271,7 @@ def test_weights_through_the_checkpoint_importer_match_the_oracle(tmp_path, form
 
 
 def test_host_facade_two_calls_in_flight_equals_serial_calls(engine, hparams):
-    """tacotron.inference.synthesize_stream (host ids in, host waveforms out, two batches in flight: the upload of batch
+    """tacotron.inference.synthesize_stream (host ids in, host waveforms out, three batches in flight: the upload of batch
     k + 1 and the download of batch k - 1 overlap batch k) gives, bit for bit, what one serialised device call per batch
     gives -- for batches of changing content and a changing sentence length (the second shape is new: unpipelined once)."""
     Inf = pkg('tacotron.inference')
@@ -327,7 +327,7 @@ def test_host_facade_two_calls_in_flight_equals_serial_calls(engine, hparams):
 
 
 def test_host_facade_keeps_the_call_pipeline():
-    """Throughput guard: through host memory (tts_synthesize_host / tts_wait_host, two calls in flight) a batch takes what it
+    """Throughput guard: through host memory (tts_synthesize_host / tts_wait_host, three calls in flight) a batch takes what it
     takes in a device-resident loop -- the copy streams must not end up serialising the front and the main stream (they did
     once: streams of one priority share a few hardware queues).  Bench shape, `bench.py --through-facade` in a process of
     its own: a process that has imported torch runs the library on torch's bundled HIP runtime, where the same loop is
