@@ -211,9 +211,12 @@ def self_launch(args, argv):
 
 
 def timed_broadcasts(dist, shard, blob, bdev, rank):
-    """The ONE collective of the path, twice: the first broadcast includes the communicator set-up of the first collective,
-    the second is what the 27.4 MB cost on the wire.  Returns (blob, first_ms, steady_ms)."""
+    """The ONE collective of the path, twice, behind a barrier that takes the communicator set-up (the first collective of
+    the process group): the second broadcast is what the 27.4 MB cost on the wire once everything is warm.
+    Returns (blob, setup_ms, first_ms, steady_ms)."""
+    t0 = time.perf_counter()
     dist.barrier()
+    setup_ms = 1e3 * (time.perf_counter() - t0)
     t0 = time.perf_counter()
     blob = shard.broadcast_blob(blob, src=0, device=bdev)
     dist.barrier()
@@ -224,7 +227,7 @@ def timed_broadcasts(dist, shard, blob, bdev, rank):
     steady_ms = 1e3 * (time.perf_counter() - t0)
     if not np.array_equal(again, blob):
         raise SystemExit('rank {}: the second weight broadcast differs from the first'.format(rank))
-    return blob, first_ms, steady_ms
+    return blob, setup_ms, first_ms, steady_ms
 
 
 def gather_rank_devices(dist, world, rank, dev_uuid, dev_cus):
@@ -255,11 +258,12 @@ def gather_rank_ms(dist, world, own_ms):
     return own
 
 
-def rank_fields(rank_ms, rank_devices, first_ms, steady_ms, padded_len):
+def rank_fields(rank_ms, rank_devices, first_ms, steady_ms, padded_len, setup_ms=None):
     """the N > 1 diagnostics of the JSON line (None / one entry for a single process)"""
     return {
-        'weight_broadcast_ms': first_ms,
-        'weight_broadcast_ms_steady': steady_ms,
+        'communicator_setup_ms': setup_ms,            # the first barrier = the first collective of the process group
+        'weight_broadcast_ms': first_ms,              # the weight broadcast of the run (first use of the broadcast)
+        'weight_broadcast_ms_steady': steady_ms,      # the same 27.4 MB again
         'rank_ms_per_step': rank_ms,
         'rank_ms_per_step_min': min(rank_ms) if rank_ms else None,
         'rank_ms_per_step_max': max(rank_ms) if rank_ms else None,
@@ -276,7 +280,7 @@ def dist_selftest(rank, local_rank, world, dist):
     Wm = importlib.import_module('single-speaker-tts_amd.tacotron.weights')
     n = Wm.n_parameters()
     blob = Wm.pack_blob(Wm.synthetic_weights(0)) if rank == 0 else np.zeros(n, np.float32)
-    got, first_ms, steady_ms = timed_broadcasts(dist, shard, blob, 'cpu', rank)
+    got, setup_ms, first_ms, steady_ms = timed_broadcasts(dist, shard, blob, 'cpu', rank)
     import torch
     t = torch.tensor([float(np.abs(got).sum()), float(rank)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -291,7 +295,7 @@ def dist_selftest(rank, local_rank, world, dist):
     if rank == 0:
         rec = {'selftest': 'dist', 'n_gpus': world, 'world_size_seen': dist.get_world_size(),
                'backend': dist.get_backend(), 'ok': all(flags)}
-        rec.update(rank_fields(rank_ms, devs, first_ms, steady_ms, padded))
+        rec.update(rank_fields(rank_ms, devs, first_ms, steady_ms, padded, setup_ms))
         print(json.dumps(rec), flush=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -364,14 +368,15 @@ def main():
         blob = Wm.pack_blob(weights, hp)
     else:
         blob = np.empty(n_floats, np.float32)
-    broadcast_ms = None          # first broadcast: includes the communicator set-up of the first collective
-    broadcast_ms_steady = None   # the same broadcast again, communicator up: what the 27.4 MB cost on the wire
+    setup_ms = None              # the first collective (a barrier): communicator set-up
+    broadcast_ms = None          # the weight broadcast
+    broadcast_ms_steady = None   # the same broadcast again: what the 27.4 MB cost on the wire
     if dist is not None:
         # the ONE collective of the path (RCCL over xGMI under "nccl"); nothing is exchanged afterwards
         if dist.get_world_size() != args.gpus:
             raise SystemExit('process group has {} ranks, --gpus says {}'.format(dist.get_world_size(), args.gpus))
         bdev = 'cuda:{}'.format(local_rank) if dist.get_backend() == 'nccl' else 'cpu'
-        blob, broadcast_ms, broadcast_ms_steady = timed_broadcasts(dist, shard, blob, bdev, rank)
+        blob, setup_ms, broadcast_ms, broadcast_ms_steady = timed_broadcasts(dist, shard, blob, bdev, rank)
     eng = sstts.Engine(hp, device_id=local_rank)
     if dist is not None and dist.get_backend() == 'nccl':
         import torch
@@ -545,7 +550,7 @@ def main():
             'world_size_seen': dist.get_world_size() if dist is not None else 1,
             # N > 1 diagnostics: the first broadcast (communicator set-up included) against the same 27.4 MB again; every
             # rank's own ms per step and the slowest rank; the devices the ranks sat on; the global padded length
-            **rank_fields(rank_ms, rank_devices, broadcast_ms, broadcast_ms_steady, padded_len),
+            **rank_fields(rank_ms, rank_devices, broadcast_ms, broadcast_ms_steady, padded_len, setup_ms),
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': ms_per_step,

@@ -2023,7 +2023,14 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     // (one encoder output per call parity: the encoder of call k + 1 writes one while the decoder of call k reads the other)
     WS(h, "syn.memory.even", float, (size_t)B * Ts * 2 * c.n_gru_units, memory_e);
     WS(h, "syn.memory.odd", float, (size_t)B * Ts * 2 * c.n_gru_units, memory_o);
-    float* memory = ((h->syn_calls & 1) ? memory_o : memory_e);   // (syn_calls is advanced below: this call's parity)
+    // (alternating only where the encoder really runs ahead: under the call pipeline with the persistent decoder.  The
+    //  launch-per-layer decoder replays a hipGraph with its buffers baked in -- a second `memory` would re-capture it every call)
+    const bool enc_ahead_cfg = h->enc_stream && h->pipeline && (h->own_stream || h->pipeline >= 2) &&
+                               h->syn_shape[0] == B && h->syn_shape[1] == Ts && h->syn_shape[2] == sp->n_steps &&
+                               (h->persistent_decoder >= 2 || (h->persistent_decoder == 1 && B > 48)) && h->reserve_cus > 0 &&
+                               decoder_persistent_supports(h->dec, c.force_cudnn, B, Ts) &&
+                               decoder_persistent_workgroups(B) <= h->reserve_cus;
+    float* memory = (enc_ahead_cfg && (h->syn_calls & 1)) ? memory_o : memory_e;   // (syn_calls is advanced below: this call's parity)
     // The decoder output is double-buffered by call parity: the encoder / decoder of call j+1 (second
     // stream) may then run while the post-net of call j still reads its mel spectrogram.
     const int parity = (int)(h->syn_calls++ & 1);
@@ -2120,7 +2127,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         }
         // the encoder: on its own stream, behind the decoder that last read this parity's `memory` (the call two back) and
         // behind the encoder before it (stream order: the encoder's scratch is one set)
-        if (h->enc_stream) {
+        if (enc_ahead_cfg) {
             if (h->dec_done_pending[parity]) HIPCHK(h, hipStreamWaitEvent(h->encs, h->ev_dec_done[parity], 0));
             // The HOST waits for the gap (the call returns at most ~2.5 calls ahead of the device: back-pressure), and the
             // encoder is enqueued into an idle queue.  As a stream wait, enqueued two calls early, the barrier packet sat at
@@ -2132,6 +2139,10 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
             }
             h->stream = h->encs;
         } else {
+            // the encoder in front of its decoder on the front stream (one `memory` buffer): behind whatever encoders and
+            // decoders of earlier calls are still on the encoder / front streams (the front stream's own order covers the latter)
+            for (int i = 0; i < 2; ++i)
+                if (h->enc_ready_pending[i]) HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_enc_ready[i], 0));
             h->stream = h->front;
         }
     } else if (h->encs) {
@@ -2146,7 +2157,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     rc = tts_encoder_forward(h, ids, B, Ts, memory);
     if (!rc && h->enc_done_event) HIPCHK(h, hipEventRecord(h->enc_done_event, h->stream));
     if (pipelined) {
-        if (!rc && h->enc_stream) {
+        if (!rc && enc_ahead_cfg) {
             HIPCHK(h, hipEventRecord(h->ev_enc_ready[parity], h->encs));
             h->enc_ready_pending[parity] = true;
             HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_enc_ready[parity], 0));

@@ -76,7 +76,7 @@ def test_bench_self_launches_n_ranks(tmp_path):
     # straggler named, the first broadcast against the steady one, one device record per rank, the global padded length
     assert rec['rank_ms_per_step'] == [1.0, 2.0] and rec['straggler_rank'] == 1
     assert rec['rank_ms_per_step_min'] == 1.0 and rec['rank_ms_per_step_max'] == 2.0
-    assert rec['weight_broadcast_ms'] > 0 and rec['weight_broadcast_ms_steady'] > 0
+    assert rec['weight_broadcast_ms'] > 0 and rec['weight_broadcast_ms_steady'] > 0 and rec['communicator_setup_ms'] > 0
     assert [d['uuid'] for d in rec['rank_devices']] == ['selftest-rank0', 'selftest-rank1']
     assert rec['padded_sentence_length'] == 150
 
@@ -107,6 +107,6 @@ def test_bench_under_torch_distributed_run():
     # straggler named, the first broadcast against the steady one, one device record per rank, the global padded length
     assert rec['rank_ms_per_step'] == [1.0, 2.0] and rec['straggler_rank'] == 1
     assert rec['rank_ms_per_step_min'] == 1.0 and rec['rank_ms_per_step_max'] == 2.0
-    assert rec['weight_broadcast_ms'] > 0 and rec['weight_broadcast_ms_steady'] > 0
+    assert rec['weight_broadcast_ms'] > 0 and rec['weight_broadcast_ms_steady'] > 0 and rec['communicator_setup_ms'] > 0
     assert [d['uuid'] for d in rec['rank_devices']] == ['selftest-rank0', 'selftest-rank1']
     assert rec['padded_sentence_length'] == 150

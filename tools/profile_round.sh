@@ -41,12 +41,13 @@ PY
 echo "== GL SQ counters"; bash $R/tools/gl_pmc.sh $TAG > $O/gl_pmc.log 2>&1; cp $R/gpurun_out/${TAG}_gl_pmc.txt $O/${TAG}_gl_iter_sq_counters.txt
 python3 $R/tools/gl_counters_json.py $O/${TAG}_gl_iter_sq_counters.txt $O/${TAG}_gl_iter_valu.json 3
 echo "== GEMM MFMA counters"
-G1="SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"
+G1="SQ_INSTS_VALU_MFMA_BF16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"
 G2="SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 G3="GRBM_GUI_ACTIVE"
 i=0
 for G in "$G1" "$G2" "$G3"; do i=$((i+1)); rm -rf $O/mfma/p$i; rocprofv3 --kernel-trace --pmc $G --output-format csv -d $O/mfma/p$i -- python3 $R/tools/net_bench.py > $O/mfma_p$i.log 2>&1; done
-python3 $R/tools/pmc_summary.py $O/mfma gemm_f32_kernel bigru_kernel > $O/${TAG}_gemm_mfma_counters.txt; head -30 $O/${TAG}_gemm_mfma_counters.txt
+python3 $R/tools/pmc_summary.py $O/mfma gemm_f32_kernel gemm_f32_pool_kernel cbhg_tail_kernel bigru_kernel > $O/${TAG}_gemm_mfma_counters.txt; head -30 $O/${TAG}_gemm_mfma_counters.txt
+echo "== step timeline"; bash $R/tools/trace_step.sh ${TAG}_trace > $O/${TAG}_step_timeline.txt 2>&1
 echo "== stage benchmarks"
 ( echo "# tools/gemm_bench.py"; python3 $R/tools/gemm_bench.py; echo; echo "# tools/net_bench.py"; python3 $R/tools/net_bench.py; echo; echo "# tools/dec_bench.py"; python3 $R/tools/dec_bench.py; echo; echo "# tools/gl_bench.py"; python3 $R/tools/gl_bench.py; echo; echo "# tools/latency_bench.py"; python3 $R/tools/latency_bench.py; echo; echo "# tools/pipeline_sweep.py"; python3 $R/tools/pipeline_sweep.py ) > $O/${TAG}_stage_benchmarks.txt 2>&1
 tail -12 $O/${TAG}_stage_benchmarks.txt
