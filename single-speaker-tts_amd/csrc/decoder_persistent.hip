@@ -111,13 +111,12 @@ size_t pd_lds_bytes(int Ts) { return ((size_t)PD_OFF_SC + 2 * (size_t)((Ts + 3) 
 size_t pd_lds_bytes(int Ts) { return ((size_t)PD_OFF_SC + 2 * (size_t)((Ts + 3) & ~3)) * sizeof(float); }
 #endif
 
-// Start of a phase: signal that this workgroup's stores of the PREVIOUS phase are complete (pd_publish ran), then
-// wait until `target` arrivals have been counted on the cluster's counter.  Lane 0 of the workgroup does both; the
-// arrival is issued here, after the caller has put its weight loads in flight, because the lane that adds also
-// waits for the add's round trip before its next memory access returns.
+// Start of a phase: wait until `target` arrivals have been counted on the cluster's counter (lane 0 polls, everybody
+// meets at the barrier).  The arrival of THIS workgroup for the previous phase was signalled when that phase ended
+// (pd_publish): until round 4 it was signalled here, behind the next phase's weight requests and address arithmetic --
+// 1.0-1.4 us in which the peers could not yet see that this workgroup was done, on every phase's critical path.
 __device__ __forceinline__ void pd_wait(unsigned* cnt, unsigned target, int* status, int* ctrl) {
     if (threadIdx.x == 0 && target > 0) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ctrl[0] == 0) {
             unsigned spins = 0;
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -135,10 +134,11 @@ __device__ __forceinline__ void pd_wait(unsigned* cnt, unsigned target, int* sta
 }
 
 // End of a phase: every storing wave waits for its (write-through) stores, then the workgroup barrier -- after it
-// one lane may signal for all of them (pd_wait of the next phase).
-__device__ __forceinline__ void pd_publish() {
+// one lane signals for all of them: the arrival on the cluster's counter (agent scope), at once.
+__device__ __forceinline__ void pd_publish(unsigned* cnt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One GEMM-shaped phase of the cluster: out[16 rows][this workgroup's units] = epi([a0 | a1] . Wt^T + bias).
@@ -301,7 +301,7 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, int j, i
     }
     PD_STAMP(4)
     if (ph.more) __syncthreads();   // r / u are in LDS, the partial tiles may be overwritten
-    else pd_publish();
+    else pd_publish(cnt);
     PD_STAMP(5)
 }
 
@@ -496,7 +496,7 @@ __device__ __forceinline__ void pd_attention_body(const float* __restrict__ quer
         }
     }
     PD_STAMP(4)
-    pd_publish();
+    pd_publish(cnt);
     PD_STAMP(5)
 }
 __device__ __attribute__((noinline)) void pd_attention_local(const float* query, const float* keys, const float* values, float* ctx,
