@@ -106,7 +106,11 @@ int tts_set_stream(tts_handle_t h, void* hip_stream);
  * with more than 48 utterances per call, where it pays (default), 2 = whenever the configuration allows, 0 = never; tts_synchronize reports TTS_ERR_HIP if one of its bounded waits timed out),
  * "gl_pair" (Griffin-Lim iterations per launch, 1..3, default 3: the spectrum passes from one iteration to the next in
  * registers; identical arithmetic per iteration), "fused_tail" (default 1: lifter + highway stack + GRU input
- * projections of a CBHG as one launch; 0 = layer by layer).
+ * projections of a CBHG as one launch; 0 = layer by layer), "enc_stream" (default 1: under the call pipeline with the
+ * persistent decoder the encoder of a call runs on a stream of its own, one inter-Griffin-Lim gap ahead of its decoder, so
+ * that the decoders of consecutive calls follow each other without a pause; tts_synthesize then waits on the HOST until the
+ * device has reached the post-net of the call two back -- at most ~2.5 calls are ever queued; 0 = the encoder in front of
+ * its decoder on the front stream, calls never block).
  * Test and diagnostic hooks -- per handle, inert (and refused with a non-zero value) until "debug_hooks" has been set to 1
  * on the same handle; nothing in the process environment changes what a call computes: "pd_debug_delay" (workgroup 3 of
  * every persistent-decoder cluster stages its tile that many x ~3.4 us late), "gl_runs" / "gl_run_len" (force the cut of

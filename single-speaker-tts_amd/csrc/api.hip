@@ -2133,10 +2133,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
             // encoder is enqueued into an idle queue.  As a stream wait, enqueued two calls early, the barrier packet sat at
             // the head of the third queue through a whole Griffin-Lim phase, and every kernel boundary of that phase took
             // ~18 us longer (13.16 against 12.67 ms per call on one box, whatever the queue's priority).
-            if (h->gap_pending[parity]) {
-                if (h->enc_stream == 2) HIPCHK(h, hipStreamWaitEvent(h->encs, h->ev_gap[parity], 0));
-                else HIPCHK(h, hipEventSynchronize(h->ev_gap[parity]));
-            }
+            if (h->gap_pending[parity]) HIPCHK(h, hipEventSynchronize(h->ev_gap[parity]));
             h->stream = h->encs;
         } else {
             // the encoder in front of its decoder on the front stream (one `memory` buffer): behind whatever encoders and

@@ -120,7 +120,9 @@ __device__ __forceinline__ void pd_wait(unsigned* cnt, unsigned target, int* sta
         if (ctrl[0] == 0) {
             unsigned spins = 0;
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+#ifndef PD_NO_POLL_SLEEP
                 __builtin_amdgcn_s_sleep(1);
+#endif
                 if ((++spins & 1023u) == 0 &&
                     (spins > PD_SPIN_LIMIT || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                     __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
