@@ -875,12 +875,13 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     // |S| e^{i phi}: x * (|S| / |x|), and (|S|, 0) for a zero bin (numpy's exp(1j * angle(0)) = 1); the
                     // bins are X / MH of a windowed signal, far from both ends of the float range
                     // |S| x / |x|, and (|S|, 0) for a zero bin (numpy's exp(1j * angle(0)) = 1) WITHOUT a compare and two selects
-                    // per bin: 1e-15 is added to the real part (a zero bin becomes (1e-15, 0) and normalises to (|S|, 0); any
-                    // bin that carries signal is >= 1e-8 of the spectrum's scale and does not see it) and 1e-37 to |x|^2 (so
-                    // that no reciprocal square root of zero is ever multiplied by zero).  6 VALU instructions per bin, 9 before
+                    // per bin: 1e-17 is added to the real part (a zero bin becomes (1e-17, 0) and normalises to (|S|, 0) within
+                    // 5e-5; a bin of 1e-9 -- the spectrum X / 1024 of a frame at the -100 dB floor -- moves by 1e-8 of itself,
+                    // below the rounding of the FFT that made it) and 1e-38 to |x|^2 (so that no reciprocal square root of zero
+                    // is ever multiplied by zero).  6 VALU instructions per bin, 9 before
                     auto normalise = [&](cf x, float mag_) __attribute__((always_inline)) {
-                        const float xr = x.x + 1.0e-15f;
-                        const float s2 = fmaf(xr, xr, fmaf(x.y, x.y, 1.0e-37f));
+                        const float xr = x.x + 1.0e-17f;
+                        const float s2 = fmaf(xr, xr, fmaf(x.y, x.y, 1.0e-38f));
                         const float g = mag_ * __builtin_amdgcn_rsqf(s2);
                         return cscale(cmk(xr, x.y), g);
                     };
