@@ -72,6 +72,13 @@ def test_unsupported_configs_are_rejected(hparams):
     eng.close()
 
 
+def test_device_info(engine):
+    """tts_device_info: 32 hex digits of the device's UUID and its compute-unit count (what bench.py compares across ranks)."""
+    uuid, cus = engine.device_info()
+    assert len(uuid) == 32 and all(c in '0123456789abcdef' for c in uuid) and cus >= 64
+    assert engine.device_info() == (uuid, cus)
+
+
 def test_stft_and_mel_features(engine):
     rng = np.random.default_rng(0)
     F = pkg('audio.features')

@@ -162,6 +162,42 @@ def test_pipelined_calls_equal_sequential(engine):
         engine.set_option('persistent_decoder', 1)
 
 
+def test_encoder_ahead_equals_encoder_in_front(engine):
+    """Round 4: under the call pipeline with the persistent decoder the encoder of a call runs on a stream of its own, one
+    inter-Griffin-Lim gap ahead of its decoder (`memory` double-buffered by call parity, the host waiting for the gap).  The
+    option enc_stream = 0 restores the round-3 order (encoder in front of its decoder on the front stream): same bits, for
+    calls of changing content, with an unpipelined call of another shape and a stand-alone encoder call in between."""
+    batches = [bench_ids(5, 21, 70 + i) for i in range(7)]
+    other = bench_ids(2, 9, 99)
+
+    def run(enc_stream):
+        engine.set_option('enc_stream', enc_stream)
+        outs = []
+        for i, b in enumerate(batches):
+            outs.append(engine.synthesize(engine.to_device(b), 6, 6.02, 99.89, 1.3, 4, WIN, HOP, seed=500 + i,
+                                          want_mel=True, want_alignments=True, want_linear=True))
+            if i == 3:   # a call of another shape (unpipelined: it sizes nothing new the second time round, but breaks the rhythm)
+                outs.append(engine.synthesize(engine.to_device(other), 6, 6.02, 99.89, 1.3, 4, WIN, HOP, seed=9, want_mel=True))
+            if i == 4:   # the encoder's scratch is shared with stand-alone calls
+                engine.encoder_forward(engine.to_device(other))
+        engine.synchronize()
+        return [{k: v.to_host() for k, v in o.items() if v is not None} for o in outs]
+
+    try:
+        engine.set_option('persistent_decoder', 2)   # (the encoder only runs ahead beside the persistent decoder)
+        run(1)                                        # shapes known: the second round is pipelined from its second call on
+        ahead = run(1)
+        front = run(0)
+        assert len(ahead) == len(front) == len(batches) + 1
+        for i, (a, b) in enumerate(zip(ahead, front)):
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (i, k)
+            assert np.isfinite(a['wav']).all() and np.abs(a['wav']).max() > 0
+    finally:
+        engine.set_option('enc_stream', 1)
+        engine.set_option('persistent_decoder', 1)
+
+
 def test_pipelined_calls_with_changing_shapes_equal_sequential(engine):
     """Shapes change between back-to-back calls, so unpipelined calls (the first of every new shape) alternate with
     pipelined ones, a stand-alone Griffin-Lim call sits in the middle, and calls of both parities use the phasor and
