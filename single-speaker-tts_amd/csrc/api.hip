@@ -1094,8 +1094,8 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     if (phase_pair) {
         ph0 = phase_pair[0]; ph1 = phase_pair[1];
     } else {   // 4 bytes per bin: the state between iterations is a 32-bit phasor code (griffin_lim.hip)
-        WS(h, "gl.phase0", unsigned, (size_t)B * T * FP, own0);
-        WS(h, "gl.phase1", unsigned, (size_t)B * T * FP, own1);
+        WS(h, "gl.phase0", unsigned, (size_t)B * T * FP * (gl_state_bytes() / sizeof(unsigned)), own0);
+        WS(h, "gl.phase1", unsigned, (size_t)B * T * FP * (gl_state_bytes() / sizeof(unsigned)), own1);
         ph0 = reinterpret_cast<float2*>(own0); ph1 = reinterpret_cast<float2*>(own1);
     }
     GlParams p;
@@ -2048,10 +2048,10 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     // the write does not wait for the previous call's Griffin-Lim.  All four are sized here, before anything is enqueued
     // (a growing workspace synchronises every stream).
     // (its own buffers, not the pair of the stand-alone tts_griffin_lim: 4 bytes per bin, the state is a phasor code)
-    WS(h, "syn.phase0.even", unsigned, (size_t)B * T * FP, gph0e);
-    WS(h, "syn.phase1.even", unsigned, (size_t)B * T * FP, gph1e);
-    WS(h, "syn.phase0.odd", unsigned, (size_t)B * T * FP, gph0o);
-    WS(h, "syn.phase1.odd", unsigned, (size_t)B * T * FP, gph1o);
+    WS(h, "syn.phase0.even", unsigned, (size_t)B * T * FP * (gl_state_bytes() / sizeof(unsigned)), gph0e);
+    WS(h, "syn.phase1.even", unsigned, (size_t)B * T * FP * (gl_state_bytes() / sizeof(unsigned)), gph1e);
+    WS(h, "syn.phase0.odd", unsigned, (size_t)B * T * FP * (gl_state_bytes() / sizeof(unsigned)), gph0o);
+    WS(h, "syn.phase1.odd", unsigned, (size_t)B * T * FP * (gl_state_bytes() / sizeof(unsigned)), gph1o);
     float2* const phase_pair[2] = {reinterpret_cast<float2*>(parity ? gph0o : gph0e), reinterpret_cast<float2*>(parity ? gph1o : gph1e)};
     // Pipelined only while the library owns its stream (inputs on a borrowed stream may still be in flight) and
     // from the second call of a shape on: the first call of a new (B, Ts, n_steps) grows the workspaces, which

@@ -371,6 +371,30 @@ __device__ __forceinline__ cf gl_unpack_phasor(unsigned c, float mag) {   // -> 
     return cmk(ph.x * mag, ph.y * mag);
 }
 
+// |S| x / |x|, and (|S|, 0) for a zero bin (numpy's exp(1j * angle(0)) = 1) WITHOUT a compare and two selects per bin: 1e-17 is
+// added to the real part (a zero bin becomes (1e-17, 0) and normalises to (|S|, 0) within 5e-5; a bin of 1e-9 -- the spectrum
+// X / 1024 of a frame at the -100 dB floor -- moves by 1e-8 of itself, below the rounding of the FFT that made it) and 1e-38 to
+// |x|^2 (so that no reciprocal square root of zero is ever multiplied by zero).  6 VALU instructions per bin.
+__device__ __forceinline__ cf gl_normalise(cf x, float mag) {
+    const float xr = x.x + 1.0e-17f;
+    const float s2 = fmaf(xr, xr, fmaf(x.y, x.y, 1.0e-38f));
+    const float g = mag * __builtin_amdgcn_rsqf(s2);
+    return cmk(xr, x.y) * g;
+}
+// The state of a bin between launches.  Default: the 32-bit phasor code (4 B in, 4 B out per bin and launch, 10 + 11 VALU
+// instructions to decode / encode).  -DGL_STATE_F2 (experiment): the raw spectrum value as it leaves the merge pass, 8 B each
+// way, decoded by the normalisation (6 instructions), encoded by nothing.
+#ifdef GL_STATE_F2
+typedef cf gl_state_t;
+__device__ __forceinline__ gl_state_t gl_state_encode(cf x) { return x; }
+__device__ __forceinline__ cf gl_state_decode(gl_state_t s, float mag) { return gl_normalise(s, mag); }
+#else
+typedef unsigned gl_state_t;
+__device__ __forceinline__ gl_state_t gl_state_encode(cf x) { return gl_pack_phasor(x); }
+__device__ __forceinline__ cf gl_state_decode(gl_state_t s, float mag) { return gl_unpack_phasor(s, mag); }
+#endif
+size_t gl_state_bytes() { return sizeof(gl_state_t); }
+
 // tools-only ablations (garbage results, timing only): -DGL_ABL_NOSTORE drops the spectrum stores, -DGL_ABL_NOLOAD the
 // spectrum loads, -DGL_ABL_NOFLAG the waits of the overlap-add chain; -DGL_CLOCK logs the shader clock of every launch
 #ifdef GL_ABL_NOLOAD
@@ -512,21 +536,21 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
 
     // prefetch registers of one spectrum row in the pair-owner layout: phasor codes and magnitudes of bins lane + 64 j
     // (j < 8) and MH - lane - 64 (j - 8) (j >= 8), and of bin 512 (`nyq_*`: the name is older than the layout; only lane 0's is used)
-    unsigned gc[16];
+    gl_state_t gc[16];
     float gs[16];
-    unsigned nyq_c;
+    gl_state_t nyq_c;
     float nyq_s;
     constexpr bool seeded = SEEDED;
 #define GLS_LOAD_ROW(BASE_C, BASE_M, TF)                                                        \
     {                                                                                           \
         int tf_ = (TF);                                                                         \
         tf_ = tf_ < 0 ? 0 : (tf_ >= p.T ? p.T - 1 : tf_);                                       \
-        const unsigned* prow_ = (BASE_C) + (size_t)tf_ * p.FP;                                  \
+        const gl_state_t* prow_ = (BASE_C) + (size_t)tf_ * p.FP;                                \
         const float* srow_ = (BASE_M) + (size_t)tf_ * p.FP;                                     \
-        const unsigned* plo_ = prow_ + lane; const unsigned* phi_ = prow_ + (MH - lane);        \
+        const gl_state_t* plo_ = prow_ + lane; const gl_state_t* phi_ = prow_ + (MH - lane);    \
         const float* slo_ = srow_ + lane; const float* shi_ = srow_ + (MH - lane);              \
         if (!seeded) {                                                                          \
-            _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = GL_ABL_LD(GL_ROW(plo_, phi_, j_), (unsigned)(tf_ * 64 + j_) * 0x9E3779B9u); \
+            _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gc[j_] = GL_ROW(plo_, phi_, j_); \
             nyq_c = prow_[MH / 2];                                                              \
         }                                                                                       \
         _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) gs[j_] = GL_ABL_LD(GL_STREAM_LOAD(j_ < 8 ? slo_ + 64 * j_ : shi_ - 64 * (j_ - 8)), (float)(tf_ + j_ + lane)); \
@@ -545,8 +569,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
     asm volatile("" : "+v"(gs[0]), "+v"(gs[1]), "+v"(gs[2]), "+v"(gs[3]), "+v"(gs[4]), "+v"(gs[5]), "+v"(gs[6]),       \
                       "+v"(gs[7]), "+v"(gs[8]), "+v"(gs[9]), "+v"(gs[10]), "+v"(gs[11]), "+v"(gs[12]), "+v"(gs[13]), \
                       "+v"(gs[14]), "+v"(gs[15]), "+v"(nyq_s));
-    const unsigned* x_in = reinterpret_cast<const unsigned*>(p.phase_in);
-    unsigned* x_out = reinterpret_cast<unsigned*>(p.phase_out);
+    const gl_state_t* x_in = reinterpret_cast<const gl_state_t*>(p.phase_in);
+    gl_state_t* x_out = reinterpret_cast<gl_state_t*>(p.phase_out);
 
 #ifdef GL_TIMELINE   // tools only: 100 MHz stamps of workgroup 0's waves, [wave][64], from the tenth iteration of a run on
     int stamp_n = 0;
@@ -745,7 +769,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         int b, run_t0, run_len, slot;
         decode_item(item, b, run_t0, run_len, slot);
         const float* magb = p.mag + (size_t)b * p.T * p.FP;
-        const unsigned* phb = x_in + (size_t)b * p.T * p.FP;
+        const gl_state_t* phb = x_in + (size_t)b * p.T * p.FP;
         // The next item is drawn LATE in a run (by the wave of index n_idx - 24, read by every wave in its last iteration):
         // drawn at the start, a workgroup committed itself to a second run before it knew how long the first would take, and
         // a cut with runs of two lengths (gl_plan_stream) paired long runs with short ones at random.  Runs too short for
@@ -804,8 +828,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     split_pass(gk, cmk(nyq_s * en.x, nyq_s * en.y), v);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) gk[j] = gl_unpack_phasor(gc[j], gs[j]);
-                    split_pass(gk, gl_unpack_phasor(nyq_c, nyq_s), v);
+                    for (int j = 0; j < 16; ++j) gk[j] = gl_state_decode(gc[j], gs[j]);
+                    split_pass(gk, gl_state_decode(nyq_c, nyq_s), v);
                 }
             } else {
 #pragma unroll
@@ -874,19 +898,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     cf gk[16];
                     // |S| e^{i phi}: x * (|S| / |x|), and (|S|, 0) for a zero bin (numpy's exp(1j * angle(0)) = 1); the
                     // bins are X / MH of a windowed signal, far from both ends of the float range
-                    // |S| x / |x|, and (|S|, 0) for a zero bin (numpy's exp(1j * angle(0)) = 1) WITHOUT a compare and two selects
-                    // per bin: 1e-17 is added to the real part (a zero bin becomes (1e-17, 0) and normalises to (|S|, 0) within
-                    // 5e-5; a bin of 1e-9 -- the spectrum X / 1024 of a frame at the -100 dB floor -- moves by 1e-8 of itself,
-                    // below the rounding of the FFT that made it) and 1e-38 to |x|^2 (so that no reciprocal square root of zero
-                    // is ever multiplied by zero).  6 VALU instructions per bin, 9 before
-                    auto normalise = [&](cf x, float mag_) __attribute__((always_inline)) {
-                        const float xr = x.x + 1.0e-17f;
-                        const float s2 = fmaf(xr, xr, fmaf(x.y, x.y, 1.0e-38f));
-                        const float g = mag_ * __builtin_amdgcn_rsqf(s2);
-                        return cscale(cmk(xr, x.y), g);
-                    };
-                    const cf xmid = merge_pass(v, [&](int c, cf x) { gk[c] = normalise(x, gs[c]); });
-                    split_pass(gk, normalise(xmid, nyq_s), v);
+                    const cf xmid = merge_pass(v, [&](int c, cf x) { gk[c] = gl_normalise(x, gs[c]); });   // |S| e^{i phi}
+                    split_pass(gk, gl_normalise(xmid, nyq_s), v);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) v[j] = cmk(0.f, 0.f);
@@ -927,14 +940,14 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                 fft1024(v, ex, tw, lane);
                 GLS_STAMP()   // 5: forward FFT done
                 GLS_URGENCY(i + GL_NW)
-                unsigned* orow = x_out + ((size_t)b * p.T + tm) * p.FP;
-                unsigned* olo = orow + lane;
-                unsigned* ohi = orow + (MH - lane);
+                gl_state_t* orow = x_out + ((size_t)b * p.T + tm) * p.FP;
+                gl_state_t* olo = orow + lane;
+                gl_state_t* ohi = orow + (MH - lane);
                 const cf xmid = merge_pass(v, [&](int c, cf x) {
 #ifdef GL_ABL_NOSTORE
-                    if (__float_as_uint(x.x) == 0x12345678u) __builtin_nontemporal_store(gl_pack_phasor(x), c < 8 ? olo + 64 * c : ohi - 64 * (c - 8));
+                    if (__float_as_uint(x.x) == 0x12345678u) __builtin_nontemporal_store(gl_state_encode(x), c < 8 ? olo + 64 * c : ohi - 64 * (c - 8));
 #else
-                    __builtin_nontemporal_store(gl_pack_phasor(x), c < 8 ? olo + 64 * c : ohi - 64 * (c - 8));
+                    __builtin_nontemporal_store(gl_state_encode(x), c < 8 ? olo + 64 * c : ohi - 64 * (c - 8));
 #endif
                     if (MSE) {
                         const float d = mg[c] - (float)MH * sqrtf(fmaf(x.x, x.x, x.y * x.y));   // x = X / MH
@@ -942,7 +955,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     }
                 });
                 if (lane == 0) {
-                    __builtin_nontemporal_store(gl_pack_phasor(xmid), orow + MH / 2);   // bin 512
+                    __builtin_nontemporal_store(gl_state_encode(xmid), orow + MH / 2);   // bin 512
                     if (MSE) {
                         const float d = fabsf(mrow[MH / 2]) - (float)MH * sqrtf(fmaf(xmid.x, xmid.x, xmid.y * xmid.y));
                         mse_acc += d * d;
@@ -1406,7 +1419,7 @@ hipError_t launch_tf_to_ft(hipStream_t s, const float* in, float* out, int B, in
 // no iteration follows -- the first launch of an iteration makes it itself); out (B,T,FP) phasor codes (no magnitudes
 // needed: the state is the phasor alone).  Running it on a side stream beside the post-net was tried and cost 1.3 ms
 // per step instead of saving 0.17: a third busy stream slows the Griffin-Lim launches of the main one.
-__global__ void phase_init_kernel(const float* init_ft, uint64_t seed, unsigned* out, int F, int T, int FP) {
+__global__ void phase_init_kernel(const float* init_ft, uint64_t seed, gl_state_t* out, int F, int T, int FP) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const int f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
@@ -1428,13 +1441,13 @@ __global__ void phase_init_kernel(const float* init_ft, uint64_t seed, unsigned*
             sincospif(2.0f * tile[tx][i], &sn, &cs);
             cf e = cmk(cs, sn);   // phasor of exp(2 pi i u)
             if (!init_ft) e = f < F ? gl_seed_phasor(seed, ((unsigned long long)b * F + f) * T + t) : cmk(1.f, 0.f);   // the seeded start
-            out[((size_t)b * T + t) * FP + f] = gl_pack_phasor(e);
+            out[((size_t)b * T + t) * FP + f] = gl_state_encode(e);
         }
     }
 }
 hipError_t launch_phase_init(hipStream_t s, const float* init_ft, uint64_t seed, void* out, int B, int F, int T, int FP) {
     dim3 grid((T + 31) / 32, (FP + 31) / 32, B);
-    hipLaunchKernelGGL(phase_init_kernel, grid, dim3(32, 8), 0, s, init_ft, seed, reinterpret_cast<unsigned*>(out), F, T, FP);
+    hipLaunchKernelGGL(phase_init_kernel, grid, dim3(32, 8), 0, s, init_ft, seed, reinterpret_cast<gl_state_t*>(out), F, T, FP);
     return hipGetLastError();
 }
 
