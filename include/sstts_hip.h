@@ -115,7 +115,8 @@ int tts_set_stream(tts_handle_t h, void* hip_stream);
  * on the same handle; nothing in the process environment changes what a call computes: "pd_debug_delay" (workgroup 3 of
  * every persistent-decoder cluster stages its tile that many x ~3.4 us late), "gl_runs" / "gl_run_len" (force the cut of
  * an utterance's frames into Griffin-Lim runs: runs per utterance / frames per run; the cut is part of the waveform's
- * rounding), "timeline" (tts_profile_get prints the absolute times of every profiled span); tts_debug_hold.
+ * rounding), "gl_workers" (plan and launch Griffin-Lim for that many workgroups instead of one per free compute unit),
+ * "timeline" (tts_profile_get prints the absolute times of every profiled span); tts_debug_hold.
  * Initial phases of Griffin-Lim: `init_phase` (a (B, F, T) array of U[0,1) numbers, angle = 2 pi u) or, when it is NULL,
  * a counter-based draw from `seed` made inside the first iteration's launch (the reference draws np.random.rand per call,
  * audio/synthesis.py:91). */

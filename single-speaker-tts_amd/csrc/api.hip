@@ -122,6 +122,7 @@ struct tts_handle_s {
     int gl_runs = 0;          // Griffin-Lim run cut: runs per utterance (0 = planned)
     int gl_run_len = 0;       // ... or frames per full run (0 = planned)
     int timeline = 0;         // print the absolute stage times of every profiled span (prof_collect)
+    int gl_workers = 0;       // Griffin-Lim: plan and launch for this many workgroups (0 = the free compute units)
     bool pd_used = false;            // a persistent launch has been enqueued since the last status check
     unsigned* pd_sync = nullptr;     // counters + status word of the last persistent launch
     int pd_clusters = 0;
@@ -1112,7 +1113,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     p.B = B;
     if (gl_stream_ring_frames(win, hop) < 1)
         return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: this window / hop pair does not fit the LDS ring (hop beyond the window's 128-sample slots, or too long)");
-    const int n_cus = device_cus(h);
+    const int n_cus = (h->debug_hooks && h->gl_workers >= 16 && h->gl_workers <= device_cus(h)) ? h->gl_workers : device_cus(h);   // (tools: "gl_workers")
     // workgroups that really run side by side: the pipelined tts_synthesize keeps `reserve_cus` compute units
     // free of Griffin-Lim for its second stream
     const int held = (under_reservation && h->reserve_cus > 0) ? h->reserve_cus : 0;
@@ -1405,12 +1406,13 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     }
     else if (!std::strcmp(key, "debug_hooks")) h->debug_hooks = value;
     else if (!std::strcmp(key, "pd_debug_delay") || !std::strcmp(key, "gl_runs") || !std::strcmp(key, "gl_run_len") ||
-             !std::strcmp(key, "timeline")) {
+             !std::strcmp(key, "timeline") || !std::strcmp(key, "gl_workers")) {
         if (!h->debug_hooks && value != 0)
             return fail(h, TTS_ERR_INVALID, std::string(key) + ": a test hook; set the option \"debug_hooks\" to 1 on this handle first");
         if (!std::strcmp(key, "pd_debug_delay")) h->pd_debug_delay = value;
         else if (!std::strcmp(key, "gl_runs")) h->gl_runs = value;
         else if (!std::strcmp(key, "gl_run_len")) h->gl_run_len = value;
+        else if (!std::strcmp(key, "gl_workers")) h->gl_workers = value;
         else h->timeline = value;
     }
     else if (!std::strcmp(key, "reserve_cus")) {

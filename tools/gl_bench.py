@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--nocheck', action='store_true', help='ablation builds produce garbage')
     ap.add_argument('--pair', type=int, default=None, help='override the library default (iterations per launch, 1..3)')
+    ap.add_argument('--workers', type=int, default=0, help='plan and launch for this many workgroups (compute units) instead of all')
     a = ap.parse_args()
     sstts = importlib.import_module('single-speaker-tts_amd')
     eng = sstts.Engine()
@@ -30,6 +31,9 @@ def main():
     init = eng.to_device(rng.random((a.B, 1025, a.T), dtype=np.float32))
     if a.pair is not None:
         eng.set_option('gl_pair', a.pair)
+    if a.workers:
+        eng.set_option('debug_hooks', 1)
+        eng.set_option('gl_workers', a.workers)
     eng.griffin_lim(mag, 2, 1102, 275, 2048, init_phase=init, want_mse=False)
     eng.set_option('profile', 1)
     eng.profile_reset()
@@ -39,8 +43,8 @@ def main():
     msf, nf = eng.profile_get('gl_final')
     per = ms / max(1, n)
     alg = 20.0 * 1025 * a.T * a.B
-    print('gl_iter: {:.1f} us/iteration over {} iterations -> {:.0f} GB/s algorithmic; gl_final {:.1f} us'.format(
-        per * 1e3, n, alg / (per * 1e-3) / 1e9, 1e3 * msf / max(1, nf)))
+    print('gl_iter: {:.1f} us/iteration over {} iterations -> {:.0f} GB/s algorithmic; gl_final {:.1f} us{}'.format(
+        per * 1e3, n, alg / (per * 1e-3) / 1e9, 1e3 * msf / max(1, nf), '  ({} workgroups)'.format(a.workers) if a.workers else ''))
     if not a.nocheck:
         assert np.isfinite(wav.to_host()).all()
 
