@@ -335,6 +335,11 @@ __device__ __forceinline__ void pd_attention_body(const float* __restrict__ quer
     const int row = b0 + 2 * j + half;
     const bool row_ok = row < B;
     const int rr = row_ok ? row : B - 1;
+#ifdef PD_ABL_ONE_MEMORY   // tools only (wrong results): every utterance attends over utterance 0's memory, 0.3 MB instead of 19 MB
+    const int mr = 0;
+#else
+    const int mr = rr;
+#endif
 
     // Scores: 16 lanes per key, 32 keys per pass of the row's 8 waves, PD_KB passes requested together (a pass per
     // round trip to L2 / the Infinity Cache was five dependent trips per step at Ts = 150).  The keys do not depend on
@@ -350,7 +355,7 @@ __device__ __forceinline__ void pd_attention_body(const float* __restrict__ quer
             for (int i = 0; i < 4; ++i) kpre[q][i] = *reinterpret_cast<const float4*>(kr + (l16 + 16 * i) * 4);
         }
     };
-    if (!LOCAL) load_keys(keys + (size_t)rr * Ts * PD_D, 0, Ts);
+    if (!LOCAL) load_keys(keys + (size_t)mr * Ts * PD_D, 0, Ts);
 
     PD_STAMP(0)
     pd_wait(cnt, target, status, ctrl);
@@ -400,7 +405,7 @@ __device__ __forceinline__ void pd_attention_body(const float* __restrict__ quer
         }
     }
 
-    const float* kb = keys + ((size_t)rr * Ts + w_lo) * PD_D;
+    const float* kb = keys + ((size_t)mr * Ts + w_lo) * PD_D;
     for (int j0 = 0; j0 < w_n; j0 += 32 * PD_KB) {
         if (LOCAL || j0 > 0) load_keys(kb, j0, w_n);
 #pragma unroll
@@ -452,7 +457,7 @@ __device__ __forceinline__ void pd_attention_body(const float* __restrict__ quer
     PD_STAMP(3)
     // context: wave hw takes positions hw, hw + 8, ...; lane d4 owns 4 consecutive depth elements (1 KB rows, coalesced);
     // PD_VB rows requested together (two per trip were ten dependent trips per step at Ts = 150)
-    const float* vb = values + ((size_t)rr * Ts + w_lo) * PD_D + 4 * lane;
+    const float* vb = values + ((size_t)mr * Ts + w_lo) * PD_D + 4 * lane;
     float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j0 = hw; j0 < w_n; j0 += 8 * PD_VB) {
         float4 vv[PD_VB];
