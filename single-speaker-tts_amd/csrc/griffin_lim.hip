@@ -160,13 +160,61 @@ __device__ __forceinline__ void r4_c_mi(cf& a, cf& b, cf& c, cf& d) {
     d = cadd_pi(s1, s3);
 }
 
+// -a - i b = (-a.x + b.y, -a.y - b.x) and -a + i b = (-a.x - b.y, -a.y + b.x)
+__device__ __forceinline__ cf cneg_add_mi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf cneg_add_pi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// The radix-4 butterfly with inputs KNOWN to be zero (ZA: a, ZD: d): the frame a forward transform is fed is zero outside
+// the window's 128-sample slots, i.e. in the first and last registers of a lane (fft_input), and x + 0 is not something
+// the compiler may drop (-0 + 0 = +0), let alone through the asm statements.  6 packed adds with one zero, 4 with two.
+template <bool ZA, bool ZD>
+__device__ __forceinline__ void r4z(cf& a, cf& b, cf& c, cf& d) {
+    if (ZA && ZD) {          // s0 = c, s1 = -c, s2 = s3 = b
+        const cf b0 = b, c0 = c;
+        a = cadd(c0, b0);
+        c = csub(c0, b0);
+        b = cneg_add_mi(c0, b0);
+        d = cneg_add_pi(c0, b0);
+    } else if (ZA) {         // s0 = c, s1 = -c
+        const cf c0 = c, s2 = cadd(b, d), s3 = csub(b, d);
+        a = cadd(c0, s2);
+        c = csub(c0, s2);
+        b = cneg_add_mi(c0, s3);
+        d = cneg_add_pi(c0, s3);
+    } else if (ZD) {         // s2 = s3 = b
+        const cf b0 = b, s0 = cadd(a, c), s1 = csub(a, c);
+        a = cadd(s0, b0);
+        c = csub(s0, b0);
+        b = cadd_mi(s1, b0);
+        d = cadd_pi(s1, b0);
+    } else {
+        r4(a, b, c, d);
+    }
+}
+
 // forward 16-point DFT in registers, natural order in and out: out[k] = sum_j v[j] W16^{jk}
-// (64 packed adds + 8 complex multiplies by constants = 80 VALU instructions)
+// (64 packed adds + 8 complex multiplies by constants = 80 VALU instructions).  ZLO / ZHI: the inputs v[j], j < ZLO or
+// j > ZHI, are known to be zero (their registers are not read): the reference window's [3, 12] saves 12 of the 32 adds of step 1
+template <int ZLO = 0, int ZHI = 15>
 __device__ __forceinline__ void fft16(cf (&v)[16]) {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
     // step 1: for each j1, radix-4 over j2 (elements j1 + 4 j2) -> t[j1][k2] stored at v[j1 + 4 k2]
-#pragma unroll
-    for (int j1 = 0; j1 < 4; ++j1) r4(v[j1], v[j1 + 4], v[j1 + 8], v[j1 + 12]);
+    {
+        // (only the two patterns r4z knows are used: a zero first and / or last input, the middle two present)
+        constexpr bool ok = ZLO >= 0 && ZLO <= 4 && ZHI >= 11 && ZHI <= 15;
+        static_assert(ok || (ZLO == 0 && ZHI == 15), "fft16: zero inputs in the first and last four registers only");
+        r4z<(0 < ZLO), (12 > ZHI)>(v[0], v[4], v[8], v[12]);
+        r4z<(1 < ZLO), (13 > ZHI)>(v[1], v[5], v[9], v[13]);
+        r4z<(2 < ZLO), (14 > ZHI)>(v[2], v[6], v[10], v[14]);
+        r4z<(3 < ZLO), (15 > ZHI)>(v[3], v[7], v[11], v[15]);
+    }
     // twiddle t[j1][k2] *= W16^{j1 k2}; W^4 = -i (t[2][2]) is folded into the second butterfly of k2 = 2
     v[1 + 4] = cmul_k(v[1 + 4], cmk(C1, -S1));    // W^1
     v[1 + 8] = cmul_k(v[1 + 8], cmk(R2, -R2));    // W^2
@@ -237,9 +285,9 @@ __device__ __forceinline__ void swap_bit4(cf& a, cf& b) {
 // a 4 x 4 transpose between the two low register-index bits and the two high lane bits, done with
 // 32 permlane swaps (no LDS); radix-4; the second exchange (a 16 x 16 transpose inside each row of 16
 // lanes) goes through the wave's LDS buffer; radix-16.
-template <typename TW>
+template <int ZLO = 0, int ZHI = 15, typename TW>
 __device__ __forceinline__ void fft1024(cf (&v)[16], cf* ex, const TW& tw, int lane) {
-    fft16(v);
+    fft16<ZLO, ZHI>(v);
 #pragma unroll
     for (int k2 = 1; k2 < 16; ++k2) v[k2] = cmul(v[k2], tw.a_at(k2));
 #ifdef GL_FFT_LDS_STAGE1
@@ -329,13 +377,15 @@ __device__ __forceinline__ void gl_stream_store(cf* p, cf v) { __builtin_nontemp
 // The state between iterations is the UNIT PHASOR of every bin, 32 bits each (round 2; the estimate X = |S| e^{i phi} it
 // stands for is rebuilt in phase A from |S|, which phase A reads anyway from then on and phase B no longer does:
 // 4 B phasor + 4 B |S| in, 4 B phasor out = 12 instead of 20 bytes per bin and iteration through a memory path that
-// gives a compute unit ~21 GB/s however many waves ask, tools/stream_microbench.hip).  Code: r = small / |big|, the
-// component of SMALLER magnitude over the magnitude of the other (|r| <= 1, a float), whose two lowest mantissa bits
-// say which component the small one is (bit 1: the real part) and carry the sign of the big one (bit 0).  Decoding:
-// |big| = rsq(1 + r^2) >= 0.707, small = r |big| -- well conditioned everywhere.  No normalisation by |x| is needed
-// to encode (the ratio does not see the scale), and the zero bin needs no special path: 0 / max(0, tiny) = 0 decodes
-// to (1, 0), numpy's exp(1j * angle(0)) (and -0.0 + 0j to (-1, 0), also numpy's).  Worst-case error of a decoded
-// component 3e-7 (two dropped mantissa bits of r, one v_rcp_f32, one v_rsq_f32; tests/test_host_logic.py::
+// gives a compute unit ~21 GB/s however many waves ask, tools/stream_microbench.hip).  Code (round 4, second form): the
+// point where the phasor's ray meets the diamond |Re| + |Im| = 1, stored as its imaginary part p = Im / (|Re| + |Im|)
+// (|p| <= 1, a float) whose lowest mantissa bit carries the sign of Re.  Decoding: |Re| = 1 - |p| on the diamond, then
+// one reciprocal square root of p^2 + (1 - |p|)^2 (between 1/2 and 1: well conditioned everywhere) brings the point
+// back to the circle, times |S|.  No normalisation by |x| is needed to encode (the ratio does not see the scale), no
+// compare and no select at either end, and the zero bin needs no special path: 0 / max(0, tiny) = 0 decodes to (1, 0),
+// numpy's exp(1j * angle(0)) (and -0.0 + 0j to (-1, 0), also numpy's).  6 + 7 VALU instructions per bin and launch (the
+// first form -- the smaller component over the larger, two flag bits -- took 11 + 10).  Worst-case error of a decoded
+// component 4e-7 (one dropped mantissa bit of p, one v_rcp_f32, one v_rsq_f32; tests/test_host_logic.py::
 // test_phasor_code_emulation), the size of the rounding in the x * rsq(|x|^2) * |S| product it replaces.
 // Seeded start: the initial phasor e^{2 pi i u} of a bin, u = 24 bits of a 32-bit mix (lowbias32) of the seed and the
 // bin's index in the reference's (B, F, T) layout.  The reference draws np.random.rand per call (audio/synthesis.py:91);
@@ -349,26 +399,20 @@ __device__ __forceinline__ cf gl_seed_phasor(unsigned long long seed, unsigned l
     return cmk(__builtin_amdgcn_cosf(u), __builtin_amdgcn_sinf(u));
 }
 __device__ __forceinline__ unsigned gl_pack_phasor(cf x) {   // x: any scale
-    const bool sw = fabsf(x.x) < fabsf(x.y);
-    const float small = sw ? x.x : x.y;
-    const float big = sw ? x.y : x.x;
-    // max(|big|, tiny) as ONE instruction: fmaxf(fabsf(big), c) compiles to a canonicalising v_max(|big|, |big|) first
-    float den;
-    asm("v_max_f32_e64 %0, |%1|, %2" : "=v"(den) : "v"(big), "v"(1.0e-30f));
-    const float r = small * __builtin_amdgcn_rcpf(den);
-    return (__float_as_uint(r) & ~3u) | (sw ? 2u : 0u) | (__float_as_uint(big) >> 31);
+    // p = Im / (|Re| + |Im|), bit 0 = sign of Re (6 VALU instructions; see the comment above gl_seed_phasor)
+    const float den = fmaxf(fabsf(x.x) + fabsf(x.y), 1.0e-30f);
+    const float p = x.y * __builtin_amdgcn_rcpf(den);
+    return (__float_as_uint(p) & ~1u) | (__float_as_uint(x.x) >> 31);
 }
 // mag >= 0 (every producer of the internal magnitude buffer writes |S|: gl_to_internal_kernel, the de-normalising
-// epilogues).  The two flag bits are NOT stripped from r before it is used: they are at most 3 ulp of r, exactly
-// what stripping (a truncation) costs.
+// epilogues).  The flag bit is NOT stripped from p before it is used: one ulp of p, exactly what stripping (a
+// truncation) costs.  7 VALU instructions.
 __device__ __forceinline__ cf gl_unpack_phasor(unsigned c, float mag) {   // -> mag * phasor
-    const float r = __uint_as_float(c);
-    const float ba = __builtin_amdgcn_rsqf(fmaf(r, r, 1.0f));            // |big|
-    const float sm = r * ba;
-    const float bg = __uint_as_float(__float_as_uint(ba) | (c << 31));
-    const bool sw = (c & 2u) != 0u;
-    const cf ph = cmk(sw ? sm : bg, sw ? bg : sm);
-    return cmk(ph.x * mag, ph.y * mag);
+    const float p = __uint_as_float(c);
+    const float q = 1.0f - fabsf(p);                                       // |Re| on the diamond |Re| + |Im| = 1
+    const float xs = __uint_as_float(__float_as_uint(q) | (c << 31));
+    const float g = mag * __builtin_amdgcn_rsqf(fmaf(p, p, q * q));       // 1/2 <= p^2 + q^2 <= 1
+    return cmk(xs, p) * g;
 }
 
 // |S| x / |x|, and (|S|, 0) for a zero bin (numpy's exp(1j * angle(0)) = 1) WITHOUT a compare and two selects per bin: 1e-17 is
@@ -381,7 +425,7 @@ __device__ __forceinline__ cf gl_normalise(cf x, float mag) {
     const float g = mag * __builtin_amdgcn_rsqf(s2);
     return cmk(xr, x.y) * g;
 }
-// The state of a bin between launches.  Default: the 32-bit phasor code (4 B in, 4 B out per bin and launch, 10 + 11 VALU
+// The state of a bin between launches.  Default: the 32-bit phasor code (4 B in, 4 B out per bin and launch, 7 + 6 VALU
 // instructions to decode / encode).  -DGL_STATE_F2 (experiment): the raw spectrum value as it leaves the merge pass, 8 B each
 // way, decoded by the normalisation (6 instructions), encoded by nothing.
 #ifdef GL_STATE_F2
@@ -461,6 +505,12 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
     const int wpad = (NFFT - win) >> 1;
     const int c_lo = wpad >> 7;                        // first / last 128-sample slot the window touches
     const int c_hi = (wpad + win - 1) >> 7;
+    // the same two as constants where the window is one: registers c < FZ_LO and c > FZ_HI of a forward transform's input
+    // are zero (fft_input) and its first radix-16 leaves them out (fft16<ZLO, ZHI>); patterns it does not know: no pruning
+    constexpr int fz_lo_ = WIN_CT ? ((NFFT - WIN_CT) >> 1) >> 7 : 0;
+    constexpr int fz_hi_ = WIN_CT ? (((NFFT - WIN_CT) >> 1) + WIN_CT - 1) >> 7 : 15;
+    constexpr bool fz_ok_ = fz_lo_ <= 4 && fz_hi_ >= 11 && fz_hi_ <= 15;
+    constexpr int FZ_LO = fz_ok_ ? fz_lo_ : 0, FZ_HI = fz_ok_ ? fz_hi_ : 15;
     const int n_sl = c_hi - c_lo + 1;
     const int S = 128 * n_sl;                          // span of a frame in the ring
     const int fs = 128 * c_lo;                         // padded sample of span sample 0
@@ -652,8 +702,22 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
 #endif
         asm volatile("" ::: "memory");
         {
-            float* wr = ring + hop * s + 2 * lane;
-            const float* rd = wr + (s == 0 ? ring_len : 0);       // first index of a lap: fold the guard in
+            // Element (float) offsets of this lane's pair in span slot 0, for writing and for reading (the first index of a
+            // lap folds the guard in).  One opaque base per PAIR of slots: slot 2k + 1 is 512 bytes behind slot 2k, which the
+            // two 8-bit dword offsets of ds_read2 / ds_write2 reach (left to itself the compiler makes an address per slot and
+            // direction: 18 VALU instructions per overlap-add).
+            // (offsets from the start of the workgroup's LDS, not from `ring`: a stage's ring is a run-time base, and base +
+            // constant + 512 is not folded into the instruction's offset fields)
+            float* const lds_f = reinterpret_cast<float*>(smem_raw);
+            const int e_wr = (int)(ring - lds_f) + hop * s + 2 * lane;
+            const int e_rd = e_wr + (s == 0 ? ring_len : 0);
+            int wo[8], ro[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                wo[k] = e_wr + 256 * k;
+                ro[k] = e_rd + 256 * k;
+                if (2 * k < n_sl) asm("" : "+v"(wo[k]), "+v"(ro[k]));
+            }
             // MODE 1: span samples [q_fin, q_fin + hop) of this index are final now; y of span sample 0
             const int q_fin = wpad - fs;
             const int y0 = t * hop + fs - MH;
@@ -662,14 +726,15 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
             // All reads first, then the adds, then the writes: written slot by slot, every read waits for the
             // previous slot's write (the compiler cannot tell that they do not alias) and the critical section of
             // the chain is eight LDS round trips instead of one.
-            float o[16][2];
+            cf o[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const int j = c - c_lo;
-                o[c][0] = o[c][1] = 0.f;
+                o[c] = cmk(0.f, 0.f);
                 if (j < 0 || j >= n_sl) continue;                  // wave-uniform (static for the reference window)
                 const int qb = 128 * j;
-                if (qb < acc_len) { o[c][0] = rd[qb]; o[c][1] = rd[qb + 1]; }
+                const float* rp = lds_f + ro[j >> 1] + 128 * (j & 1);
+                if (qb < acc_len) o[c] = cmk(rp[0], rp[1]);
             }
             asm volatile("" ::: "memory");
 #pragma unroll
@@ -677,20 +742,23 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                 const int j = c - c_lo;
                 if (j < 0 || j >= n_sl) continue;
                 const int qb = 128 * j;
-                float a0 = o[c][0], a1 = o[c][1];
-                if (qb < acc_len && qb + 127 >= acc_len) {         // the slot where accumulate turns into store
-                    a0 = qb + 2 * lane < acc_len ? a0 : 0.f;
-                    a1 = qb + 2 * lane + 1 < acc_len ? a1 : 0.f;
+                cf a = v[c];                                       // a slot no earlier index has written: a plain store
+                if (qb < acc_len) {
+                    cf acc = o[c];
+                    if (qb + 127 >= acc_len) {                     // the slot where accumulate turns into store
+                        acc.x = qb + 2 * lane < acc_len ? acc.x : 0.f;
+                        acc.y = qb + 2 * lane + 1 < acc_len ? acc.y : 0.f;
+                    }
+                    a = cadd(acc, v[c]);
                 }
-                a0 += v[c].x;
-                a1 += v[c].y;
-                wr[qb] = a0;
-                wr[qb + 1] = a1;
+                float* wp = lds_f + wo[j >> 1] + 128 * (j & 1);
+                wp[0] = a.x;
+                wp[1] = a.y;
                 if (MODE == 1 && qb + 127 >= q_fin && qb < q_fin + hop) {   // slot holds final samples (wave-uniform)
                     const int q = qb + 2 * lane;
                     const int y = y0 + q;
-                    if (emit && q >= q_fin && q < q_fin + hop && y >= 0 && y < L) { wb[y] = a0; pk = fmaxf(pk, fabsf(a0)); }
-                    if (emit && q + 1 >= q_fin && q + 1 < q_fin + hop && y + 1 >= 0 && y + 1 < L) { wb[y + 1] = a1; pk = fmaxf(pk, fabsf(a1)); }
+                    if (emit && q >= q_fin && q < q_fin + hop && y >= 0 && y < L) { wb[y] = a.x; pk = fmaxf(pk, fabsf(a.x)); }
+                    if (emit && q + 1 >= q_fin && q + 1 < q_fin + hop && y + 1 >= 0 && y + 1 < L) { wb[y + 1] = a.y; pk = fmaxf(pk, fabsf(a.y)); }
                 }
             }
         }
@@ -894,7 +962,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     int sm = s_prev - lag;
                     sm += sm < 0 ? R : 0;
                     fft_input(ring_prev, i_prev, sm, tk, yb_prev, v);
-                    fft1024(v, ex, tw, lane);
+                    fft1024<FZ_LO, FZ_HI>(v, ex, tw, lane);
                     cf gk[16];
                     // |S| e^{i phi}: x * (|S| / |x|), and (|S|, 0) for a zero bin (numpy's exp(1j * angle(0)) = 1); the
                     // bins are X / MH of a windowed signal, far from both ends of the float range
@@ -937,7 +1005,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     for (int c = 0; c < 16; ++c) mg[c] = fabsf(GL_STREAM_LOAD(c < 8 ? mrow + lane + 64 * c : mrow + (MH - lane) - 64 * (c - 8)));
                 }
                 fft_input(ring_k, jj, sm, tm, yb_k, v);
-                fft1024(v, ex, tw, lane);
+                fft1024<FZ_LO, FZ_HI>(v, ex, tw, lane);
                 GLS_STAMP()   // 5: forward FFT done
                 GLS_URGENCY(i + GL_NW)
                 gl_state_t* orow = x_out + ((size_t)b * p.T + tm) * p.FP;

@@ -343,41 +343,46 @@ def test_stream_ring_emulation(win, hop, T, n_stage):
 
 def test_phasor_code_emulation():
     """The Griffin-Lim state between iterations is a 32-bit code per bin (griffin_lim.hip, gl_pack_phasor /
-    gl_unpack_phasor): r = small / |big| (the component of smaller magnitude over the magnitude of the other) as a
-    float whose two lowest mantissa bits say which component the small one is and carry the sign of the big one.
-    numpy emulation of exactly those operations: the decoded phasor is within 4e-7 of the exact unit phasor for random
-    angles at any scale, on the axes, the diagonals and next to them, and the zero bin decodes to (1, 0)."""
+    gl_unpack_phasor): the point where the phasor's ray meets the diamond |Re| + |Im| = 1, stored as its imaginary part
+    p = Im / (|Re| + |Im|), a float whose lowest mantissa bit carries the sign of Re; decoded with |Re| = 1 - |p| and one
+    reciprocal square root.  numpy emulation of exactly those operations (with a random relative error of one ulp on the
+    reciprocal and the reciprocal square root, as v_rcp_f32 / v_rsq_f32 have): the decoded phasor is within 4e-7 of the
+    exact unit phasor for random angles at any scale, on the axes, the diagonals and next to them, and the zero bin
+    decodes to (1, 0)."""
     rng = np.random.default_rng(5)
     ang = np.concatenate([rng.uniform(-np.pi, np.pi, 200000), np.arange(-8, 9) * (np.pi / 4),
                           np.arange(-8, 9) * (np.pi / 4) + 1e-6, np.arange(-8, 9) * (np.pi / 4) - 3e-4])
     scale = np.exp(rng.uniform(-20, 20, ang.size))                 # the FFT output is not normalised
     x = (np.cos(ang) * scale).astype(np.float32)
     y = (np.sin(ang) * scale).astype(np.float32)
+    one = np.float32(1.0)
+
+    def hw(v):   # a transcendental unit's result: one ulp
+        return (v * (1 + rng.uniform(-1, 1, v.shape) * 2.0 ** -24)).astype(np.float32)
 
     def pack(x, y):
-        sw = np.abs(x) < np.abs(y)
-        small, big = np.where(sw, x, y), np.where(sw, y, x)
-        r = (small * (np.float32(1.0) / np.maximum(np.abs(big), np.float32(1e-30)))).astype(np.float32)
-        return (r.view(np.uint32) & ~np.uint32(3)) | np.where(sw, np.uint32(2), np.uint32(0)) | (big.view(np.uint32) >> np.uint32(31))
+        den = np.maximum((np.abs(x) + np.abs(y)).astype(np.float32), np.float32(1e-30))
+        p = (y * hw((one / den).astype(np.float32))).astype(np.float32)
+        return (p.view(np.uint32) & ~np.uint32(1)) | (x.view(np.uint32) >> np.uint32(31))
 
     def unpack(code):
-        r = code.view(np.float32)   # the flag bits are not stripped: 3 ulp of r at most, what stripping costs too
-        ba = (np.float32(1.0) / np.sqrt((r * r + np.float32(1.0)).astype(np.float32))).astype(np.float32)
-        sm = (r * ba).astype(np.float32)
-        bg = (ba.view(np.uint32) | (code << np.uint32(31))).view(np.float32)
-        swd = (code & np.uint32(2)) != 0
-        return np.where(swd, sm, bg), np.where(swd, bg, sm)
+        p = code.view(np.float32)   # the flag bit is not stripped: one ulp of p, what stripping costs too
+        q = (one - np.abs(p)).astype(np.float32)
+        xs = (q.view(np.uint32) | (code << np.uint32(31))).view(np.float32)
+        s2 = (p * p + (q * q).astype(np.float32)).astype(np.float32)
+        n = hw((one / np.sqrt(s2)).astype(np.float32))
+        return (xs * n).astype(np.float32), (p * n).astype(np.float32)
 
     code = pack(x, y)
     ux, uy = unpack(code)
     err = np.maximum(np.abs(ux - np.cos(ang)), np.abs(uy - np.sin(ang)))
     assert err.max() < 4e-7, err.max()
-    assert np.all(np.abs((code & ~np.uint32(3)).view(np.float32)) <= 1.0)          # the stored ratio is small / |big|
-    assert np.abs(ux * ux + uy * uy - 1.0).max() < 4e-7
+    assert np.all(np.abs((code & ~np.uint32(1)).view(np.float32)) <= 1.0)          # the stored value lies on the diamond
+    assert np.abs(ux * ux + uy * uy - 1.0).max() < 6e-7
     # zero bins (angle(0) = 0 -> 1 + 0j, reference audio/synthesis.py:109) and the codes the kernel writes directly
     z = np.zeros(1, np.float32)
     def near(v, want):   # a flag bit left in a zero ratio is a denormal (1e-45), not a phase
-        return float(v[0][0]) == want[0] and abs(float(v[1][0]) - want[1]) < 1e-40
+        return abs(float(v[0][0]) - want[0]) < 2e-7 and abs(float(v[1][0]) - want[1]) < 1e-40
 
     assert near(unpack(pack(z, z)), [1.0, 0.0])
     assert near(unpack(pack(-z, z)), [-1.0, 0.0])                                  # np.angle(-0.0 + 0j) = pi
