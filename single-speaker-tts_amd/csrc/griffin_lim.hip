@@ -773,12 +773,21 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
         // The span is read linearly when it does not cross the end of the lap, or when the next lap's fold (index
         // m + R - sm) has not happened yet: what it will fold is still in the guard, behind the ring.
         if (!edge && (hop * sm + S <= ring_len || R - sm > lag)) {
-            const float* sf = ring + hop * sm + 2 * lane;
+            // (one opaque LDS base per pair of slots, as in overlap_add; a packed multiply per slot)
+            const float* const lds_f = reinterpret_cast<const float*>(smem_raw);
+            const int e_rd = (int)(ring - lds_f) + hop * sm + 2 * lane;
+            int ro[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                ro[k] = e_rd + 256 * k;
+                if (2 * k < n_sl) asm("" : "+v"(ro[k]));
+            }
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const int j = c - c_lo;
-                if (j < 0 || j >= n_sl) v[c] = cmk(0.f, 0.f);
-                else v[c] = cmk(wana[c][0] * sf[128 * j], wana[c][1] * sf[128 * j + 1]);
+                if (j < 0 || j >= n_sl) { v[c] = cmk(0.f, 0.f); continue; }
+                const float* sf = lds_f + ro[j >> 1] + 128 * (j & 1);
+                v[c] = cmk(wana[c][0], wana[c][1]) * cmk(sf[0], sf[1]);
             }
         } else {
             // index-mapped reads: reflect at the signal's ends; run coordinate u = lap * ring_len + off lives at
@@ -900,8 +909,10 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     split_pass(gk, gl_state_decode(nyq_c, nyq_s), v);
                 }
             } else {
+                // (zeros from asm statements: as constants the sixteen pairs are materialised in FRONT of the branch on
+                // `valid` -- 32 v_mov in every iteration for the few indices that lie outside the utterance)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = cmk(0.f, 0.f);
+                for (int j = 0; j < 16; ++j) asm volatile("v_mov_b64 %0, 0" : "=v"(v[j]));
             }
             GLS_STAMP()   // 1: decoded, split
             GLS_URGENCY(i)
@@ -970,7 +981,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     split_pass(gk, gl_normalise(xmid, nyq_s), v);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) v[j] = cmk(0.f, 0.f);
+                    for (int j = 0; j < 16; ++j) asm volatile("v_mov_b64 %0, 0" : "=v"(v[j]));   // (as in stage 0)
                 }
                 if (k + 1 < NST) {
                     const int tq = tk - lag < 0 ? 0 : (tk - lag >= p.T ? p.T - 1 : tk - lag);
