@@ -47,7 +47,9 @@ G3="GRBM_GUI_ACTIVE"
 i=0
 for G in "$G1" "$G2" "$G3"; do i=$((i+1)); rm -rf $O/mfma/p$i; rocprofv3 --kernel-trace --pmc $G --output-format csv -d $O/mfma/p$i -- python3 $R/tools/net_bench.py > $O/mfma_p$i.log 2>&1; done
 python3 $R/tools/pmc_summary.py $O/mfma gemm_f32_kernel gemm_f32_pool_kernel cbhg_tail_kernel bigru_kernel > $O/${TAG}_gemm_mfma_counters.txt; head -30 $O/${TAG}_gemm_mfma_counters.txt
-echo "== step timeline"; bash $R/tools/trace_step.sh ${TAG}_trace > $O/${TAG}_step_timeline.txt 2>&1
+echo "== step timeline"; ( cd $R && bash tools/trace_step.sh ${TAG}_trace ) > $O/${TAG}_step_timeline.txt 2> $O/step_timeline.err; wc -l $O/${TAG}_step_timeline.txt
+echo "== driver's form"; python3 $R/bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_steps20.json 2>> $O/bench.err; python3 $R/bench.py --steps 20 --warmup 5 --through-facade > $O/${TAG}_bench_steps20_facade.json 2>> $O/bench.err
+echo "== decoder L2 counters"; ( cd $R && bash tools/dec_pmc.sh ${TAG} ) > $O/dec_pmc.log 2>&1; cp $R/gpurun_out/${TAG}_dec_pmc.txt $O/${TAG}_decoder_l2_counters.txt
 echo "== stage benchmarks"
 ( echo "# tools/gemm_bench.py"; python3 $R/tools/gemm_bench.py; echo; echo "# tools/net_bench.py"; python3 $R/tools/net_bench.py; echo; echo "# tools/dec_bench.py"; python3 $R/tools/dec_bench.py; echo; echo "# tools/gl_bench.py"; python3 $R/tools/gl_bench.py; echo; echo "# tools/latency_bench.py"; python3 $R/tools/latency_bench.py; echo; echo "# tools/pipeline_sweep.py"; python3 $R/tools/pipeline_sweep.py ) > $O/${TAG}_stage_benchmarks.txt 2>&1
 tail -12 $O/${TAG}_stage_benchmarks.txt
