@@ -156,6 +156,25 @@ def cpu_baseline(weights, hp, n_utts=6, repeats=5):
                 griffin_lim_rtf_cpu_share=t_glc / (share * n_samples / SR))
 
 
+def cpu_baseline_in_child(timeout_s=900):
+    """cpu_baseline() in a fresh interpreter that never touches the GPU: its worker pools are made by fork(), and forking a
+    process that holds a HIP runtime (its helper threads, their locks) now and then leaves a child waiting for a lock nobody
+    in it will release -- the pool never answers and the bench hangs behind a finished measurement.  The child is a plain
+    subprocess of this one (nothing is exec'ed over the process that holds the device); a child that fails or overruns is
+    reported in the field, never waited for."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only']
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, check=False)
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'error': 'CPU baseline child overran {} s'.format(timeout_s)}
+    lines = [ln for ln in r.stdout.decode(errors='replace').splitlines() if ln.startswith('{')]
+    if r.returncode != 0 or not lines:
+        return {'value': None, 'error': 'CPU baseline child failed (rc {}): {}'.format(
+            r.returncode, r.stderr.decode(errors='replace')[-400:])}
+    return json.loads(lines[-1])
+
+
 def _cpu_gl_job(args):
     from oracle import audio_oracle as A
     lin, seed = args
@@ -320,7 +339,21 @@ def main():
                          'waveforms out, upload and download inside the timed region) and report facade_ms_per_step')
     ap.add_argument('--no-aux-outputs', action='store_true', help='A/B: do not write the linear spectrograms and alignments')
     ap.add_argument('--dist-selftest', action='store_true', help='rehearse the N > 1 launch path without GPU work')
+    ap.add_argument('--cpu-baseline-only', action='store_true',
+                    help='print the cpu_baseline object and exit (no GPU call is made: how the bench runs it, in a child)')
     args = ap.parse_args()
+
+    # a bench that stops answering says where: every 4 minutes without an exit, all thread stacks on stderr
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
+
+    if args.cpu_baseline_only:
+        P = importlib.import_module('single-speaker-tts_amd.tacotron.params')
+        Wm = importlib.import_module('single-speaker-tts_amd.tacotron.weights')
+        hp = P.ModelParams()
+        print(json.dumps(cpu_baseline(Wm.synthetic_weights(0, hp), hp)), flush=True)
+        return
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))
@@ -631,7 +664,7 @@ def main():
                               'traffic': None, 'launch_ms': gemm_ms, 'flop_per_launch': gemm_flop},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(weights, hp)
+            out['cpu_baseline'] = cpu_baseline_in_child()
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
