@@ -123,6 +123,7 @@ struct tts_handle_s {
     int gl_run_len = 0;       // ... or frames per full run (0 = planned)
     int timeline = 0;         // print the absolute stage times of every profiled span (prof_collect)
     int gl_workers = 0;       // Griffin-Lim: plan and launch for this many workgroups (0 = the free compute units)
+    float* pre_keys = nullptr;   // attention keys of the memory the next tts_decoder_forward gets, already computed (tts_synthesize)
     bool pd_used = false;            // a persistent launch has been enqueued since the last status check
     unsigned* pd_sync = nullptr;     // counters + status word of the last persistent launch
     int pd_clusters = 0;
@@ -1678,6 +1679,12 @@ int tts_encoder_forward(tts_handle_t h, const int32_t* ids, int B, int Ts, float
     return TTS_OK;
 }
 
+// keys = memory_layer(memory), no bias (LuongAttention, reference tacotron/model.py:205-223; the values stay the raw memory)
+static int attention_keys(tts_handle_t h, const float* memory, int B, int Ts, float* keys) {
+    const int A = h->cfg.n_attention_units, mem = 2 * h->cfg.n_gru_units;
+    return run_single(h, dense_group(memory, mem, h->mem_wt, nullptr, keys, A, B * Ts, A, mem, ACT_NONE));
+}
+
 int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int n_steps, float* mel,
                         float* alignments) {
     DeviceScope dev_scope(h);
@@ -1692,7 +1699,11 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
                     "changes shape and TensorFlow fails)");
     const int A = c.n_attention_units, U = c.n_decoder_gru_units, mem = 2 * c.n_gru_units;
     const int NL = c.n_decoder_gru_layers;
-    WS(h, "dec.keys", float, (size_t)B * Ts * A, keys);
+    WS(h, "dec.keys", float, (size_t)B * Ts * A, keys_ws);
+    // (the call pipeline computes the keys behind the encoder, on the encoder's stream, in a buffer of the call's parity)
+    float* keys = h->pre_keys ? h->pre_keys : keys_ws;
+    const bool have_keys = h->pre_keys != nullptr;
+    h->pre_keys = nullptr;
     const size_t state_floats = (size_t)B * (A + 2 * ((size_t)A + (size_t)NL * U));   // att | h_att, h_dec[] | their second copies
     WS(h, "dec.state", float, state_floats, state);
     WS(h, "dec.tmp", float, (size_t)B * (c.dec_prenet_units[0] + c.dec_prenet_units[1] + 6 * (size_t)U), tmp);
@@ -1744,7 +1755,7 @@ int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int 
     const int64_t per_step = 2 + 2 + 1 + 1 + 2 * NL;
     ProfScope ps(h, ST_DECODER, 3 + per_step * n_steps);
     // keys = memory_layer(memory), no bias (LuongAttention; values stay the raw memory)
-    if ((rc = run_single(h, dense_group(memory, mem, h->mem_wt, nullptr, keys, A, B * Ts, A, mem, ACT_NONE)))) return rc;
+    if (!have_keys && (rc = attention_keys(h, memory, B, Ts, keys))) return rc;
 
     if (use_pd) {
         if (!h->pd_configured) {
@@ -2033,6 +2044,11 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
                                decoder_persistent_supports(h->dec, c.force_cudnn, B, Ts) &&
                                decoder_persistent_workgroups(B) <= h->reserve_cus;
     float* memory = (enc_ahead_cfg && (h->syn_calls & 1)) ? memory_o : memory_e;   // (syn_calls is advanced below: this call's parity)
+    // the attention keys of that memory, likewise: made behind the encoder on ITS stream, so that nothing but two fills
+    // stands between two decoders on the front stream (the 0.04 ms GEMM was on the step's critical path there)
+    WS(h, "syn.keys.even", float, (size_t)B * Ts * c.n_attention_units, keys_e);
+    WS(h, "syn.keys.odd", float, (size_t)B * Ts * c.n_attention_units, keys_o);
+    float* const keys_ahead = enc_ahead_cfg ? ((h->syn_calls & 1) ? keys_o : keys_e) : nullptr;
     // The decoder output is double-buffered by call parity: the encoder / decoder of call j+1 (second
     // stream) may then run while the post-net of call j still reads its mel spectrogram.
     const int parity = (int)(h->syn_calls++ & 1);
@@ -2155,6 +2171,10 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     if (h->input_event) HIPCHK(h, hipStreamWaitEvent(h->stream, h->input_event, 0));   // (tts_synthesize_host: the ids' upload)
     rc = tts_encoder_forward(h, ids, B, Ts, memory);
     if (!rc && h->enc_done_event) HIPCHK(h, hipEventRecord(h->enc_done_event, h->stream));
+    if (!rc && pipelined && keys_ahead) {
+        ProfScope ps(h, ST_ENCODER, 1);
+        rc = attention_keys(h, memory, B, Ts, keys_ahead);
+    }
     if (pipelined) {
         if (!rc && enc_ahead_cfg) {
             HIPCHK(h, hipEventRecord(h->ev_enc_ready[parity], h->encs));
@@ -2168,7 +2188,9 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     h->defer_projection = pipelined;
     h->defer_parity = parity;
     h->has_pending_proj = false;
+    h->pre_keys = (pipelined && keys_ahead) ? keys_ahead : nullptr;
     if (!rc) rc = tts_decoder_forward(h, memory, B, Ts, sp->n_steps, mel, align_out);
+    h->pre_keys = nullptr;
     if (!rc && pipelined) {
         HIPCHK(h, hipEventRecord(h->ev_dec_done[parity], h->front));
         h->dec_done_pending[parity] = true;
