@@ -137,10 +137,22 @@ __device__ __forceinline__ void pd_wait(unsigned* cnt, unsigned target, int* sta
 
 // End of a phase: every storing wave waits for its (write-through) stores, then the workgroup barrier -- after it
 // one lane signals for all of them: the arrival on the cluster's counter (agent scope), at once.
+// A workgroup counts PD_ARRIVALS on the counter per phase, however many of its waves store.
+#define PD_ARRIVALS 2u
 __device__ __forceinline__ void pd_publish(unsigned* cnt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, PD_ARRIVALS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The same for a phase whose stores all come from its first one or two waves (the GEMM phases' epilogue): every storing wave
+// signals for itself when ITS stores have drained (MI355X_MICROARCH.md, valid forms: "each storing wave for itself"), and
+// no workgroup barrier stands between the other fourteen waves and the next phase's weight requests: those are in
+// flight while the epilogue runs, not behind it.  (What the barrier also did -- keep the partial tiles and the staged tile
+// from being overwritten under the epilogue's reads -- the next phase's own barrier does: nobody writes either before
+// pd_wait, and a `cont` phase is entered through the barrier of the `more` phase in front of it.)
+__device__ __forceinline__ void pd_publish_wave(unsigned* cnt, unsigned arrivals) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One GEMM-shaped phase of the cluster: out[16 rows][this workgroup's units] = epi([a0 | a1] . Wt^T + bias).
@@ -303,7 +315,7 @@ __device__ __forceinline__ void pd_phase(const PdPhase& ph, float* lds, int j, i
     }
     PD_STAMP(4)
     if (ph.more) __syncthreads();   // r / u are in LDS, the partial tiles may be overwritten
-    else pd_publish(cnt);
+    else if (tid < tpg * 64) pd_publish_wave(cnt, PD_ARRIVALS / (unsigned)tpg);   // (tpg = 1 or 2 storing waves)
     PD_STAMP(5)
 }
 
@@ -549,8 +561,8 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
                 lc.wp = p.local_wp; lc.vp = p.local_vp; lc.p_hist_t = p.p_hist ? p.p_hist + (size_t)t * p.B : nullptr;
                 lc.err_flag = p.err_flag;
                 float* align_t = p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr;
-                if (p.local_d > 0) pd_attention_local(h_att_new, p.keys, p.memory, p.ctx, align_t, p.Ts, lds, j, b0, p.B, cnt, PD_W * g, p.status, lc);
-                else pd_attention_body<false>(h_att_new, p.keys, p.memory, p.ctx, align_t, p.Ts, lds, j, b0, p.B, cnt, PD_W * g, p.status, lc);
+                if (p.local_d > 0) pd_attention_local(h_att_new, p.keys, p.memory, p.ctx, align_t, p.Ts, lds, j, b0, p.B, cnt, PD_ARRIVALS * PD_W * g, p.status, lc);
+                else pd_attention_body<false>(h_att_new, p.keys, p.memory, p.ctx, align_t, p.Ts, lds, j, b0, p.B, cnt, PD_ARRIVALS * PD_W * g, p.status, lc);
                 ++g;
                 continue;
             }
@@ -600,7 +612,7 @@ __global__ __launch_bounds__(PD_THREADS) void dec_persistent_kernel(PdParams p) 
                     if (second) { ph.yout = l == 0 ? p.y0 : p.yhist + (size_t)t * PD_D; ph.ldy = l == 0 ? PD_D : yld; }
                 } break;
             }
-            pd_phase(ph, lds, j, b0, p.B, cnt, PD_W * g, p.status);
+            pd_phase(ph, lds, j, b0, p.B, cnt, PD_ARRIVALS * PD_W * g, p.status);
             if (!ph.more) ++g;
         }
     }
