@@ -123,6 +123,11 @@ struct tts_handle_s {
     int gl_run_len = 0;       // ... or frames per full run (0 = planned)
     int timeline = 0;         // print the absolute stage times of every profiled span (prof_collect)
     int gl_workers = 0;       // Griffin-Lim: plan and launch for this many workgroups (0 = the free compute units)
+    // Griffin-Lim work counters: a ring of slots, zeroed once; a launch takes the next slot and zeroes its predecessor's
+    unsigned* gl_ring = nullptr;       // the ring the bookkeeping below refers to (a re-allocated workspace starts over)
+    unsigned gl_ring_seq = 0;
+    unsigned* gl_ring_last = nullptr;  // slot of the most recent launch (dirty)
+    hipStream_t gl_ring_stream = nullptr;
     float* pre_keys = nullptr;   // attention keys of the memory the next tts_decoder_forward gets, already computed (tts_synthesize)
     bool pd_used = false;            // a persistent launch has been enqueued since the last status check
     unsigned* pd_sync = nullptr;     // counters + status word of the last persistent launch
@@ -1126,9 +1131,23 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
                    h->debug_hooks ? h->gl_run_len : 0);
     const int nchunks = p.slots_per_utt;
     WS(h, "gl.mse_partial", float, (size_t)B * nchunks, msep);
-    // one zeroed work counter per launch (the persistent workgroups draw their item ids from it)
-    WS(h, "gl.counters", unsigned, (size_t)n_iter + 1, counters);
-    HIPCHK(h, hipMemsetAsync(counters, 0, ((size_t)n_iter + 1) * sizeof(unsigned), h->stream));
+    // One zeroed work counter per launch (the persistent workgroups draw their item ids from it): slots of a ring that is
+    // zeroed ONCE; a launch takes the next slot and zeroes the slot of the launch before it on the stream, which is drained
+    // by then.  (Until round 4 a memset per call: two fill kernels and their dependencies, 0.1 ms between the post-net and
+    // the first Griffin-Lim launch of every call, on the stream that bounds the step.)
+    constexpr unsigned GL_RING = 256;
+    WS(h, "gl.counter_ring", unsigned, GL_RING, ring);
+    if (ring != h->gl_ring || h->gl_ring_stream != h->stream) {   // new buffer, or launches of another stream before these
+        HIPCHK(h, hipMemsetAsync(ring, 0, GL_RING * sizeof(unsigned), h->stream));
+        h->gl_ring = ring;
+        h->gl_ring_stream = h->stream;
+        h->gl_ring_last = nullptr;
+    }
+    auto next_counter = [&](GlParams& q) {
+        q.clear_counter = h->gl_ring_last;
+        q.work_counter = ring + (h->gl_ring_seq++ % GL_RING);
+        h->gl_ring_last = q.work_counter;
+    };
     // a seeded start with at least one iteration needs no codes: the first launch makes the initial phasors itself
     const bool seed_in_kernel = !init_ft && n_iter >= 1;
     if (!phase_ready && !seed_in_kernel) HIPCHK(h, launch_phase_init(h->stream, init_ft, seed, ph0, B, F, T, FP));
@@ -1149,7 +1168,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
             p.phase_out = nxt;
             p.seeded = seed_in_kernel && it == 0;
             p.mse_partial = want_mse ? msep : nullptr;
-            p.work_counter = counters + it;
+            next_counter(p);
 #ifdef GL_TIMELINE   // tools only: stamps of workgroup 0 during the last launch
             WS(h, "gl.timeline", unsigned long long, 1024 + 64 * 16, tl);
             if (it + n_stage >= n_iter) {
@@ -1213,7 +1232,7 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
         p.mse_partial = nullptr;
         p.wav = wav;
         p.peak_partial = peak_normalize ? msep : nullptr;   // the mse partials are consumed by now
-        p.work_counter = counters + n_iter;
+        next_counter(p);
         HIPCHK(h, launch_gl_stream(h->stream, p, free_cus, 1, 1));
     }
     // (dividing by the peak inside the final launch -- by the workgroup that finishes an utterance's last run -- was built

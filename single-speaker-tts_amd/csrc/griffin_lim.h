@@ -37,6 +37,7 @@ struct GlParams {
     int seeded, F;
     unsigned long long seed;
     unsigned* work_counter;  // zeroed counter of THIS launch: the persistent workgroups draw item ids from it
+    unsigned* clear_counter; // null, or the counter of an EARLIER launch on this stream: one thread zeroes it for a later launch
     unsigned long long* dbg; // tools only (-DGL_TIMELINE builds): [GL waves][64] s_memrealtime stamps of workgroup 0
 };
 

@@ -542,6 +542,8 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
 #endif
     // ---------------- one-time setup: twiddles and BOTH windows in registers
     if (tid == 0) ctrl[CT_SNEXT] = (int)atomicAdd(p.work_counter, 1u);
+    // (the counter of the launch before this one on the stream is drained: every workgroup that drew from it has ended)
+    if (tid == 0 && blockIdx.x == 0 && p.clear_counter) *p.clear_counter = 0u;
     // twr[j] = W2048^{lane + 64 j} for j < 8; W2048^{512} = -i, so slot j + 8 uses -i twr[j] (folded into the adds)
     cf twr[8];
 #pragma unroll
