@@ -8,8 +8,13 @@
 // LDS for the whole chain: every stage is a 128 x 256 x 128 GEMM whose A operand is that tile and whose weights stream
 // through a double-buffered LDS image in k-chunks of 32 (all workgroups read the same 0.9 MB of weights: L2 hits); a
 // highway stage writes its output back into the tile (between two workgroup barriers: every wave has read the old rows
-// by then), the three GRU passes store to the projection buffer.  Same MFMA step, LDS image and k permutation as
-// gemm_f32.hip (v_mfma_f32_32x32x2_f32, [row][32 + 4] floats, one ds_read_b128 per operand per four MFMAs).
+// by then), the three GRU passes store to the projection buffer.  Round 4: the products run on the bf16 matrix pipe
+// at f32 accuracy, as in gemm_f32.hip: a k-chunk of the tile (read from its f32 rows in LDS) and of the weights is split
+// exactly into three bf16 terms when it is staged, [split][row][4 chunks of 8 bf16] swizzled, and a 16-deep step of a 32 x 32
+// block is six v_mfma_f32_32x32x16_bf16 (the kernel was bound by the f32 MFMA rate: 62.9 MFLOP per workgroup = 117 us at
+// 256 flop per cycle).  One image per operand, two workgroup barriers per chunk; the next chunk's weights are in flight in
+// registers meanwhile.  -DCBHG_TAIL_F32_MFMA builds the round-3 form (v_mfma_f32_32x32x2_f32, [row][32 + 4] floats,
+// double-buffered weights) for A/B runs.
 // 512 threads = 8 waves (2 x 4), a wave owns 64 rows x 64 columns; the highway packing puts the 32 H columns and the 32 T
 // columns of the same units in one 64-column span, so the gate mix is lane-local.
 #include "tts_common.h"
@@ -24,7 +29,36 @@ namespace tts {
 #define CT_BN 256
 #define CT_THREADS 512
 
+#ifdef CBHG_TAIL_F32_MFMA
 size_t cbhg_tail_lds_bytes() { return ((size_t)CT_BM * CT_XLD + 2 * (size_t)CT_BN * CT_BLD) * sizeof(float); }
+#else
+// the tile's f32 rows, then the bf16 images of one k-chunk: A [3][128][64 B], B [3][256][64 B]
+#define CT_AIMG (3 * CT_BM * 64)
+#define CT_BIMG (3 * CT_BN * 64)
+size_t cbhg_tail_lds_bytes() { return (size_t)CT_BM * CT_XLD * sizeof(float) + CT_AIMG + CT_BIMG; }
+typedef __bf16 ct_bf16x8_t __attribute__((ext_vector_type(8)));
+// x = hi + mid + lo exactly, each a bf16 (the top 16 bits of an f32): bits of x, of x - hi, of x - hi - mid (gemm_f32.hip)
+__device__ __forceinline__ void ct_split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(h & 0xFFFF0000u);
+    m = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(m & 0xFFFF0000u);
+    l = __float_as_uint(r2);
+}
+__device__ __forceinline__ unsigned ct_pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+// four consecutive k (quad kq of the chunk's eight) of one row -> 8 bytes per split; `rows` rows per split
+__device__ __forceinline__ void ct_store_split4(unsigned char* img, int rows, int row, int kq, float4 v) {
+    unsigned h[4], m[4], l[4];
+    ct_split3(v.x, h[0], m[0], l[0]);
+    ct_split3(v.y, h[1], m[1], l[1]);
+    ct_split3(v.z, h[2], m[2], l[2]);
+    ct_split3(v.w, h[3], m[3], l[3]);
+    const int off = (row * 4 + ((kq >> 1) ^ ((row >> 2) & 3))) * 16 + (kq & 1) * 8;
+    *reinterpret_cast<uint2*>(img + off) = make_uint2(ct_pack_hi(h[0], h[1]), ct_pack_hi(h[2], h[3]));
+    *reinterpret_cast<uint2*>(img + rows * 64 + off) = make_uint2(ct_pack_hi(m[0], m[1]), ct_pack_hi(m[2], m[3]));
+    *reinterpret_cast<uint2*>(img + 2 * rows * 64 + off) = make_uint2(ct_pack_hi(l[0], l[1]), ct_pack_hi(l[2], l[3]));
+}
+#endif
 
 bool cbhg_tail_supports(int c_in, int units, int gru_units, int n_hw, long long M) {
     // (32-bit byte offsets into the projection buffer)
@@ -35,7 +69,12 @@ bool cbhg_tail_supports(int c_in, int units, int gru_units, int n_hw, long long 
 __global__ __launch_bounds__(CT_THREADS) void cbhg_tail_kernel(CbhgTailParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Xs = lds;                          // [128][CT_XLD]
+#ifdef CBHG_TAIL_F32_MFMA
     float* Bs = lds + CT_BM * CT_XLD;         // [2][256][CT_BLD]
+#else
+    unsigned char* Ai = reinterpret_cast<unsigned char*>(lds + CT_BM * CT_XLD);   // [3][128][64 B]
+    unsigned char* Bi = Ai + CT_AIMG;                                              // [3][256][64 B]
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -77,6 +116,7 @@ __global__ __launch_bounds__(CT_THREADS) void cbhg_tail_kernel(CbhgTailParams p)
             rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (int)((unsigned)(row * K + kk) * 4u) : -1, 0, 0));
         }
     };
+#ifdef CBHG_TAIL_F32_MFMA
     auto store_chunk = [&](int buf) {
         float* B = Bs + buf * (CT_BN * CT_BLD);
 #pragma unroll
@@ -85,6 +125,18 @@ __global__ __launch_bounds__(CT_THREADS) void cbhg_tail_kernel(CbhgTailParams p)
             *reinterpret_cast<float4*>(&B[row * CT_BLD + 4 * kq]) = rb[i];
         }
     };
+#else
+    // chunk kc of the weights (registers) and of the tile (its f32 rows in LDS) -> the two bf16 images
+    auto stage_chunk = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ct_store_split4(Bi, CT_BN, (tid >> 3) + 64 * i, kq, rb[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (tid >> 3) + 64 * i;
+            ct_store_split4(Ai, CT_BM, row, kq, *reinterpret_cast<const float4*>(&Xs[row * CT_XLD + kc * CT_BK + 4 * kq]));
+        }
+    };
+#endif
 
     // Outputs leave through raw buffer stores whose resource ends with row M - 1: one 32-bit offset register per lane plus a
     // compile-time constant per element (as 64-bit addresses the 64 stores of an epilogue held 128 registers), and rows
@@ -107,6 +159,46 @@ __global__ __launch_bounds__(CT_THREADS) void cbhg_tail_kernel(CbhgTailParams p)
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#ifndef CBHG_TAIL_F32_MFMA
+        for (int kc = 0; kc < nch; ++kc) {
+            __syncthreads();   // the images are free (the previous chunk's MFMAs have read them); the tile's rows are written
+            stage_chunk(kc);
+            __syncthreads();
+            if (kc + 1 < nch) load_chunk(j, kc + 1);
+            else if (j + 1 < n_jobs) load_chunk(j + 1, 0);
+            if (live) {
+                // two 16-deep steps: lane (li, lh) of a 32-row block holds k = 16 q + 8 lh .. + 7 of row li: chunk 2 q + lh
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int ch = 2 * q + lh;
+                    uint4 fa[2][3];
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm) {
+                        const int row = wm * 64 + tm * 32 + li;
+                        const int off = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) fa[tm][sp] = *reinterpret_cast<const uint4*>(Ai + sp * CT_BM * 64 + off);
+                    }
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        const int row = wn * 64 + tn * 32 + li;
+                        const int off = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
+                        uint4 fb[3];
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) fb[sp] = *reinterpret_cast<const uint4*>(Bi + sp * CT_BN * 64 + off);
+#pragma unroll
+                        for (int tm = 0; tm < 2; ++tm) {
+#define CT_MMA(SA, SB)                                                                                                   \
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ct_bf16x8_t, fa[tm][SA]), \
+                                                                                  __builtin_bit_cast(ct_bf16x8_t, fb[SB]), acc[tm][tn], 0, 0, 0);
+                            CT_MMA(0, 2) CT_MMA(2, 0) CT_MMA(1, 1) CT_MMA(0, 1) CT_MMA(1, 0) CT_MMA(0, 0)
+#undef CT_MMA
+                        }
+                    }
+                }
+            }
+        }
+#else
         for (int kc = 0; kc < nch; ++kc) {
             store_chunk(buf);
             __syncthreads();   // (the first one also covers the tile's rows, a job's first one its updated rows)
@@ -144,6 +236,7 @@ __global__ __launch_bounds__(CT_THREADS) void cbhg_tail_kernel(CbhgTailParams p)
             }
             buf ^= 1;
         }
+#endif
 
         // ---- epilogue.  C/D map of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
         if (j == 0) {                       // lifter: relu(acc + b) -> the tile
