@@ -10,10 +10,12 @@
 //   * the weights of the NEXT phase are fetched from L2 into registers BEFORE the workgroup waits for its peers
 //     (they do not depend on data);
 //   * activations travel between the workgroups of a cluster through small global buffers with the write-through
-//     hand-off of MI355X_MICROARCH.md ("valid forms"): every byte stored sc1, every storing wave waits vmcnt(0),
-//     a workgroup barrier, ONE lane adds to the cluster's counter (agent scope); consumers poll that counter with
-//     an sc1 load in one lane, then a workgroup barrier, then sc1 loads of the bytes.  No cache-wide release or
-//     acquire anywhere, no grid-wide barrier: clusters never talk to each other;
+//     hand-off of MI355X_MICROARCH.md ("valid forms"): every byte stored sc1; every storing wave waits vmcnt(0) and
+//     adds to the cluster's counter (agent scope) for itself -- a GEMM phase's stores come from its first one or two
+//     waves, and no workgroup barrier holds the other fourteen back from the next phase's weight requests (round 4:
+//     14.9 -> 13.6 ms alone; the attention phase, where every wave stores, keeps drain -> barrier -> one add);
+//     consumers poll that counter with an sc1 load in one lane, then a workgroup barrier, then sc1 loads of the
+//     bytes.  No cache-wide release or acquire anywhere, no grid-wide barrier: clusters never talk to each other;
 //   (Round 4 measured the alternative hand-off of cdna_hip_programming.md Guideline 16 R2 -- every value an 8-byte
 //   {value, tag} granule, the consumers sweeping the tile until the tags match, no counter and no drained stores --
 //   on one box against this form: 15.48 against 14.86 ms alone, 16.1 against 15.5 ms beside Griffin-Lim.  A phase is bound
