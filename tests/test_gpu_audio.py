@@ -71,6 +71,25 @@ def test_griffin_lim_seeded_is_deterministic(engine):
     assert np.isfinite(w0.to_host()).all()
 
 
+def test_griffin_lim_work_counter_ring_wraps(engine):
+    """The work counters of the launches are slots of a 256-entry ring that is zeroed once; every launch zeroes the slot of the
+    launch before it (csrc/api.hip, gl_run).  More launches than slots on one handle: the result of a call does not depend
+    on where in the ring it falls (a slot that was not cleared would hand a launch no work: frames left unwritten)."""
+    rng = np.random.default_rng(14)
+    mag = engine.to_device(synth_mag(rng, 2, 24))
+    first, first_mse = engine.griffin_lim(mag, 4, WIN, HOP, N_FFT, seed=7)   # 3 + 1 iterations and the final iSTFT: 3 launches
+    first, first_mse = first.to_host(), first_mse.to_host()
+    for k in range(100):                                                     # 300 launches: the ring wraps
+        w, m = engine.griffin_lim(mag, 4, WIN, HOP, N_FFT, seed=7)
+        if k % 20 == 19:
+            assert np.array_equal(w.to_host(), first) and np.array_equal(m.to_host(), first_mse), k
+    # another launch form in between (one iteration per launch, no mse) and back
+    w1, _ = engine.griffin_lim(mag, 1, WIN, HOP, N_FFT, seed=7, want_mse=False)
+    assert np.isfinite(w1.to_host()).all()
+    w, m = engine.griffin_lim(mag, 4, WIN, HOP, N_FFT, seed=7)
+    assert np.array_equal(w.to_host(), first) and np.array_equal(m.to_host(), first_mse)
+
+
 def test_griffin_lim_zero_bins(engine):
     # zero magnitude everywhere -> zero signal; angle(0) = 0 must not produce NaNs
     mag = np.zeros((1, 1025, 12), np.float32)

@@ -388,3 +388,24 @@ def test_phasor_code_emulation():
     assert near(unpack(pack(-z, z)), [-1.0, 0.0])                                  # np.angle(-0.0 + 0j) = pi
     for c, want in ((np.uint32(0), [1.0, 0.0]), (np.uint32(1), [-1.0, 0.0])):      # Nyquist / DC phasors
         assert near(unpack(np.array([c], np.uint32)), want)
+
+
+def test_bench_cpu_baseline_runs_in_a_child_without_the_gpu():
+    """bench.py times the numpy oracle in a child interpreter (`--cpu-baseline-only`): its fork()ed worker pools must not be
+    made by the process that holds the HIP runtime.  The child, on a one-utterance sample: a JSON object with the fields the
+    bench line carries, and no GPU call on the way (this suite runs where there is none)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--cpu-baseline-only', '--cpu-baseline-utts', '1',
+                        '--cpu-baseline-repeats', '1'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')][-1])
+    assert out['kind'] == 'port' and out['unit'] == 'mel-frames/s' and out['value'] > 0 and out['cores'] >= 1
+    assert out['gl_workers_reference'] == 1 and out['repeats'] == 1
+    # and the parent's wrapper reports a failing child instead of waiting for it
+    import bench
+    src = open(os.path.join(root, 'bench.py')).read()
+    assert "cpu_baseline_in_child()" in src and "out['cpu_baseline'] = cpu_baseline(" not in src
+    assert callable(bench.cpu_baseline_in_child)
