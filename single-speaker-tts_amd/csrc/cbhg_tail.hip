@@ -148,7 +148,9 @@ __global__ __launch_bounds__(CT_THREADS) void cbhg_tail_kernel(CbhgTailParams p)
     const int row_l = wm * 64 + 4 * lh;   // + tm * 32 + (r & 3) + 8 * (r >> 2)
 
     f32x16 acc[2][2];
+#ifdef CBHG_TAIL_F32_MFMA
     int buf = 0;
+#endif
     load_chunk(0, 0);
     for (int j = 0; j < n_jobs; ++j) {
         const int nch = (job_k(j) + CT_BK - 1) / CT_BK;
