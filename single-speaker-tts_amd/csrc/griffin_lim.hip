@@ -699,32 +699,37 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
     float pk = 0.f;
     auto overlap_add = [&](float* ring, int chain, int idx, int s, int t, int b, int run_t0, int run_len, const cf (&v)[16])
                            __attribute__((always_inline)) {
+        // Everything that does not depend on the ring comes BEFORE the wait for the chain: a chain step -- flag seen, reads,
+        // adds, writes, flag passed on -- is what the eight waves of a workgroup do one after another (0.7 us per step in the
+        // per-wave timeline; the final iSTFT, one stage per index, is bound by it), so the addresses and the masks of the
+        // boundary slot are made while the wave would wait anyway, and what MODE 1 does with the finished samples (stores to
+        // the waveform, the running peak) comes AFTER the flag is passed on.
+        // Element (float) offsets of this lane's pair in span slot 0, for writing and for reading (the first index of a
+        // lap folds the guard in).  One opaque base per PAIR of slots: slot 2k + 1 is 512 bytes behind slot 2k, which the
+        // two 8-bit dword offsets of ds_read2 / ds_write2 reach (left to itself the compiler makes an address per slot and
+        // direction: 18 VALU instructions per overlap-add).
+        // (offsets from the start of the workgroup's LDS, not from `ring`: a stage's ring is a run-time base, and base +
+        // constant + 512 is not folded into the instruction's offset fields)
+        float* const lds_f = reinterpret_cast<float*>(smem_raw);
+        const int e_wr = (int)(ring - lds_f) + hop * s + 2 * lane;
+        const int e_rd = e_wr + (s == 0 ? ring_len : 0);
+        int wo[8], ro[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            wo[k] = e_wr + 256 * k;
+            ro[k] = e_rd + 256 * k;
+            if (2 * k < n_sl) asm volatile("" : "+v"(wo[k]), "+v"(ro[k]));
+        }
+        // the slot where accumulate turns into store: which of this lane's two samples earlier indices have written
+        const int qb_edge = 128 * ((acc_len - 1) >> 7);
+        unsigned keep0 = qb_edge + 2 * lane < acc_len ? ~0u : 0u, keep1 = qb_edge + 2 * lane + 1 < acc_len ? ~0u : 0u;   // (bit masks)
+        asm volatile("" : "+v"(keep0), "+v"(keep1));
 #ifndef GL_ABL_NOFLAG
         while (gl_flag_load(ctrl + chain) < idx) __builtin_amdgcn_s_sleep(1);
 #endif
         asm volatile("" ::: "memory");
+        cf fin[16];   // MODE 1: what the slots hold after this index (the finished samples are among them)
         {
-            // Element (float) offsets of this lane's pair in span slot 0, for writing and for reading (the first index of a
-            // lap folds the guard in).  One opaque base per PAIR of slots: slot 2k + 1 is 512 bytes behind slot 2k, which the
-            // two 8-bit dword offsets of ds_read2 / ds_write2 reach (left to itself the compiler makes an address per slot and
-            // direction: 18 VALU instructions per overlap-add).
-            // (offsets from the start of the workgroup's LDS, not from `ring`: a stage's ring is a run-time base, and base +
-            // constant + 512 is not folded into the instruction's offset fields)
-            float* const lds_f = reinterpret_cast<float*>(smem_raw);
-            const int e_wr = (int)(ring - lds_f) + hop * s + 2 * lane;
-            const int e_rd = e_wr + (s == 0 ? ring_len : 0);
-            int wo[8], ro[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                wo[k] = e_wr + 256 * k;
-                ro[k] = e_rd + 256 * k;
-                if (2 * k < n_sl) asm("" : "+v"(wo[k]), "+v"(ro[k]));
-            }
-            // MODE 1: span samples [q_fin, q_fin + hop) of this index are final now; y of span sample 0
-            const int q_fin = wpad - fs;
-            const int y0 = t * hop + fs - MH;
-            const bool emit = MODE == 1 && (t >= run_t0 || run_t0 == 0) && (t < run_t0 + run_len || run_t0 + run_len == p.T);
-            float* wb = MODE == 1 ? p.wav + (size_t)b * L : nullptr;
             // All reads first, then the adds, then the writes: written slot by slot, every read waits for the
             // previous slot's write (the compiler cannot tell that they do not alias) and the critical section of
             // the chain is eight LDS round trips instead of one.
@@ -747,25 +752,41 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                 cf a = v[c];                                       // a slot no earlier index has written: a plain store
                 if (qb < acc_len) {
                     cf acc = o[c];
-                    if (qb + 127 >= acc_len) {                     // the slot where accumulate turns into store
-                        acc.x = qb + 2 * lane < acc_len ? acc.x : 0.f;
-                        acc.y = qb + 2 * lane + 1 < acc_len ? acc.y : 0.f;
+                    if (qb + 127 >= acc_len) {                     // (qb == qb_edge)
+                        acc.x = __uint_as_float(__float_as_uint(acc.x) & keep0);
+                        acc.y = __uint_as_float(__float_as_uint(acc.y) & keep1);
                     }
                     a = cadd(acc, v[c]);
                 }
                 float* wp = lds_f + wo[j >> 1] + 128 * (j & 1);
                 wp[0] = a.x;
                 wp[1] = a.y;
-                if (MODE == 1 && qb + 127 >= q_fin && qb < q_fin + hop) {   // slot holds final samples (wave-uniform)
+                if (MODE == 1) fin[c] = a;
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (lane == 0) gl_flag_store(ctrl + chain, idx + 1);
+        if (MODE == 1) {
+            // span samples [q_fin, q_fin + hop) of this index are final now; y of span sample 0
+            asm volatile("" ::: "memory");
+            const int q_fin = wpad - fs;
+            const int y0 = t * hop + fs - MH;
+            const bool emit = (t >= run_t0 || run_t0 == 0) && (t < run_t0 + run_len || run_t0 + run_len == p.T);
+            float* wb = p.wav + (size_t)b * L;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int j = c - c_lo;
+                if (j < 0 || j >= n_sl) continue;
+                const int qb = 128 * j;
+                if (qb + 127 >= q_fin && qb < q_fin + hop) {       // slot holds final samples (wave-uniform)
                     const int q = qb + 2 * lane;
                     const int y = y0 + q;
+                    const cf a = fin[c];
                     if (emit && q >= q_fin && q < q_fin + hop && y >= 0 && y < L) { wb[y] = a.x; pk = fmaxf(pk, fabsf(a.x)); }
                     if (emit && q + 1 >= q_fin && q + 1 < q_fin + hop && y + 1 >= 0 && y + 1 < L) { wb[y + 1] = a.y; pk = fmaxf(pk, fabsf(a.y)); }
                 }
             }
         }
-        asm volatile("" ::: "memory");
-        if (lane == 0) gl_flag_store(ctrl + chain, idx + 1);
     };
     // windowed input of the forward transform of frame tm, whose overlap-add index was idx - lag (ring slot sm), read in
     // the iteration of index idx of its stage (y_base: trimmed-signal index of that stage's ring coordinate 0)
