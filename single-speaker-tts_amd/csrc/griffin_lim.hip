@@ -997,11 +997,13 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                     sm += sm < 0 ? R : 0;
                     fft_input(ring_prev, i_prev, sm, tk, yb_prev, v);
                     fft1024<FZ_LO, FZ_HI>(v, ex, tw, lane);
+                    GLS_STAMP()   // (a) a further stage's forward transform done
                     cf gk[16];
                     // |S| e^{i phi}: x * (|S| / |x|), and (|S|, 0) for a zero bin (numpy's exp(1j * angle(0)) = 1); the
                     // bins are X / MH of a windowed signal, far from both ends of the float range
                     const cf xmid = merge_pass(v, [&](int c, cf x) { gk[c] = gl_normalise(x, gs[c]); });   // |S| e^{i phi}
                     split_pass(gk, gl_normalise(xmid, nyq_s), v);
+                    GLS_STAMP()   // (b) merged, normalised, split
                 } else {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) asm volatile("v_mov_b64 %0, 0" : "=v"(v[j]));   // (as in stage 0)
@@ -1021,7 +1023,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                         fft1024(v, ex, tw, lane);
                         synth_window(tk, v);
                     }
+                    GLS_STAMP()   // (c) inverse transform and window done
                     overlap_add(ring_k, CT_OLB + k - 1, ik, sk, tk, b, run_t0, run_len, v);
+                    GLS_STAMP()   // (d) overlap-add done, flag passed on
                 }
             }
             if (NST > 1) GLS_TOUCH_ROW()
