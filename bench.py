@@ -192,6 +192,46 @@ def _free_port():
     return port
 
 
+# What a rank process needs from its environment, whoever launched it (this file's self_launch or the driver's
+# `python -m torch.distributed.run ... bench.py --gpus N`): applied by rank_env() at the top of main(), BEFORE torch
+# or the HIP runtime is loaded, so the two launch paths cannot differ.
+#   HSA_ENABLE_IPC_MODE_LEGACY=0 -- the host driver of this pool only supports dmabuf IPC; with the legacy mode RCCL's
+#   (and torch's) cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid argument` when the ranks of one
+#   node set up their communicator.  A value the launcher exported is kept.
+RANK_ENV = {'HSA_ENABLE_IPC_MODE_LEGACY': '0'}
+
+
+def rank_cpu_share(cpus, local_rank, local_world):
+    """the contiguous share of the CPUs this process may use that belongs to local rank `local_rank` of `local_world`"""
+    cpus = sorted(cpus)
+    n = len(cpus)
+    if local_world <= 1 or n < local_world:
+        return cpus
+    return cpus[local_rank * n // local_world:(local_rank + 1) * n // local_world]
+
+
+def rank_env():
+    """Environment and CPU binding of a rank process; returns what was applied (reported in the JSON line and compared
+    between the two launch paths by tests/test_distributed_cpu.py).  The call path blocks in hipEventSynchronize and
+    hipStreamSynchronize (csrc/api.hip, tts_synthesize): eight ranks' host threads wandering over all cores of the node
+    wake each other's caches; each rank keeps to its share."""
+    applied = {}
+    if 'RANK' in os.environ:
+        for k, v in RANK_ENV.items():
+            os.environ.setdefault(k, v)
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')))
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        if local_world > 1 and hasattr(os, 'sched_setaffinity'):
+            share = rank_cpu_share(os.sched_getaffinity(0), local_rank, local_world)
+            try:
+                os.sched_setaffinity(0, share)
+            except OSError:
+                pass
+    applied.update({k: os.environ.get(k) for k in RANK_ENV})
+    applied['n_cpus_bound'] = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None
+    return applied
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh child processes, one rank per GPU, wired up
     the way `python -m torch.distributed.run --nproc-per-node N` would (RANK / LOCAL_RANK / WORLD_SIZE /
@@ -201,8 +241,9 @@ def self_launch(args, argv):
     port = _free_port()
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        # (exactly the variables torch.distributed.run sets; everything else a rank needs it sets itself: rank_env())
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         # only rank 0 prints the result; the others' stdout is dropped (an unread pipe would block a chatty child)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
@@ -292,7 +333,14 @@ def rank_fields(rank_ms, rank_devices, first_ms, steady_ms, padded_len, setup_ms
     }
 
 
-def dist_selftest(rank, local_rank, world, dist):
+def gather_rank_env(dist, world, env_applied):
+    """every rank's rank_env() record: one entry per rank, all equal in their environment part"""
+    envs = [None] * world
+    dist.all_gather_object(envs, env_applied)
+    return envs
+
+
+def dist_selftest(rank, local_rank, world, dist, env_applied=None):
     """--dist-selftest: everything of the N > 1 path except the GPU work (process group, the one weight broadcast,
     shard ranges, the max-over-ranks reduction), so that the launcher can be rehearsed on a box without GPUs."""
     shard = importlib.import_module('single-speaker-tts_amd.sharding')
@@ -311,10 +359,12 @@ def dist_selftest(rank, local_rank, world, dist):
     rank_ms = gather_rank_ms(dist, world, 1.0 + rank)   # (rank r "took" 1 + r ms: the last rank is the straggler)
     flags = [None] * world
     dist.all_gather_object(flags, bool(ok))
+    envs = gather_rank_env(dist, world, env_applied or rank_env())
     if rank == 0:
         rec = {'selftest': 'dist', 'n_gpus': world, 'world_size_seen': dist.get_world_size(),
                'backend': dist.get_backend(), 'ok': all(flags)}
         rec.update(rank_fields(rank_ms, devs, first_ms, steady_ms, padded, setup_ms))
+        rec['rank_env'] = envs
         print(json.dumps(rec), flush=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -361,6 +411,7 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))
 
+    env_applied = rank_env()   # before torch / the HIP runtime: the same for both launch paths
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -388,7 +439,7 @@ def main():
     if args.dist_selftest:
         if dist is None:
             raise SystemExit('--dist-selftest needs --gpus N > 1')
-        return dist_selftest(rank, local_rank, world, dist)
+        return dist_selftest(rank, local_rank, world, dist, env_applied)
 
     sstts = importlib.import_module('single-speaker-tts_amd')
     P = importlib.import_module('single-speaker-tts_amd.tacotron.params')
@@ -422,8 +473,12 @@ def main():
                 rank, eng.device_id, torch.cuda.current_device(), local_rank))
     dev_uuid, dev_cus = eng.device_info()
     rank_devices = [(None, dev_uuid, dev_cus)]
+    rank_envs = [env_applied]
     if dist is not None:
         rank_devices = gather_rank_devices(dist, world, rank, dev_uuid, dev_cus)
+        rank_envs = gather_rank_env(dist, world, env_applied)
+        if len({e.get('HSA_ENABLE_IPC_MODE_LEGACY') for e in rank_envs}) != 1:
+            raise SystemExit('rank {}: the ranks differ in HSA_ENABLE_IPC_MODE_LEGACY: {}'.format(rank, rank_envs))
     eng.load_weights_blob(blob)
     if args.pipeline is not None:
         eng.set_option('pipeline', args.pipeline)
@@ -575,6 +630,14 @@ def main():
         traffic_rec, traffic_why = _newest_profile('*gl_iter_hbm_bytes_per_launch.json', per_launch)
         traffic = traffic_rec.get('hbm_bytes_per_launch') if traffic_rec else None
         valu_rec, valu_why = _newest_profile('*gl_iter_valu.json', per_launch)
+        # VALU issue: a SIMD issues one VALU wave-instruction per 4 cycles at best (MI355X_MICROARCH.md, cycle constants);
+        # fraction = wave-instructions x 4 / (SIMDs the launch ran on x cycles of the launch) at the clock the counter record
+        # measured (shader_clock_mhz), on the n_cus - reserve_cus compute units Griffin-Lim is planned for
+        valu_issue_frac = None
+        if valu_rec and valu_rec.get('valu_wave_insts_per_launch') and gl_launch_ms > 0:
+            gl_cus = max(1, dev_cus - (args.reserve_cus if args.reserve_cus is not None else 32))
+            clock_hz = 1e6 * (valu_rec.get('shader_clock_mhz') or 2400.0)
+            valu_issue_frac = valu_rec['valu_wave_insts_per_launch'] * 4.0 / (4 * gl_cus * gl_launch_ms * 1e-3 * clock_hz)
         dec_ms = stage_ms['decoder']
         dec_flop = DEC_MFLOP_PER_UTT_STEP * 1e6 * B_PER_GPU * N_STEPS
         gemm_tflops = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -587,6 +650,7 @@ def main():
             # N > 1 diagnostics: the first broadcast (communicator set-up included) against the same 27.4 MB again; every
             # rank's own ms per step and the slowest rank; the devices the ranks sat on; the global padded length
             **rank_fields(rank_ms, rank_devices, broadcast_ms, broadcast_ms_steady, padded_len, setup_ms),
+            'rank_env': rank_envs,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': ms_per_step,
@@ -613,7 +677,10 @@ def main():
             # is VALU issue (`limiter`, `roofline_valu`), neither roof.
             'roofline': {'kernel': 'gl_stream_kernel<0, 1102, 275, false, {0}> ({0} Griffin-Lim iterations per launch: iSTFT + STFT '
                                    'of every iteration fused, the spectrum passed from one iteration to the next in registers)'.format(per_launch),
-                         'bound': 'hbm',
+                         # what the counters show (roofline_valu): the launch is bound by VALU issue, not by either roof of the
+                         # contract; achieved / peak / frac stay the contract's HBM figures (algorithmic bytes)
+                         'bound': 'valu-issue',
+                         'valu_issue_frac': valu_issue_frac,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic,
                          'traffic_source': ({'file': traffic_rec['file'], 'commit': traffic_rec.get('commit'),

@@ -439,7 +439,7 @@ class Engine(object):
 
     def wait_host(self, ticket, copy=True):
         """Waveforms (B, hop*(T-1)) float32 of a ``synthesize_host`` call.  ``copy=False`` returns a view of the library's
-        pinned buffer, valid until the second ``synthesize_host`` call after the one that produced it."""
+        pinned buffer, valid until the THIRD ``synthesize_host`` call (three buffer sets) after the one that produced it."""
         p = c_void_p()
         n = c_size_t(0)
         self._check(self.lib.tts_wait_host(self.handle, int(ticket), byref(p), byref(n)))

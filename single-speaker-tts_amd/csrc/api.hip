@@ -104,6 +104,8 @@ struct tts_handle_s {
     bool serial_pending = false;           // ... has been recorded since the front stream last waited for it
     unsigned syn_calls = 0;
     int syn_shape[3] = {0, 0, 0};   // (B, Ts, n_steps) of the previous tts_synthesize call
+    int last_enc_ahead = -1;        // did the previous PIPELINED call run its encoder ahead on `encs` (1) or on `front` (0)?
+    bool in_synthesize = false;     // the stage entry points are being called by tts_synthesize (which orders the streams itself)
     // persistent decoder (decoder_persistent.hip).  1 (default): under the call pipeline AND with more than 48
     // utterances per call -- there the step is bound by post-net + Griffin-Lim, and the persistent kernel (17 ms
     // under that load against 21 for the launch-per-layer graph, no launch boundaries that disturb Griffin-Lim, no
@@ -160,6 +162,7 @@ struct tts_handle_s {
         float* ali_pinned[3] = {nullptr, nullptr, nullptr};
         size_t ali_bytes = 0;
         size_t n_lin[3] = {0, 0, 0}, n_ali[3] = {0, 0, 0};
+        bool failed[3] = {false, false, false};   // this set's call ended on a decoder timeout: EVERY wait on its ticket fails
         int* status_pinned = nullptr;   // [3][2]: the persistent decoder's sticky status word ([.][1]) as it stood behind
                                         // each call's download
         int tickets = 0;
@@ -1417,7 +1420,16 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     if (!std::strcmp(key, "use_graph")) h->use_graph = value;
     else if (!std::strcmp(key, "profile")) h->profile = value;
     else if (!std::strcmp(key, "fused_tail")) h->fused_tail = value;
-    else if (!std::strcmp(key, "persistent_decoder")) h->persistent_decoder = value;
+    else if (!std::strcmp(key, "persistent_decoder")) {
+        // the decoder form decides whether a pipelined call runs its encoder ahead on `encs` (tts_synthesize: enc_ahead_cfg):
+        // a call of the other form may still be using the one set of encoder workspaces and the `memory` buffer of its
+        // parity on `front`, which the encoder-ahead ordering (ev_dec_done of the call two back) does not cover
+        if (value != h->persistent_decoder) {
+            int rc = sync_all(h);
+            if (rc) return rc;
+        }
+        h->persistent_decoder = value;
+    }
     else if (!std::strcmp(key, "gl_pair")) h->gl_pair = value;
     else if (!std::strcmp(key, "enc_stream")) {
         int rc = sync_all(h);
@@ -1436,6 +1448,10 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
         else h->timeline = value;
     }
     else if (!std::strcmp(key, "reserve_cus")) {
+        if (value != h->reserve_cus) {   // decides the encoder-ahead form as well (see "persistent_decoder")
+            int rc = sync_all(h);
+            if (rc) return rc;
+        }
         h->reserve_cus = value;
     } else if (!std::strcmp(key, "hold_lds_kb")) {
         if (value < 1 || value > 160) return fail(h, TTS_ERR_INVALID, "hold_lds_kb must be 1..160");
@@ -1670,11 +1686,43 @@ int tts_memset(tts_handle_t h, void* dst, int value, size_t bytes) {
 }
 
 // ---------------------------------------------------------------------------------------- stages
+// A stage entry point called by the USER (not by tts_synthesize) runs on the main stream in the one set of enc.* / dec.*
+// workspaces that the pipelined calls use on the encoder and front streams: it starts behind whatever those streams still
+// hold, and the next pipelined call's encoder and decoder start behind it (ev_serial_done, as for an unpipelined
+// tts_synthesize).  Stream order alone covers the post-net (main stream on both sides).
+static int standalone_begin(tts_handle_t h) {
+    if (h->in_synthesize || !h->encs) return TTS_OK;
+    for (int i = 0; i < 2; ++i) {
+        if (h->enc_ready_pending[i]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_enc_ready[i], 0));
+        if (h->dec_done_pending[i]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_dec_done[i], 0));
+    }
+    return TTS_OK;
+}
+static int standalone_end(tts_handle_t h) {
+    if (h->in_synthesize || !h->front) return TTS_OK;
+    if (!h->ev_serial_done) HIPCHK(h, hipEventCreateWithFlags(&h->ev_serial_done, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(h->ev_serial_done, h->stream));
+    h->serial_pending = true;
+    return TTS_OK;
+}
+struct SynthScope {   // tts_synthesize is running: the stage entry points leave the stream ordering to it
+    tts_handle_t h;
+    explicit SynthScope(tts_handle_t h_) : h(h_) { h->in_synthesize = true; }
+    ~SynthScope() { h->in_synthesize = false; }
+};
+
+static int encoder_impl(tts_handle_t h, const int32_t* ids, int B, int Ts, float* memory);
 int tts_encoder_forward(tts_handle_t h, const int32_t* ids, int B, int Ts, float* memory) {
     DeviceScope dev_scope(h);
     int rc = check_ready(h);
     if (rc) return rc;
     if (!ids || !memory || B < 1 || Ts < 1) return fail(h, TTS_ERR_INVALID, "encoder_forward: bad arguments");
+    if ((rc = standalone_begin(h))) return rc;
+    if ((rc = encoder_impl(h, ids, B, Ts, memory))) return rc;
+    return standalone_end(h);
+}
+static int encoder_impl(tts_handle_t h, const int32_t* ids, int B, int Ts, float* memory) {
+    int rc = TTS_OK;
     const tts_config_t& c = h->cfg;
     const int M = B * Ts;
     WS(h, "enc.pre1", float, (size_t)M * c.enc_prenet_units[0], pre1);
@@ -1704,12 +1752,19 @@ static int attention_keys(tts_handle_t h, const float* memory, int B, int Ts, fl
     return run_single(h, dense_group(memory, mem, h->mem_wt, nullptr, keys, A, B * Ts, A, mem, ACT_NONE));
 }
 
+static int decoder_impl(tts_handle_t h, const float* memory, int B, int Ts, int n_steps, float* mel, float* alignments);
 int tts_decoder_forward(tts_handle_t h, const float* memory, int B, int Ts, int n_steps, float* mel,
                         float* alignments) {
     DeviceScope dev_scope(h);
     int rc = check_ready(h);
     if (rc) return rc;
     if (!memory || !mel || B < 1 || Ts < 1 || n_steps < 1) return fail(h, TTS_ERR_INVALID, "decoder_forward: bad arguments");
+    if ((rc = standalone_begin(h))) return rc;
+    if ((rc = decoder_impl(h, memory, B, Ts, n_steps, mel, alignments))) return rc;
+    return standalone_end(h);
+}
+static int decoder_impl(tts_handle_t h, const float* memory, int B, int Ts, int n_steps, float* mel, float* alignments) {
+    int rc = TTS_OK;
     const tts_config_t& c = h->cfg;
     if (h->dec.local_d > 0 && Ts < 2 * h->dec.local_d + 1)
         return fail(h, TTS_ERR_UNSUPPORTED,
@@ -2041,6 +2096,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     int rc = check_ready(h);
     if (rc) return rc;
     if (!ids || !sp || !wav) return fail(h, TTS_ERR_INVALID, "synthesize: bad arguments");
+    SynthScope synth_scope(h);
     const tts_config_t& c = h->cfg;
     const int T = sp->n_steps * c.reduction;
     const int F = 1 + c.n_fft / 2, FP = TTS_GL_FP;
@@ -2166,6 +2222,12 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         // behind the encoder before it (stream order: the encoder's scratch is one set)
         if (enc_ahead_cfg) {
             if (h->dec_done_pending[parity]) HIPCHK(h, hipStreamWaitEvent(h->encs, h->ev_dec_done[parity], 0));
+            // ... which is enough only if the previous call ran encoder-ahead too.  A call in the other form (the decoder
+            // form was switched in between: tts_set_option, or tts_wait_host / check_status after a decoder timeout) ran its
+            // encoder AND decoder on `front`, in the one encoder scratch and in memory.even: behind its decoder, the last
+            // thing recorded on that stream
+            if (h->last_enc_ahead == 0 && h->dec_done_pending[parity ^ 1])
+                HIPCHK(h, hipStreamWaitEvent(h->encs, h->ev_dec_done[parity ^ 1], 0));
             // The HOST waits for the gap (the call returns at most ~2.5 calls ahead of the device: back-pressure), and the
             // encoder is enqueued into an idle queue.  As a stream wait, enqueued two calls early, the barrier packet sat at
             // the head of the third queue through a whole Griffin-Lim phase, and every kernel boundary of that phase took
@@ -2187,6 +2249,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
             if (h->dec_done_pending[i]) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_dec_done[i], 0));
         }
     }
+    if (pipelined) h->last_enc_ahead = enc_ahead_cfg ? 1 : 0;
     if (h->input_event) HIPCHK(h, hipStreamWaitEvent(h->stream, h->input_event, 0));   // (tts_synthesize_host: the ids' upload)
     rc = tts_encoder_forward(h, ids, B, Ts, memory);
     if (!rc && h->enc_done_event) HIPCHK(h, hipEventRecord(h->enc_done_event, h->stream));
@@ -2368,6 +2431,7 @@ int tts_synthesize_host(tts_handle_t h, const int32_t* ids_host, int B, int Ts, 
     // the sticky status words of the persistent kernels travel with the waveforms (tts_wait_host must not wait for
     // anything but this call: a stream synchronisation there would wait for the NEXT call's download as well)
     io.status_pinned[2 * par] = io.status_pinned[2 * par + 1] = 0;
+    io.failed[par] = false;   // (the set is reused: the ticket that failed can no longer be waited on)
     if (h->pd_used && h->pd_sync)
         HIPCHK(h, hipMemcpyAsync(&io.status_pinned[2 * par + 1], h->pd_sync + 64 * h->pd_clusters + 1, sizeof(int),
                                  hipMemcpyDeviceToHost, io.out));
@@ -2387,14 +2451,18 @@ int tts_wait_host(tts_handle_t h, int ticket, const float** wav_host, size_t* n_
     const int par = ticket % 3;
     HIPCHK(h, hipEventSynchronize(io.ev_d2h[par]));
     // the download is behind everything the call launched: a timed-out persistent kernel must not pass for a result
-    if (io.status_pinned[2 * par + 1]) {
-        // what check_status does at a synchronisation: the sticky device word is cleared (behind the downloads already
-        // queued: a call in flight behind this one may still be reported once, conservatively), the handle leaves the
-        // persistent path by itself and stops carrying the word along
-        io.status_pinned[2 * par + 1] = 0;
-        if (h->pd_sync) HIPCHK(h, hipMemsetAsync(h->pd_sync + 64 * h->pd_clusters + 1, 0, sizeof(int), io.out));
-        h->persistent_decoder = 0;
-        h->pd_used = false;
+    if (io.status_pinned[2 * par + 1] || io.failed[par]) {
+        // what check_status does at a synchronisation, on the first report: the sticky device word is cleared (behind the
+        // downloads already queued: a call in flight behind this one may still be reported once, conservatively), the
+        // handle leaves the persistent path by itself and stops carrying the word along.  The buffer set stays marked:
+        // a second wait on this ticket (tts_wait_host after a failed tts_wait_host_outputs) must not hand out its waveforms
+        if (!io.failed[par]) {
+            io.failed[par] = true;
+            io.status_pinned[2 * par + 1] = 0;
+            if (h->pd_sync) HIPCHK(h, hipMemsetAsync(h->pd_sync + 64 * h->pd_clusters + 1, 0, sizeof(int), io.out));
+            h->persistent_decoder = 0;
+            h->pd_used = false;
+        }
         return fail(h, TTS_ERR_HIP,
                     "persistent decoder: a workgroup waited for its cluster longer than the bound (not all "
                     "workgroups were co-resident); the outputs of that call are invalid -- the handle has "

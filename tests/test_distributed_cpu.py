@@ -110,3 +110,49 @@ def test_bench_under_torch_distributed_run():
     assert rec['weight_broadcast_ms'] > 0 and rec['weight_broadcast_ms_steady'] > 0 and rec['communicator_setup_ms'] > 0
     assert [d['uuid'] for d in rec['rank_devices']] == ['selftest-rank0', 'selftest-rank1']
     assert rec['padded_sentence_length'] == 150
+
+
+def _selftest_rank_env(cmd, env):
+    import json
+    import subprocess
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    rec = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert rec['ok'] is True and len(rec['rank_env']) == 2
+    return rec['rank_env']
+
+
+def test_both_launch_paths_give_a_rank_the_same_environment():
+    """Round 5: what a rank process needs (HSA_ENABLE_IPC_MODE_LEGACY=0 -- RCCL's buffer sharing between the ranks of a
+    node needs dmabuf IPC on this pool --, its share of the host's CPUs) is applied by the rank itself (bench.rank_env)
+    before torch is imported, so a rank started by the driver's `python -m torch.distributed.run` line and one started by
+    `python bench.py --gpus N` see the same thing -- also when the launcher's own environment does not carry the variable."""
+    env = dict(os.environ, SSTTS_DIST_BACKEND='gloo')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY'):
+        env.pop(k, None)
+    bench = os.path.join(ROOT, 'bench.py')
+    own = _selftest_rank_env([sys.executable, bench, '--gpus', '2', '--dist-selftest'], env)
+    run = _selftest_rank_env([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                              '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), bench, '--gpus', '2',
+                              '--dist-selftest'], env)
+    assert own == run, (own, run)
+    n_cpus = len(os.sched_getaffinity(0))
+    for e in own:
+        assert e['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+        assert e['n_cpus_bound'] == (n_cpus // 2 if n_cpus >= 2 else n_cpus)
+    # a value the launcher exported wins (setdefault), on both paths
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '1'
+    kept = _selftest_rank_env([sys.executable, bench, '--gpus', '2', '--dist-selftest'], env)
+    assert [e['HSA_ENABLE_IPC_MODE_LEGACY'] for e in kept] == ['1', '1']
+
+
+def test_rank_cpu_share_partitions_the_cpus():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cpus = list(range(3, 35))
+    shares = [bench.rank_cpu_share(cpus, r, 8) for r in range(8)]
+    assert sorted(c for s in shares for c in s) == cpus and all(len(s) == 4 for s in shares)
+    assert bench.rank_cpu_share(cpus, 0, 1) == cpus
+    assert bench.rank_cpu_share([0, 1], 2, 4) == [0, 1]   # fewer CPUs than ranks: no binding

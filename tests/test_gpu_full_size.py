@@ -172,14 +172,18 @@ def test_encoder_ahead_equals_encoder_in_front(engine):
 
     def run(enc_stream):
         engine.set_option('enc_stream', enc_stream)
+        # every upload before the first call: a host copy between two calls is a null-stream copy, which would serialise
+        # exactly the overlaps this test is about (the stand-alone encoder call against the next pipelined encoder)
+        dev = [engine.to_device(b) for b in batches]
+        dev_other = engine.to_device(other)
         outs = []
-        for i, b in enumerate(batches):
-            outs.append(engine.synthesize(engine.to_device(b), 6, 6.02, 99.89, 1.3, 4, WIN, HOP, seed=500 + i,
+        for i in range(len(batches)):
+            outs.append(engine.synthesize(dev[i], 6, 6.02, 99.89, 1.3, 4, WIN, HOP, seed=500 + i,
                                           want_mel=True, want_alignments=True, want_linear=True))
             if i == 3:   # a call of another shape (unpipelined: it sizes nothing new the second time round, but breaks the rhythm)
-                outs.append(engine.synthesize(engine.to_device(other), 6, 6.02, 99.89, 1.3, 4, WIN, HOP, seed=9, want_mel=True))
-            if i == 4:   # the encoder's scratch is shared with stand-alone calls
-                engine.encoder_forward(engine.to_device(other))
+                outs.append(engine.synthesize(dev_other, 6, 6.02, 99.89, 1.3, 4, WIN, HOP, seed=9, want_mel=True))
+            if i == 4:   # the encoder's scratch is shared with stand-alone calls (ordered by an event since round 5)
+                engine.encoder_forward(dev_other)
         engine.synchronize()
         return [{k: v.to_host() for k, v in o.items() if v is not None} for o in outs]
 
@@ -195,6 +199,36 @@ def test_encoder_ahead_equals_encoder_in_front(engine):
             assert np.isfinite(a['wav']).all() and np.abs(a['wav']).max() > 0
     finally:
         engine.set_option('enc_stream', 1)
+        engine.set_option('persistent_decoder', 1)
+
+
+def test_decoder_form_switched_between_pipelined_calls(engine):
+    """The decoder form decides whether a pipelined call's encoder runs ahead on its own stream (persistent decoder) or in
+    front of its decoder on the front stream (launch-per-layer): switching the form between back-to-back pipelined calls
+    of one shape must not let the two orders meet in the one encoder scratch / `memory` buffer.  Same bits as serial calls."""
+    batches = [bench_ids(5, 21, 170 + i) for i in range(8)]
+    forms = [0, 0, 2, 2, 0, 2, 2, 0]
+
+    def run(pipeline):
+        engine.set_option('pipeline', pipeline)
+        dev = [engine.to_device(b) for b in batches]
+        outs = []
+        for i, d in enumerate(dev):
+            engine.set_option('persistent_decoder', forms[i])
+            outs.append(engine.synthesize(d, 6, 6.02, 99.89, 1.3, 4, WIN, HOP, seed=700 + i, want_mel=True, want_linear=True))
+        engine.synchronize()
+        return [{k: v.to_host() for k, v in o.items() if v is not None} for o in outs]
+
+    try:
+        run(1)   # shapes known
+        seq = run(0)
+        pip = run(1)
+        for i, (a, b) in enumerate(zip(seq, pip)):
+            for k in a:
+                # (the two decoder forms differ in the last bits, so call i is compared with call i of the same form)
+                assert np.array_equal(a[k], b[k]), (i, forms[i], k)
+    finally:
+        engine.set_option('pipeline', 1)
         engine.set_option('persistent_decoder', 1)
 
 
