@@ -61,7 +61,15 @@ struct tts_handle_s {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
-    int use_graph = 1;
+    // Launch-per-layer decoder: replay the whole loop from one executable hipGraph instead of enqueueing its ~10 launches per
+    // step.  OFF by default since round 5: in a long-lived process (the whole GPU test suite in one interpreter: dozens of
+    // graphs instantiated and destroyed, buffers allocated and freed between replays) replays of a freshly instantiated
+    // graph returned wrong mel spectrograms -- garbage of 1e20...1e34 from step 0 on, or plausible values that differ in nearly
+    // every element -- in 2-5 of every 5 runs of the suite on MI355X / ROCm 7.2, serial or pipelined, also with the captured
+    // hipGraph_t kept alive beside the executable one and never two launches of it in flight; the same kernels enqueued
+    // directly were right every time, and the same sequence in a fresh process replays correctly.  The dependent launches
+    // cost ~5 us each either way; the host enqueues them in ~3.5 us each.
+    int use_graph = 0;
     int fused_tail = 1;          // CBHG: lifter + highway stack + GRU input projections as one launch (cbhg_tail.hip)
     bool tail_configured = false;
     int profile = 0;
@@ -199,6 +207,12 @@ struct tts_handle_s {
 
     // decoder graph cache
     hipGraphExec_t dec_graph = nullptr;
+    // A launch of dec_graph is complete: recorded behind every hipGraphLaunch, waited for by the HOST before the same
+    // executable graph is launched again or destroyed (never two launches of one hipGraphExec_t in flight, never one
+    // destroyed under a launch).
+    hipEvent_t ev_graph_done = nullptr;
+    bool graph_in_flight = false;
+    hipGraph_t dec_graph_src = nullptr;   // the captured graph the executable one was instantiated from: kept alive with it
     struct {
         const void* memory = nullptr;
         void* mel = nullptr;
@@ -624,6 +638,28 @@ int sync_all(tts_handle_t h) {
     return check_status(h);
 }
 
+// the decoder graph's last launch has finished (see ev_graph_done)
+int graph_quiesce(tts_handle_t h) {
+    if (h->graph_in_flight) {
+        HIPCHK(h, hipEventSynchronize(h->ev_graph_done));
+        h->graph_in_flight = false;
+    }
+    return TTS_OK;
+}
+int graph_drop(tts_handle_t h) {
+    if (h->dec_graph) {
+        int rc = graph_quiesce(h);
+        if (rc) return rc;
+        hipGraphExecDestroy(h->dec_graph);
+        h->dec_graph = nullptr;
+    }
+    if (h->dec_graph_src) {
+        hipGraphDestroy(h->dec_graph_src);
+        h->dec_graph_src = nullptr;
+    }
+    return TTS_OK;
+}
+
 int ws_get(tts_handle_t h, const char* name, size_t bytes, void** out) {
     DevBuf& b = h->ws[name];
     if (b.bytes < bytes) {
@@ -636,9 +672,9 @@ int ws_get(tts_handle_t h, const char* name, size_t bytes, void** out) {
             b.p = nullptr;
             b.bytes = 0;
             // pointers baked into the decoder graph may have changed
-            if (h->dec_graph) {
-                hipGraphExecDestroy(h->dec_graph);
-                h->dec_graph = nullptr;
+            {
+                int rc = graph_drop(h);
+                if (rc) return rc;
             }
         }
         HIPCHK(h, hipMalloc(&b.p, bytes));
@@ -1326,7 +1362,7 @@ int tts_destroy(tts_handle_t h) {
         hipEventDestroy(s.a);
         hipEventDestroy(s.b);
     }
-    if (h->dec_graph) hipGraphExecDestroy(h->dec_graph);
+    graph_drop(h);
     for (auto& kv : h->ws)
         if (kv.second.p) hipFree(kv.second.p);
     if (h->arena) hipFree(h->arena);
@@ -1379,6 +1415,7 @@ int tts_destroy(tts_handle_t h) {
     }
     if (h->encs) hipStreamDestroy(h->encs);
     if (h->ev_serial_done) hipEventDestroy(h->ev_serial_done);
+    if (h->ev_graph_done) hipEventDestroy(h->ev_graph_done);
     for (int i = 0; i < 2; ++i) {
         if (h->ev_post_done[i]) hipEventDestroy(h->ev_post_done[i]);
         if (h->ev_gl_done[i]) hipEventDestroy(h->ev_gl_done[i]);
@@ -1399,9 +1436,9 @@ int tts_set_stream(tts_handle_t h, void* s) {
     }
     h->post_pending[0] = h->post_pending[1] = false;
     h->gl_pending[0] = h->gl_pending[1] = false;
-    if (h->dec_graph) {
-        hipGraphExecDestroy(h->dec_graph);
-        h->dec_graph = nullptr;
+    {
+        int rc = graph_drop(h);
+        if (rc) return rc;
     }
     if (h->own_stream) hipStreamDestroy(h->stream);
     if (s) {
@@ -1598,9 +1635,9 @@ int tts_finalize_weights(tts_handle_t h) {
         int rc = sync_all(h);
         if (rc) return rc;
     }
-    if (h->dec_graph) {
-        hipGraphExecDestroy(h->dec_graph);
-        h->dec_graph = nullptr;
+    {
+        int rc = graph_drop(h);
+        if (rc) return rc;
     }
     if (h->arena) hipFree(h->arena);
     h->arena = nullptr;
@@ -1851,10 +1888,7 @@ static int decoder_impl(tts_handle_t h, const float* memory, int B, int Ts, int 
         auto& k = h->dec_key;
         if (!h->dec_graph || k.memory != memory || k.align != alignments || k.B != B || k.Ts != Ts ||
             k.n_steps != n_steps) {
-            if (h->dec_graph) {
-                hipGraphExecDestroy(h->dec_graph);
-                h->dec_graph = nullptr;
-            }
+            if ((rc = graph_drop(h))) return rc;
             hipGraph_t graph = nullptr;
             HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
             hipError_t e = decoder_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, alignments, c.force_cudnn);
@@ -1865,15 +1899,22 @@ static int decoder_impl(tts_handle_t h, const float* memory, int B, int Ts, int 
                 return TTS_ERR_HIP;
             }
             e = hipGraphInstantiate(&h->dec_graph, graph, nullptr, nullptr, 0);
-            hipGraphDestroy(graph);
+            // (the captured graph lives as long as the executable one: see dec_graph_src)
+            h->dec_graph_src = graph;
             if (e != hipSuccess) {
+                hipGraphDestroy(graph);
+                h->dec_graph_src = nullptr;
                 h->dec_graph = nullptr;
                 h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
                 return TTS_ERR_HIP;
             }
             k.memory = memory; k.mel = nullptr; k.align = alignments; k.B = B; k.Ts = Ts; k.n_steps = n_steps;
         }
+        if ((rc = graph_quiesce(h))) return rc;   // (never two launches of one executable graph in flight)
         HIPCHK(h, hipGraphLaunch(h->dec_graph, h->stream));
+        if (!h->ev_graph_done) HIPCHK(h, hipEventCreateWithFlags(&h->ev_graph_done, hipEventDisableTiming));
+        HIPCHK(h, hipEventRecord(h->ev_graph_done, h->stream));
+        h->graph_in_flight = true;
     }
     // OutputProjectionWrapper for all steps at once: mel[b][t][:] = y[b][t] W_o + b_o
     {

@@ -223,10 +223,9 @@ def test_decoder_form_switched_between_pipelined_calls(engine):
         run(1)   # shapes known
         seq = run(0)
         pip = run(1)
-        for i, (a, b) in enumerate(zip(seq, pip)):
-            for k in a:
-                # (the two decoder forms differ in the last bits, so call i is compared with call i of the same form)
-                assert np.array_equal(a[k], b[k]), (i, forms[i], k)
+        # (the two decoder forms differ in the last bits, so call i is compared with call i of the same form)
+        bad = [(i, forms[i], k) for i, (a, b) in enumerate(zip(seq, pip)) for k in a if not np.array_equal(a[k], b[k])]
+        assert not bad, bad
     finally:
         engine.set_option('pipeline', 1)
         engine.set_option('persistent_decoder', 1)
