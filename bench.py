@@ -382,6 +382,7 @@ def main():
     ap.add_argument('--reserve-cus', type=int, default=None)
     ap.add_argument('--hold-lds-kb', type=int, default=None)
     ap.add_argument('--persistent-decoder', type=int, default=None, help='override the library default (0 never, 1 pipelined, 2 always)')
+    ap.add_argument('--pd-ws', type=int, default=None, help='override the library default (1: the weight-stationary persistent decoder, 0: decoder_persistent.hip)')
     ap.add_argument('--gl-pair', type=int, default=None, help='override the library default (Griffin-Lim iterations per launch, 1..3)')
     ap.add_argument('--enc-stream', type=int, default=None, help='override the library default (1: the encoder on a stream of its own, a gap ahead of its decoder)')
     ap.add_argument('--through-facade', action='store_true',
@@ -488,6 +489,8 @@ def main():
         eng.set_option('hold_lds_kb', args.hold_lds_kb)
     if args.persistent_decoder is not None:
         eng.set_option('persistent_decoder', args.persistent_decoder)
+    if args.pd_ws is not None:
+        eng.set_option('pd_ws', args.pd_ws)
     if args.gl_pair is not None:
         eng.set_option('gl_pair', args.gl_pair)
     if args.enc_stream is not None:

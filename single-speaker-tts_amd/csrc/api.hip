@@ -122,6 +122,11 @@ struct tts_handle_s {
     // at B = 64; tools/pipeline_sweep.py: 16.0 against 19.6 ms per call at B = 32), so it stays.  2: whenever the
     // configuration allows it.  0: never.
     int persistent_decoder = 1;
+    // which persistent kernel: 1 (default) = the weight-stationary one (decoder_ws.hip: clusters of 16 workgroups x 32
+    // utterances, weights in registers) wherever it covers the configuration and its 16 * ceil(B / 32) workgroups fit the
+    // budget, else decoder_persistent.hip (8 x 16, weights streamed from L2 every step); 0 = always the latter
+    int pd_ws = 1;
+    bool ws_configured = false;
     int gl_pair = 3;                 // Griffin-Lim iterations per launch (1..3) where nothing per-iteration is asked for
     int n_cus_dev = 0;
     bool pd_configured = false;
@@ -1468,6 +1473,13 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
         h->persistent_decoder = value;
     }
     else if (!std::strcmp(key, "gl_pair")) h->gl_pair = value;
+    else if (!std::strcmp(key, "pd_ws")) {
+        if (value != h->pd_ws) {   // (may change whether a pipelined call's decoder is a persistent kernel at all)
+            int rc = sync_all(h);
+            if (rc) return rc;
+        }
+        h->pd_ws = value;
+    }
     else if (!std::strcmp(key, "enc_stream")) {
         int rc = sync_all(h);
         if (rc) return rc;
@@ -1630,6 +1642,25 @@ int tts_finalize_weights(tts_handle_t h) {
     const size_t o_dw = pack_transposed(p, W(h, "dense/kernel").data(), mem, F);
     const size_t o_db = pack_copy(p, W(h, "dense/bias").data(), F);
     const size_t o_zero = p.alloc(1024);
+    // the decoder's weights once more, in the register order of the weight-stationary persistent kernel (decoder_ws.hip):
+    // TF GRUCell form, the default layer sizes (decoder_ws_supports checks the rest per call)
+    size_t o_wsw = 0, o_wsb = 0;
+    const bool ws_image = !cudnn && c.n_decoder_gru_layers == 2 && att == 256 && U == 256 && mem == 256 &&
+                          c.dec_prenet_units[0] == 256 && c.dec_prenet_units[1] == 128 && c.n_mels <= 256;
+    if (ws_image) {
+        o_wsw = p.alloc(decoder_ws_wimg_floats());
+        o_wsb = p.alloc(decoder_ws_bimg_floats());
+        const float* hb = p.host.data();   // (no allocation below this line)
+        DecWsHostWeights hw;
+        hw.w1f = hb + o_dpfw; hw.b1f = hb + o_dpfb; hw.b1 = hb + o_dpb[0]; hw.w2 = hb + o_dpw[1]; hw.b2 = hb + o_dpb[1];
+        hw.ag_w = hb + o_ag.gates_wt; hw.ag_b = hb + o_ag.gates_b; hw.ac_w = hb + o_ag.cand_wt; hw.ac_b = hb + o_ag.cand_b;
+        hw.al_w = hb + o_al;
+        for (int l = 0; l < 2; ++l) {
+            hw.g_gw[l] = hb + o_dg[l].gates_wt; hw.g_gb[l] = hb + o_dg[l].gates_b;
+            hw.g_cw[l] = hb + o_dg[l].cand_wt; hw.g_cb[l] = hb + o_dg[l].cand_b;
+        }
+        decoder_ws_pack(hw, p.host.data() + o_wsw, p.host.data() + o_wsb);
+    }
 
     {
         int rc = sync_all(h);
@@ -1673,6 +1704,8 @@ int tts_finalize_weights(tts_handle_t h) {
     d.local_vp = predictive ? base + o_vp : nullptr;
     d.n_mels = c.n_mels; d.reduction = c.reduction;
     d.prenet1_units = c.dec_prenet_units[0]; d.prenet2_units = c.dec_prenet_units[1];
+    d.ws_wimg = ws_image ? base + o_wsw : nullptr;
+    d.ws_bimg = ws_image ? base + o_wsb : nullptr;
     h->dense_wt = base + o_dw;
     h->dense_b = base + o_db;
     h->zeros = base + o_zero;
@@ -1783,6 +1816,15 @@ static int encoder_impl(tts_handle_t h, const int32_t* ids, int B, int Ts, float
     return TTS_OK;
 }
 
+// Which persistent decoder kernel a call of this shape takes when `budget` compute units are free for it:
+// 2 = weight-stationary (decoder_ws.hip), 1 = decoder_persistent.hip, 0 = neither (launch-per-layer path).
+static int pd_kernel_for(tts_handle_t h, int B, int Ts, int budget) {
+    const int cudnn = h->cfg.force_cudnn;
+    if (h->pd_ws && decoder_ws_supports(h->dec, cudnn, B, Ts) && decoder_ws_workgroups(B) <= budget) return 2;
+    if (decoder_persistent_supports(h->dec, cudnn, B, Ts) && decoder_persistent_workgroups(B) <= budget) return 1;
+    return 0;
+}
+
 // keys = memory_layer(memory), no bias (LuongAttention, reference tacotron/model.py:205-223; the values stay the raw memory)
 static int attention_keys(tts_handle_t h, const float* memory, int B, int Ts, float* keys) {
     const int A = h->cfg.n_attention_units, mem = 2 * h->cfg.n_gru_units;
@@ -1823,8 +1865,8 @@ static int decoder_impl(tts_handle_t h, const float* memory, int B, int Ts, int 
     // (the launch-per-layer path replays a captured graph with its buffers baked in: one y history there)
     const int pd_budget = h->cur_cu_budget > 0 ? h->cur_cu_budget : h->n_cus_dev;
     const bool pd_wanted = h->persistent_decoder >= 2 || (h->persistent_decoder == 1 && h->cur_cu_budget > 0 && B > 48);
-    const bool use_pd = pd_wanted && decoder_persistent_supports(h->dec, c.force_cudnn, B, Ts) &&
-                        decoder_persistent_workgroups(B) <= pd_budget;
+    const int pd_kernel = pd_wanted ? pd_kernel_for(h, B, Ts, pd_budget) : 0;
+    const bool use_pd = pd_kernel != 0;
     const bool defer_proj = h->defer_projection && use_pd;
     WS(h, defer_proj ? (h->defer_parity ? "dec.yhist.odd" : "dec.yhist.even") : "dec.yhist", float, (size_t)B * n_steps * U, yhist);
     WS(h, "dec.align_raw", float, (size_t)n_steps * B * Ts, align_raw);
@@ -1868,7 +1910,22 @@ static int decoder_impl(tts_handle_t h, const float* memory, int B, int Ts, int 
     // keys = memory_layer(memory), no bias (LuongAttention; values stay the raw memory)
     if (!have_keys && (rc = attention_keys(h, memory, B, Ts, keys))) return rc;
 
-    if (use_pd) {
+    if (pd_kernel == 2) {
+        if (!h->ws_configured) {
+            HIPCHK(h, decoder_ws_configure());
+            h->ws_configured = true;
+        }
+        const int clusters = (B + 31) / 32;
+        WS(h, "dec.ws_scratch", float, decoder_ws_scratch_floats(B), ws_scratch);
+        WS(h, "dec.ws_sync", unsigned, (size_t)64 * clusters + 2, ws_sync);
+        if (ws_sync != h->pd_sync || clusters != h->pd_clusters)   // new buffer / new layout: the sticky status word starts clean
+            HIPCHK(h, hipMemsetAsync(ws_sync + 64 * clusters + 1, 0, sizeof(unsigned), h->stream));
+        HIPCHK(h, decoder_ws_enqueue(h->stream, h->dec, ws_scratch, yhist, memory, keys, B, Ts, n_steps, alignments, ws_sync,
+                                     h->cur_hold_flag, h->debug_hooks ? h->pd_debug_delay : 0));
+        h->pd_sync = ws_sync;
+        h->pd_clusters = clusters;
+        h->pd_used = true;
+    } else if (use_pd) {
         if (!h->pd_configured) {
             HIPCHK(h, decoder_persistent_configure());
             h->pd_configured = true;
@@ -2157,8 +2214,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     const bool enc_ahead_cfg = h->enc_stream && h->pipeline && (h->own_stream || h->pipeline >= 2) &&
                                h->syn_shape[0] == B && h->syn_shape[1] == Ts && h->syn_shape[2] == sp->n_steps &&
                                (h->persistent_decoder >= 2 || (h->persistent_decoder == 1 && B > 48)) && h->reserve_cus > 0 &&
-                               decoder_persistent_supports(h->dec, c.force_cudnn, B, Ts) &&
-                               decoder_persistent_workgroups(B) <= h->reserve_cus;
+                               pd_kernel_for(h, B, Ts, h->reserve_cus) != 0;
     float* memory = (enc_ahead_cfg && (h->syn_calls & 1)) ? memory_o : memory_e;   // (syn_calls is advanced below: this call's parity)
     // the attention keys of that memory, likewise: made behind the encoder on ITS stream, so that nothing but two fills
     // stands between two decoders on the front stream (the 0.04 ms GEMM was on the step's critical path there)
@@ -2233,8 +2289,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         // without costing the step anything: no sleepers then.  The launch-per-layer decoder (configurations the
         // persistent kernel does not cover) still needs the reservation for its ~2000 dependent launches.
         const bool pd_path = (h->persistent_decoder >= 2 || (h->persistent_decoder == 1 && B > 48)) && h->reserve_cus > 0 &&
-                             decoder_persistent_supports(h->dec, c.force_cudnn, B, Ts) &&
-                             decoder_persistent_workgroups(B) <= h->reserve_cus;
+                             pd_kernel_for(h, B, Ts, h->reserve_cus) != 0;
         // the post-net of the call two back read the mel buffer this call's decoder writes; with a caller's
         // mel buffer (possibly the same one every call) the previous call's post-net has to finish as well
         if (h->post_pending[parity]) HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_post_done[parity], 0));

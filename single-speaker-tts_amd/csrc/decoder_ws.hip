@@ -1,0 +1,557 @@
+// Weight-stationary persistent decoder (gfx950, round 5): the 200-step Luong-attention GRU decoder loop as ONE launch
+// whose workgroups keep their share of every layer's weights in REGISTERS for the whole loop.
+//
+// Same arithmetic as decoder.hip / decoder_persistent.hip (reference tacotron/model.py:191-331, wrappers.py:94-124,
+// helpers.py:83-110,161-205; TF-1.8 GRUCell form, global LuongAttention).  What changed against decoder_persistent.hip:
+// there a cluster of 8 workgroups x 16 utterances re-streamed its share of the 6 MB of weights from L2 in EVERY step
+// (128 KB per workgroup and phase: 101 M L2 read requests = 12.6 GB per launch for an algorithmic 44 MB, 20 of the 78 us of
+// a step by ablation: profiles/r04_decoder_l2_counters.txt).  Here
+//   * a CLUSTER is 16 workgroups (one per CU, 512 threads = 2 waves per SIMD, 256 registers per lane) x 32 utterances;
+//     workgroup j owns units [16 j, 16 j + 16) of every 256-unit layer (for a GRU its r AND u columns: the update gate
+//     and the cell state of its units never leave its LDS) and units [8 j, 8 j + 8) of pre-net 2;
+//   * its weights -- 5.25 MB / 16 = 336 KB, 172 registers per lane (WS_NREG) -- are loaded ONCE, from an image that
+//     tts_finalize_weights lays out in register order (decoder_ws_pack: lane (n, q) of wave w holds W[n][k(w, reg, q)]), and
+//     are the B operands of v_mfma_f32_16x16x4_f32 straight from the register file; K is split over the 8 waves (over 4 for
+//     the two gate tiles of a GRU), two 16-row blocks per wave;
+//   * the hand-off buffers are in BLOCK FORMAT [producer workgroup][row 0..31][its units]: a producer's epilogue writes
+//     whole 128-byte lines (two rows x 16 units, eight lanes of one store instruction), a consumer stages the cluster's
+//     A tile with a linear copy (sc1 16-byte loads, no address arithmetic, conflict-free ds_write_b128), and a 16-deep k
+//     chunk of the tile is one contiguous 1 KB block for the MFMA fragment reads;
+//   * hand-off protocol as in decoder_persistent.hip (MI355X_MICROARCH.md, valid forms): every handed-off byte stored
+//     sc1, each storing wave waits vmcnt(0) and adds to the cluster's counter for itself, consumers poll the counter with
+//     an sc1 load in one lane, then a workgroup barrier, then sc1 loads.  No cache-wide release / acquire, no grid barrier;
+//   * attention: workgroup j scores, normalises and contracts rows 2 j and 2 j + 1 of its cluster (4 waves each).
+// Every wait is bounded; on a timeout the sticky status word is set and the grid drains.  All workgroups must be
+// co-resident: 16 * ceil(B / 32) compute units (api.hip checks the budget).  Configurations this kernel does not cover
+// (CudnnCompatibleGRUCell arithmetic, LocalLuongAttention, other layer sizes) run in decoder_persistent.hip / decoder.hip.
+#include "tts_common.h"
+#include "decoder.h"
+#include <cstring>
+
+namespace tts {
+
+#define WS_W 16
+#define WS_M 32
+#define WS_NW 8
+#define WS_THREADS (WS_NW * 64)
+#define WS_D 256
+#define WS_P2 128
+#define WS_RED_LD 20
+#define WS_SPIN_LIMIT 2000000u
+#ifndef WS_KB
+#define WS_KB 2      // key passes (16 positions each) requested together per row
+#endif
+#ifndef WS_VB
+#define WS_VB 8      // value rows per wave requested together
+#endif
+
+// weight registers per lane and phase: 4 * (K / k-slices / 16); the offsets of the phases in the register image
+#define WS_R0 0      // pre-net 1 (folded)        K 512, 1 tile : 16
+#define WS_R1 16     // pre-net 2                 K 256, 1 tile :  8
+#define WS_R2 24     // attention GRU gates       K 384, 2 tiles: 24
+#define WS_R3 48     // attention GRU candidate   K 384, 1 tile : 12
+#define WS_R5 60     // attention layer           K 512, 1 tile : 16
+#define WS_R6 76     // GRU 1 gates               K 512, 2 tiles: 32
+#define WS_R7 108    // GRU 1 candidate           K 512, 1 tile : 16
+#define WS_R8 124    // GRU 2 gates                             : 32
+#define WS_R9 156    // GRU 2 candidate                         : 16
+static_assert(WS_R9 + 16 == DEC_WS_NREG, "register image size");
+
+// LDS map (floats)
+#define WS_OFF_AS 0                                         // staged A tile, block format: 32 rows x <= 512 k
+#define WS_OFF_RED (WS_M * 512)                             // [8 waves][2 row blocks][16][WS_RED_LD]
+#define WS_OFF_H (WS_OFF_RED + WS_NW * 2 * 16 * WS_RED_LD)  // [3 layers][32 rows][16 units]: this workgroup's cell states
+#define WS_OFF_U (WS_OFF_H + 3 * WS_M * 16)                 // [32][16] update gate
+#define WS_OFF_BIAS (WS_OFF_U + WS_M * 16)                  // [DEC_WS_BIAS_SLOTS][32]
+#define WS_OFF_CTRL (WS_OFF_BIAS + DEC_WS_BIAS_SLOTS * 32)
+#define WS_OFF_SC (WS_OFF_CTRL + 16)                        // [2][Ts padded] scores
+
+size_t ws_lds_bytes(int Ts) { return ((size_t)WS_OFF_SC + 2 * (size_t)((Ts + 3) & ~3)) * sizeof(float); }
+
+// per-cluster buffers (floats): the zeroed state block, then the plain hand-off buffers
+#define WS_BUF (WS_M * WS_D)                                // one 256-unit vector of a cluster
+#define WS_STATE_FLOATS (5 * WS_BUF)                        // att | h_att | h_dec1 | h_dec2 | y (top layer output)
+#define WS_REST_FLOATS (4 * WS_BUF + WS_M * WS_P2)          // p1 | rh | ctx | y0 | p2
+
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned ws_u32x4;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)0xFFFFFFF0u, 0x00020000);
+}
+// 16-byte sc1 (write-through / L1-bypassing) accesses: aux bit 4
+__device__ __forceinline__ float4 ws_ld4(const __amdgpu_buffer_rsrc_t& rs, unsigned byte_off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16));
+}
+__device__ __forceinline__ void ws_st4(const __amdgpu_buffer_rsrc_t& rs, unsigned byte_off, float4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, v), rs, (int)byte_off, 0, 16);
+}
+
+enum WsEpi { WS_ACT = 0, WS_GATES = 1, WS_CAND = 2 };
+
+// Start of a phase: wait until `target` arrivals have been counted on the cluster's counter (one lane polls, everybody
+// meets at the barrier).
+__device__ __forceinline__ void ws_wait(unsigned* cnt, unsigned target, int* status, int* ctrl) {
+    if (threadIdx.x == 0 && target > 0) {
+        if (ctrl[0] == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 1023u) == 0 &&
+                    (spins > WS_SPIN_LIMIT || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ctrl[0] = 1;   // drain: no further waits in this workgroup
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+// End of a phase, per storing wave: its (write-through) stores have drained, then its arrival (agent scope).  A workgroup
+// counts WS_ARRIVALS per phase, however many of its waves store.
+#define WS_ARRIVALS 2u
+__device__ __forceinline__ void ws_publish_wave(unsigned* cnt, unsigned arrivals) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct WsPhase {
+    const float* a0; const float* a1;   // the two segments of the A tile: a cluster's buffers, block format
+    float* out;                         // WS_ACT: activations; WS_GATES: r*h; WS_CAND: the new state
+    float* yout;                        // WS_CAND with residual: y = x + h' (block format), or null
+    float* yhist; int yld;              // ... and the same rows in the y history [B][n_steps][256] (+ t * 256), or null
+    int bias_slot, layer;
+    unsigned target;
+    int delay;                          // tests only: workgroup 3 stages late
+};
+
+// LDS offset (floats) of element (row r of row block 0, k = kk + 4 q) of the staged tile, kk a multiple of 16; the
+// distance to row block 1 in *rbs.  Segment 0 holds K0 columns in blocks of UB0 units per producer, segment 1 blocks of 16.
+template <int K0, int UB0>
+__device__ __forceinline__ int ws_a_off(int kk, int r, int q, int* rbs) {
+    if (kk < K0) {
+        if (UB0 == 16) { *rbs = 256; return (kk >> 4) * (WS_M * 16) + r * 16 + 4 * q; }
+        *rbs = 128;
+        return ((kk >> 3) + (q >> 1)) * (WS_M * 8) + r * 8 + 4 * (q & 1);
+    }
+    *rbs = 256;
+    return WS_M * K0 + ((kk - K0) >> 4) * (WS_M * 16) + r * 16 + 4 * q;
+}
+
+// One GEMM-shaped phase: out[32 rows][this workgroup's UBO units (x TILES gates)] = epi([a0 | a1] . W^T + bias), the
+// weights in registers w[ROFF ...].
+template <int K0, int UB0, int K1, int TILES, int UBO, int EPI, int ACT, int ROFF>
+__device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const WsPhase& ph, float* lds, int j, int b0, int B,
+                                         unsigned* cnt, int* status) {
+    constexpr int K = K0 + K1, KSL = WS_NW / TILES, KW = K / KSL, CH = KW / 16, NLD = K / 64, NLD0 = K0 / 64;
+    static_assert(KW % 16 == 0 && K % 64 == 0 && K0 % 64 == 0 && K0 % 16 == 0, "phase shape");
+    // (the thread index is made opaque per phase: every address below is a function of it alone, and hoisted out of the
+    //  step loop for all nine phases at once those addresses -- not the weights -- were what the register allocator spilled)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    float* As = lds + WS_OFF_AS;
+    float* red = lds + WS_OFF_RED;
+    float* h_loc = lds + WS_OFF_H + ph.layer * (WS_M * 16);
+    float* u_loc = lds + WS_OFF_U;
+    const float* bias = lds + WS_OFF_BIAS + ph.bias_slot * 32;
+    int* ctrl = reinterpret_cast<int*>(lds + WS_OFF_CTRL);
+
+    ws_wait(cnt, ph.target, status, ctrl);
+    if (ph.delay && j == 3)   // a late stager: what a workgroup that clears its poll late looks like to its peers
+        for (int i = 0; i < ph.delay; ++i) __builtin_amdgcn_s_sleep(127);
+
+    // ---- stage the cluster's A tile: a linear copy of the (at most two) block-format buffers, all loads in flight together
+    {
+        const __amdgpu_buffer_rsrc_t r0 = ws_rsrc(ph.a0), r1 = ws_rsrc(K1 > 0 ? ph.a1 : ph.a0);
+        float4 sv[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u)
+            sv[u] = u < NLD0 ? ws_ld4(r0, (unsigned)(tid + WS_THREADS * u) * 16u)
+                             : ws_ld4(r1, (unsigned)(tid + WS_THREADS * (u - NLD0)) * 16u);
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) *reinterpret_cast<float4*>(As + 4 * (tid + WS_THREADS * u)) = sv[u];
+        __syncthreads();
+    }
+
+    // ---- this wave's K slice of one 16-column tile, both 16-row blocks
+    const int tile = wave % TILES, slice = wave / TILES;
+    const int kb = slice * KW;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        int rbs;
+        const int off = ws_a_off<K0, UB0>(kb + 16 * c, r, q, &rbs);
+        const float4 a0v = *reinterpret_cast<const float4*>(As + off);
+        const float4 a1v = *reinterpret_cast<const float4*>(As + off + rbs);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.x, w[ROFF + 4 * c + 0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.x, w[ROFF + 4 * c + 0], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.y, w[ROFF + 4 * c + 1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.y, w[ROFF + 4 * c + 1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.z, w[ROFF + 4 * c + 2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.z, w[ROFF + 4 * c + 2], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.w, w[ROFF + 4 * c + 3], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.w, w[ROFF + 4 * c + 3], acc1, 0, 0, 0);
+    }
+    (void)tile;
+    // C/D map of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        red[((wave * 2 + 0) * 16 + q * 4 + i) * WS_RED_LD + r] = acc0[i];
+        red[((wave * 2 + 1) * 16 + q * 4 + i) * WS_RED_LD + r] = acc1[i];
+    }
+    __syncthreads();
+
+    // ---- epilogue: thread e owns (row, 4 consecutive units) of every gate; the K slices are added in a fixed order.
+    // Eight consecutive threads cover one 128-byte line of the output block (two rows x 16 units, four rows x 8).
+    constexpr int NT = WS_M * UBO / 4;             // 128 threads (two waves) or 64
+    if (tid < NT) {
+        const int row = UBO == 16 ? tid >> 2 : tid >> 1;
+        const int c4 = UBO == 16 ? (tid & 3) * 4 : (tid & 1) * 4;
+        const int rb = row >> 4, rr = row & 15;
+        float4 v[TILES];
+#pragma unroll
+        for (int g = 0; g < TILES; ++g) {
+            v[g] = *reinterpret_cast<const float4*>(bias + g * 16 + c4);
+#pragma unroll
+            for (int s = 0; s < KSL; ++s) {
+                const float4 t4 = *reinterpret_cast<const float4*>(red + (((s * TILES + g) * 2 + rb) * 16 + rr) * WS_RED_LD + c4);
+                v[g].x += t4.x; v[g].y += t4.y; v[g].z += t4.z; v[g].w += t4.w;
+            }
+        }
+        const unsigned ooff = (unsigned)((j * WS_M + row) * UBO + c4) * 4u;   // byte offset inside a cluster's buffer
+        float* hl = h_loc + row * 16 + c4;
+        float* ul = u_loc + row * 16 + c4;
+        if (EPI == WS_ACT) {
+            float4 o = v[0];
+            o.x = apply_act(o.x, ACT); o.y = apply_act(o.y, ACT); o.z = apply_act(o.z, ACT); o.w = apply_act(o.w, ACT);
+            ws_st4(ws_rsrc(ph.out), ooff, o);
+        } else if (EPI == WS_GATES) {
+            float4 rr4, uu4;
+            rr4.x = sigmoidf_(v[0].x); rr4.y = sigmoidf_(v[0].y); rr4.z = sigmoidf_(v[0].z); rr4.w = sigmoidf_(v[0].w);
+            uu4.x = sigmoidf_(v[TILES - 1].x); uu4.y = sigmoidf_(v[TILES - 1].y); uu4.z = sigmoidf_(v[TILES - 1].z); uu4.w = sigmoidf_(v[TILES - 1].w);
+            *reinterpret_cast<float4*>(ul) = uu4;               // u stays in this workgroup
+            const float4 h4 = *reinterpret_cast<const float4*>(hl);
+            rr4.x *= h4.x; rr4.y *= h4.y; rr4.z *= h4.z; rr4.w *= h4.w;   // r*h is the candidate's K operand: hand it over
+            ws_st4(ws_rsrc(ph.out), ooff, rr4);
+        } else {   // WS_CAND: h' = u h + (1 - u) tanh(.)
+            const float4 h4 = *reinterpret_cast<const float4*>(hl);
+            const float4 u4 = *reinterpret_cast<const float4*>(ul);
+            float4 hn;
+            hn.x = u4.x * h4.x + (1.0f - u4.x) * tanhf_(v[0].x);
+            hn.y = u4.y * h4.y + (1.0f - u4.y) * tanhf_(v[0].y);
+            hn.z = u4.z * h4.z + (1.0f - u4.z) * tanhf_(v[0].z);
+            hn.w = u4.w * h4.w + (1.0f - u4.w) * tanhf_(v[0].w);
+            *reinterpret_cast<float4*>(hl) = hn;
+            ws_st4(ws_rsrc(ph.out), ooff, hn);
+            if (ph.yout) {   // ResidualWrapper: y = x + h'; x = this workgroup's units of segment 0 of the staged tile
+                const float4 x4 = *reinterpret_cast<const float4*>(As + (j * WS_M + row) * 16 + c4);
+                hn.x += x4.x; hn.y += x4.y; hn.z += x4.z; hn.w += x4.w;
+                ws_st4(ws_rsrc(ph.yout), ooff, hn);
+                if (ph.yhist && b0 + row < B)   // (read by the deferred output projection after the launch: a plain store)
+                    *reinterpret_cast<float4*>(ph.yhist + (size_t)(b0 + row) * ph.yld + j * 16 + c4) = hn;
+            }
+        }
+        // (a plain yhist store drains with the others: one wait covers both)
+        ws_publish_wave(cnt, WS_ARRIVALS / (unsigned)(NT / 64));
+    }
+}
+
+// Luong dot attention for rows 2j and 2j+1 of the cluster (TF-1.8 _luong_score / _compute_attention; dot form at
+// reference attention.py:396-400): softmax over ALL Ts positions, context = alignments . memory.  Four waves per row.
+__device__ __forceinline__ void ws_attention(const float* __restrict__ query, const float* __restrict__ keys,
+                                             const float* __restrict__ values, float* ctx, float* align_t, int Ts, float* lds,
+                                             int j, int b0, int B, unsigned* cnt, unsigned target, int* status) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // (see ws_phase)
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, hw = wave & 3, t256 = tid & 255;
+    float* qs = lds + WS_OFF_AS + half * WS_D;                        // [2][256]
+    float* part = lds + WS_OFF_AS + 2 * WS_D + half * (4 * WS_D);     // [2][4][256]
+    float* redm = lds + WS_OFF_RED + half * 16;                       // [2][4] maxima, then sums
+    float* invs = lds + WS_OFF_RED + 32;                              // [2] 1 / sum
+    const int Tsp = (Ts + 3) & ~3;
+    float* sc = lds + WS_OFF_SC + half * Tsp;
+    int* ctrl = reinterpret_cast<int*>(lds + WS_OFF_CTRL);
+
+    const int rl = 2 * j + half;           // row inside the cluster
+    const int row = b0 + rl;
+    const bool row_ok = row < B;
+    const int mr = row_ok ? row : B - 1;   // (a padding row of the last cluster attends over the last utterance's memory)
+
+    // Scores: 16 lanes per key, 16 keys per pass of the row's 4 waves, WS_KB passes requested together.  The keys do
+    // not depend on the query: the first WS_KB passes are requested BEFORE the wait for the cluster.
+    const int sub = lane >> 4, l16 = lane & 15;
+    float4 kpre[WS_KB][4];
+    auto load_keys = [&](const float* kbase, int j0) {
+#pragma unroll
+        for (int p = 0; p < WS_KB; ++p) {
+            const int jj = j0 + 16 * p + hw * 4 + sub;
+            const float* kr = kbase + (size_t)(jj < Ts ? jj : Ts - 1) * WS_D;   // clamped, never branched on
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kpre[p][i] = *reinterpret_cast<const float4*>(kr + (l16 + 16 * i) * 4);
+        }
+    };
+    const float* kb = keys + (size_t)mr * Ts * WS_D;
+    load_keys(kb, 0);
+
+    ws_wait(cnt, target, status, ctrl);
+
+    // the query: row rl of the attention GRU's new state (block format: unit u at ((u / 16) * 32 + row) * 16 + u % 16)
+    if (t256 < 64)
+        *reinterpret_cast<float4*>(qs + 4 * t256) =
+            ws_ld4(ws_rsrc(query), (unsigned)(((t256 >> 2) * WS_M + rl) * 16 + 4 * (t256 & 3)) * 4u);
+    __syncthreads();
+
+    for (int j0 = 0; j0 < Ts; j0 += 16 * WS_KB) {
+        if (j0 > 0) load_keys(kb, j0);
+#pragma unroll
+        for (int p = 0; p < WS_KB; ++p) {
+            const int jj = j0 + 16 * p + hw * 4 + sub;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 kv = kpre[p][i];
+                const float4 qv = *reinterpret_cast<const float4*>(qs + (l16 + 16 * i) * 4);
+                s = fmaf(kv.x, qv.x, s);
+                s = fmaf(kv.y, qv.y, s);
+                s = fmaf(kv.z, qv.z, s);
+                s = fmaf(kv.w, qv.w, s);
+            }
+            s += __shfl_xor(s, 8);
+            s += __shfl_xor(s, 4);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 1);
+            if (jj < Ts && l16 == 0) sc[jj] = s;
+        }
+    }
+    __syncthreads();
+
+    float m = -INFINITY;
+    for (int jj = t256; jj < Ts; jj += 256) m = fmaxf(m, sc[jj]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) redm[hw] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    float sum = 0.f;
+    for (int jj = t256; jj < Ts; jj += 256) {
+        const float e = __expf(sc[jj] - m);
+        sc[jj] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    __syncthreads();   // everyone has read the maxima
+    if (lane == 0) redm[hw] = sum;
+    __syncthreads();
+    sum = (redm[0] + redm[1]) + (redm[2] + redm[3]);
+    const float inv = 1.0f / sum;
+    if (hw == 0 && lane == 0) invs[half] = inv;
+
+    // context: wave hw takes positions hw, hw + 4, ...; a lane owns 4 consecutive depth elements (1 KB rows, coalesced);
+    // WS_VB rows requested together
+    const float* vb = values + (size_t)mr * Ts * WS_D + 4 * lane;
+    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = hw; j0 < Ts; j0 += 4 * WS_VB) {
+        float4 vv[WS_VB];
+#pragma unroll
+        for (int p = 0; p < WS_VB; ++p) {
+            const int jj = j0 + 4 * p;
+            vv[p] = *reinterpret_cast<const float4*>(vb + (size_t)(jj < Ts ? jj : Ts - 1) * WS_D);
+        }
+#pragma unroll
+        for (int p = 0; p < WS_VB; ++p) {
+            const int jj = j0 + 4 * p;
+            const float e = jj < Ts ? sc[jj] : 0.f;
+            c0.x = fmaf(e, vv[p].x, c0.x); c0.y = fmaf(e, vv[p].y, c0.y); c0.z = fmaf(e, vv[p].z, c0.z); c0.w = fmaf(e, vv[p].w, c0.w);
+        }
+    }
+    *reinterpret_cast<float4*>(part + hw * WS_D + 4 * lane) = c0;
+    __syncthreads();
+    // wave 0 hands over both rows: a lane's 16 bytes are (block j', row 2j + hf, units 4c..4c+3), eight lanes one
+    // 128-byte line of the context buffer (block format), two store instructions
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int jb = 8 * i + (lane >> 3), hf = (lane >> 2) & 1, c = lane & 3;
+            const float* pp = lds + WS_OFF_AS + 2 * WS_D + hf * (4 * WS_D) + 16 * jb + 4 * c;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) {
+                const float4 t4 = *reinterpret_cast<const float4*>(pp + wv * WS_D);
+                a.x += t4.x; a.y += t4.y; a.z += t4.z; a.w += t4.w;
+            }
+            const float iv = invs[hf];
+            a.x *= iv; a.y *= iv; a.z *= iv; a.w *= iv;
+            ws_st4(ws_rsrc(ctx), (unsigned)((jb * WS_M + 2 * j + hf) * 16 + 4 * c) * 4u, a);
+        }
+        ws_publish_wave(cnt, WS_ARRIVALS);
+    }
+    if (align_t && row_ok)
+        for (int k = t256; k < Ts; k += 256) align_t[(size_t)row * Ts + k] = sc[k] * inv;
+}
+
+__global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cluster = blockIdx.x / WS_W, j = blockIdx.x - cluster * WS_W;
+    const int b0 = cluster * WS_M;
+    unsigned* cnt = p.counters + 64 * cluster;
+    int* ctrl = reinterpret_cast<int*>(lds + WS_OFF_CTRL);
+
+    // ---- this wave's weights: 172 registers per lane, once, from the register-order image (decoder_ws_pack)
+    float w[DEC_WS_NREG];
+    {
+        const float4* img = reinterpret_cast<const float4*>(p.wimg) + (size_t)(j * WS_NW + wave) * (DEC_WS_NREG / 4) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < DEC_WS_NREG / 4; ++i) {
+            const float4 v = img[i * 64];
+            w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+        // (opaque from here on: the compiler must keep them in registers, not re-load them inside the loop)
+#pragma unroll
+        for (int i = 0; i < DEC_WS_NREG; ++i) asm volatile("" : "+v"(w[i]));
+    }
+    for (int i = tid; i < 4 * WS_M * 16; i += WS_THREADS) lds[WS_OFF_H + i] = 0.f;   // zero_state (h of three cells, u)
+    for (int i = tid; i < DEC_WS_BIAS_SLOTS * 32; i += WS_THREADS) lds[WS_OFF_BIAS + i] = p.bimg[j * (DEC_WS_BIAS_SLOTS * 32) + i];
+    if (tid == 0) {
+        ctrl[0] = 0;
+        // all workgroups resident: the CUs the call pipeline held for this stream are no longer needed
+        const unsigned n = __hip_atomic_fetch_add(p.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n + 1 == gridDim.x && p.hold_flag) __hip_atomic_store(p.hold_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+
+    float* st = p.state + (size_t)cluster * WS_STATE_FLOATS;
+    float* att = st, *h_att = st + WS_BUF, *h_d1 = st + 2 * WS_BUF, *h_d2 = st + 3 * WS_BUF, *ycur = st + 4 * WS_BUF;
+    float* rs = p.rest + (size_t)cluster * WS_REST_FLOATS;
+    float* p1 = rs, *rh = rs + WS_BUF, *ctx = rs + 2 * WS_BUF, *y0 = rs + 3 * WS_BUF, *p2 = rs + 4 * WS_BUF;
+    const int yld = p.n_steps * WS_D;
+    unsigned g = 0;   // phases completed by the cluster
+    const unsigned per = WS_ARRIVALS * WS_W;
+
+    for (int t = 0; t < p.n_steps; ++t) {
+        WsPhase ph;
+        ph.yout = nullptr; ph.yhist = nullptr; ph.yld = yld; ph.layer = 0; ph.delay = p.dbg_delay;
+        // PrenetWrapper on concat([x_t, attention_{t-1}]) (wrappers.py:122-124).  x_t = (y_{t-1} W_o + b_o)[-n_mels:] is folded
+        // into the pre-net matrix (decoder.hip); x_0 = GO frame = zeros (helpers.py:108): y and attention are zero at step 0,
+        // so only the bias differs there (the un-folded one)
+        ph.a0 = ycur; ph.a1 = att; ph.out = p1; ph.bias_slot = t == 0 ? 1 : 0; ph.target = per * g++;
+        ws_phase<WS_D, 16, WS_D, 1, 16, WS_ACT, ACT_RELU, WS_R0>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        ph.a0 = p1; ph.a1 = nullptr; ph.out = p2; ph.bias_slot = 2; ph.target = per * g++;
+        ws_phase<WS_D, 16, 0, 1, 8, WS_ACT, ACT_RELU, WS_R1>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        // attention GRU (model.py:226-229): gates on [p2 ; h_att], candidate on [p2 ; r*h_att]; the new state is the query
+        ph.a0 = p2; ph.a1 = h_att; ph.out = rh; ph.bias_slot = 3; ph.target = per * g++;
+        ws_phase<WS_P2, 8, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R2>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        ph.a0 = p2; ph.a1 = rh; ph.out = h_att; ph.bias_slot = 4; ph.target = per * g++;
+        ws_phase<WS_P2, 8, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R3>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        ws_attention(h_att, p.keys, p.memory, ctx, p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr, p.Ts, lds, j, b0, p.B,
+                     cnt, per * g++, p.status);
+        // attention_layer(concat([cell_output, context])), no bias
+        ph.a0 = h_att; ph.a1 = ctx; ph.out = att; ph.bias_slot = 5; ph.target = per * g++;
+        ws_phase<WS_D, 16, WS_D, 1, 16, WS_ACT, ACT_NONE, WS_R5>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        // two ResidualWrapper(GRU cell) layers (model.py:254-269); the top one writes the y history
+        ph.layer = 1;
+        ph.a0 = att; ph.a1 = h_d1; ph.out = rh; ph.bias_slot = 6; ph.target = per * g++;
+        ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R6>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        ph.a0 = att; ph.a1 = rh; ph.out = h_d1; ph.yout = y0; ph.bias_slot = 7; ph.target = per * g++;
+        ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R7>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        ph.layer = 2; ph.yout = nullptr;
+        ph.a0 = y0; ph.a1 = h_d2; ph.out = rh; ph.bias_slot = 8; ph.target = per * g++;
+        ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R8>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        ph.a0 = y0; ph.a1 = rh; ph.out = h_d2; ph.yout = ycur; ph.yhist = p.yhist + (size_t)t * WS_D; ph.bias_slot = 9;
+        ph.target = per * g++;
+        ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R9>(w, ph, lds, j, b0, p.B, cnt, p.status);
+    }
+}
+
+bool decoder_ws_supports(const DecoderWeights& w, int cudnn, int B, int Ts) {
+    return !cudnn && w.local_d == 0 && w.n_layers == 2 && w.att_units == WS_D && w.dec_units == WS_D && w.mem_units == WS_D &&
+           w.prenet1_units == WS_D && w.prenet2_units == WS_P2 && w.n_mels <= WS_D && w.ws_wimg && w.ws_bimg && B >= 1 && Ts >= 1 &&
+           ws_lds_bytes(Ts) <= 160 * 1024 - 64 && (size_t)B * Ts * WS_D * 4 < 0xFFFFFFF0ull;
+}
+
+int decoder_ws_workgroups(int B) { return WS_W * ((B + WS_M - 1) / WS_M); }
+size_t decoder_ws_scratch_floats(int B) { return (size_t)((B + WS_M - 1) / WS_M) * (WS_STATE_FLOATS + WS_REST_FLOATS); }
+
+hipError_t decoder_ws_configure() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024 - 64);
+}
+
+// The register-order image of the decoder's weights (host; called by tts_finalize_weights).  Wt arrays are the packed
+// [N][K] matrices of decoder.hip (k contiguous, K = the concatenated A operand).  wimg [16 workgroups][8 waves]
+// [DEC_WS_NREG / 4 float4][64 lanes][4]: lane (n = lane & 15, q = lane >> 4) of wave w holds, in register ROFF + 4 c + e
+// of a phase with TILES column tiles, W[gate * 256 + j * UBO + n][slice * KW + 16 c + 4 q + e] with gate = w % TILES,
+// slice = w / TILES -- exactly what ws_phase multiplies the staged element (row, that k) with.  bimg [16][slots][32].
+void decoder_ws_pack(const DecWsHostWeights& hw, float* wimg, float* bimg) {
+    struct Ph { const float* Wt; int K, tiles, ubo, roff; };
+    const Ph phs[9] = {
+        {hw.w1f, 512, 1, 16, WS_R0}, {hw.w2, 256, 1, 8, WS_R1}, {hw.ag_w, 384, 2, 16, WS_R2}, {hw.ac_w, 384, 1, 16, WS_R3},
+        {hw.al_w, 512, 1, 16, WS_R5}, {hw.g_gw[0], 512, 2, 16, WS_R6}, {hw.g_cw[0], 512, 1, 16, WS_R7},
+        {hw.g_gw[1], 512, 2, 16, WS_R8}, {hw.g_cw[1], 512, 1, 16, WS_R9}};
+    std::memset(wimg, 0, sizeof(float) * decoder_ws_wimg_floats());
+    for (int j = 0; j < WS_W; ++j)
+        for (int wv = 0; wv < WS_NW; ++wv) {
+            float* base = wimg + (size_t)(j * WS_NW + wv) * DEC_WS_NREG * 64;
+            for (const Ph& ph : phs) {
+                const int ksl = WS_NW / ph.tiles, kw = ph.K / ksl, ch = kw / 16;
+                const int gate = wv % ph.tiles, slice = wv / ph.tiles;
+                for (int c = 0; c < ch; ++c)
+                    for (int e = 0; e < 4; ++e) {
+                        const int reg = ph.roff + 4 * c + e;
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int n = lane & 15, q = lane >> 4;
+                            const int k = slice * kw + 16 * c + 4 * q + e;
+                            const float v = n < ph.ubo ? ph.Wt[(size_t)(gate * WS_D + j * ph.ubo + n) * ph.K + k] : 0.f;
+                            base[((size_t)(reg >> 2) * 64 + lane) * 4 + (reg & 3)] = v;   // float4 i = reg / 4 of the lane
+                        }
+                    }
+            }
+        }
+    std::memset(bimg, 0, sizeof(float) * decoder_ws_bimg_floats());
+    for (int j = 0; j < WS_W; ++j) {
+        float* b = bimg + (size_t)j * DEC_WS_BIAS_SLOTS * 32;
+        for (int n = 0; n < 16; ++n) {
+            b[0 * 32 + n] = hw.b1f[j * 16 + n];
+            b[1 * 32 + n] = hw.b1[j * 16 + n];
+            if (n < 8) b[2 * 32 + n] = hw.b2[j * 8 + n];
+            b[3 * 32 + n] = hw.ag_b[j * 16 + n]; b[3 * 32 + 16 + n] = hw.ag_b[WS_D + j * 16 + n];
+            b[4 * 32 + n] = hw.ac_b[j * 16 + n];
+            for (int l = 0; l < 2; ++l) {
+                b[(6 + 2 * l) * 32 + n] = hw.g_gb[l][j * 16 + n]; b[(6 + 2 * l) * 32 + 16 + n] = hw.g_gb[l][WS_D + j * 16 + n];
+                b[(7 + 2 * l) * 32 + n] = hw.g_cb[l][j * 16 + n];
+            }
+        }
+    }
+}
+size_t decoder_ws_wimg_floats() { return (size_t)WS_W * WS_NW * DEC_WS_NREG * 64; }
+size_t decoder_ws_bimg_floats() { return (size_t)WS_W * DEC_WS_BIAS_SLOTS * 32; }
+
+// Capturable: two memsets and one launch.  `scratch`: decoder_ws_scratch_floats(B) floats (the state blocks of all clusters
+// first: zeroed here); `sync` = 64 unsigned per cluster + 1 (resident count) + 1 (sticky status word, see decoder_persistent.hip).
+hipError_t decoder_ws_enqueue(hipStream_t s, const DecoderWeights& w, float* scratch, float* yhist, const float* memory,
+                              const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync, int* hold_flag,
+                              int dbg_delay) {
+    const int clusters = (B + WS_M - 1) / WS_M;
+    hipError_t e;
+    if ((e = hipMemsetAsync(scratch, 0, (size_t)clusters * WS_STATE_FLOATS * sizeof(float), s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(sync, 0, ((size_t)64 * clusters + 1) * sizeof(unsigned), s)) != hipSuccess) return e;
+    WsParams p;
+    p.wimg = w.ws_wimg; p.bimg = w.ws_bimg;
+    p.memory = memory; p.keys = keys;
+    p.state = scratch; p.rest = scratch + (size_t)clusters * WS_STATE_FLOATS;
+    p.yhist = yhist; p.align = align;
+    p.counters = sync; p.resident = sync + 64 * clusters; p.status = reinterpret_cast<int*>(sync + 64 * clusters + 1);
+    p.hold_flag = hold_flag;
+    p.B = B; p.Ts = Ts; p.n_steps = n_steps; p.dbg_delay = dbg_delay;
+    hipLaunchKernelGGL(dec_ws_kernel, dim3(WS_W * clusters), dim3(WS_THREADS), ws_lds_bytes(Ts), s, p);
+    return hipGetLastError();
+}
+
+}  // namespace tts

@@ -14,16 +14,20 @@ pytestmark = pytest.mark.gpu
 WIN, HOP, NFFT = 1102, 275, 2048
 
 
-@pytest.fixture()
-def persistent(engine):
+@pytest.fixture(params=[1, 0], ids=['weight-stationary', 'streamed-weights'])
+def persistent(engine, request):
+    """both persistent kernels: decoder_ws.hip (round 5: clusters of 16 workgroups x 32 utterances, the weights resident
+    in registers; the default) and decoder_persistent.hip (8 x 16, the weights streamed from L2 in every step)"""
     engine.set_option('persistent_decoder', 2)   # also outside the call pipeline
+    engine.set_option('pd_ws', request.param)
     yield engine
+    engine.set_option('pd_ws', 1)
     engine.set_option('persistent_decoder', 1)
 
 
 @pytest.mark.parametrize('B,Ts,S', [(1, 5, 3), (3, 37, 10), (17, 150, 6), (33, 64, 4), (16, 1, 3), (2, 401, 3), (80, 33, 3)])
 def test_persistent_decoder_vs_oracle(persistent, hparams, weights64, B, Ts, S):
-    """Row counts that are no multiple of the 16-row cluster tile, one to five clusters (80 utterances = 40 workgroups),
+    """Row counts that are no multiple of the 16- / 32-row cluster tile, one to five clusters (80 utterances = 40 / 48 workgroups),
     memories of 1 and of 401 positions (the score / context loops run 1 and 13 passes)."""
     rng = np.random.default_rng(200 + B)
     memory = (rng.standard_normal((B, Ts, 256)) * 1.5).astype(np.float32)

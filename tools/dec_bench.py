@@ -13,6 +13,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 mem = eng.to_device((rng.standard_normal((B, 150, 256)) * 0.5).astype(np.float32))
 out = {}
 FORMS = (2,) if 'persistent' in sys.argv[2:] else (0, 2)   # (under --pmc the launch-per-layer form is 12000 dispatches)
+if 'streamed' in sys.argv[2:]:
+    eng.set_option('pd_ws', 0)   # decoder_persistent.hip instead of the weight-stationary kernel
+if 'graph' in sys.argv[2:]:
+    eng.set_option('use_graph', 1)
 for pd in FORMS:
     eng.set_option('persistent_decoder', pd)
     mel, al = eng.decoder_forward(mem, 200)
@@ -23,7 +27,7 @@ for pd in FORMS:
         eng.decoder_forward(mem, 200, mel=mel, alignments=al)
     eng.synchronize()
     print('decoder 200 steps, B=%d: %.2f ms (%s)' % (B, (time.perf_counter() - t0) / n * 1e3,
-                                                     'persistent kernel' if pd else 'launch per layer, hipGraph'), flush=True)
+                                                     ('persistent kernel, weights streamed' if 'streamed' in sys.argv[2:] else 'persistent kernel, weight-stationary') if pd else ('launch per layer, hipGraph' if 'graph' in sys.argv[2:] else 'launch per layer')), flush=True)
     out[pd] = (mel.to_host().astype(np.float64), al.to_host().astype(np.float64))
 for name, i in ((('mel', 0), ('alignments', 1)) if len(FORMS) == 2 else ()):
     a, b = out[0][i], out[2][i]
