@@ -127,6 +127,17 @@ struct tts_handle_s {
     // budget, else decoder_persistent.hip (8 x 16, weights streamed from L2 every step); 0 = always the latter
     int pd_ws = 1;
     bool ws_configured = false;
+    // GEMM weights pre-split into the kernel's bf16 LDS images (gemm_f32.hip, PRE): made on first use per weight matrix
+    // (keyed by its address in the arena; tts_finalize_weights drops them).  Option "gemm_presplit", OFF by default: built
+    // and measured in round 5 (tools/gemm_bench.py 1 / 0, profiles/r05_experiment_gemm_presplit.txt) -- no launch got
+    // faster.  With the register budget of two waves per SIMD the pre-split kernels ran within 1 % of the in-kernel split
+    // on the long-K layers and 10-15 % slower on the short-K ones (1.5 x the weight bytes per tile); at the three-waves
+    // budget the six 16-byte image pieces a thread holds in flight spill (77 against 158 TFLOP/s).  Halving the split
+    // arithmetic changes nothing: the kernel is bound by neither the vector pipe nor LDS latency (fragment reads requested
+    // a step ahead, -DGEMM_FRAG_PIPE: -2 %).
+    struct WeightImage { unsigned char* p = nullptr; size_t bytes = 0; int N = 0, K = 0, Cin = 0; };
+    std::map<const float*, WeightImage> wimg;
+    int gemm_presplit = 0;
     int gl_pair = 3;                 // Griffin-Lim iterations per launch (1..3) where nothing per-iteration is asked for
     int n_cus_dev = 0;
     bool pd_configured = false;
@@ -762,10 +773,48 @@ GemmGroup conv_group(const float* A, int Cin, int ktaps, int T, const float* Wt,
     return g;
 }
 
+// Attach the pre-split image of g.Wt (made now if this weight matrix has none yet for this (N, K, Cin); `refresh`: made
+// again whatever the cache holds -- tts_debug_gemm, whose caller owns the weights and may have rewritten them).
+int gemm_attach_image(tts_handle_t h, GemmGroup& g, bool refresh = false) {
+    g.Wimg = nullptr;
+    if (!h->gemm_presplit) return TTS_OK;
+    auto& im = h->wimg[g.Wt];
+    const size_t bytes = gemm_weight_image_bytes(g.N, g.K);
+    const bool fresh = im.p == nullptr || im.N != g.N || im.K != g.K || im.Cin != g.Cin;
+    if (fresh || refresh) {
+        if (im.bytes < bytes) {
+            if (im.p) {
+                int rc = sync_all(h);   // (a launch that reads the old image may be in flight)
+                if (rc) return rc;
+                HIPCHK(h, hipFree(im.p));
+                im.p = nullptr; im.bytes = 0;
+            }
+            HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&im.p), bytes));
+            im.bytes = bytes;
+        }
+        im.N = g.N; im.K = g.K; im.Cin = g.Cin;
+        HIPCHK(h, launch_gemm_pack_weights(h->stream, g.Wt, im.p, g.N, g.K, g.Cin));
+        // a new image is complete before any stream may use it (the first call of a shape runs unpipelined and makes them
+        // all; later calls find them in the cache)
+        if (fresh) HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    g.Wimg = im.p;
+    return TTS_OK;
+}
+void gemm_drop_images(tts_handle_t h) {
+    for (auto& kv : h->wimg)
+        if (kv.second.p) hipFree(kv.second.p);
+    h->wimg.clear();
+}
+
 int run_single(tts_handle_t h, const GemmGroup& g) {
     GemmBatch b;
     std::memset(&b, 0, sizeof(b));
     b.g[0] = g;
+    {
+        int rc = gemm_attach_image(h, b.g[0]);
+        if (rc) return rc;
+    }
     HIPCHK(h, launch_gemm(h->stream, b, 1));
     return TTS_OK;
 }
@@ -797,6 +846,10 @@ int run_cbhg(tts_handle_t h, const CbhgWeights& w, const char* tag, const float*
             b.g[i] = conv_group(x, w.c_in, k + 1, T, w.bank_wt[k], w.bank_b[k], w.bank_scale[k], w.bank_shift[k], bank,
                                 NB * NF, k * NF, M, NF, ACT_RELU, 0);
         }
+        for (int i = 0; i < ng; ++i) {
+            int rc = gemm_attach_image(h, b.g[i]);
+            if (rc) return rc;
+        }
         HIPCHK(h, launch_gemm(h->stream, b, ng));
         ++*launches;
     }
@@ -808,6 +861,10 @@ int run_cbhg(tts_handle_t h, const CbhgWeights& w, const char* tag, const float*
         const int slices = gemm_splitk_slices(g.K);
         if (slices > 1) {
             WS(h, (t + ".splitk").c_str(), float, (size_t)slices * M * g.N, part);
+            {
+                int rc = gemm_attach_image(h, g);
+                if (rc) return rc;
+            }
             HIPCHK(h, launch_gemm_splitk(h->stream, g, slices, part));
             ++*launches;
         } else {
@@ -1421,6 +1478,7 @@ int tts_destroy(tts_handle_t h) {
     if (h->encs) hipStreamDestroy(h->encs);
     if (h->ev_serial_done) hipEventDestroy(h->ev_serial_done);
     if (h->ev_graph_done) hipEventDestroy(h->ev_graph_done);
+    gemm_drop_images(h);
     for (int i = 0; i < 2; ++i) {
         if (h->ev_post_done[i]) hipEventDestroy(h->ev_post_done[i]);
         if (h->ev_gl_done[i]) hipEventDestroy(h->ev_gl_done[i]);
@@ -1473,6 +1531,7 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
         h->persistent_decoder = value;
     }
     else if (!std::strcmp(key, "gl_pair")) h->gl_pair = value;
+    else if (!std::strcmp(key, "gemm_presplit")) h->gemm_presplit = value;
     else if (!std::strcmp(key, "pd_ws")) {
         if (value != h->pd_ws) {   // (may change whether a pipelined call's decoder is a persistent kernel at all)
             int rc = sync_all(h);
@@ -1670,6 +1729,7 @@ int tts_finalize_weights(tts_handle_t h) {
         int rc = graph_drop(h);
         if (rc) return rc;
     }
+    gemm_drop_images(h);   // (keyed by addresses inside the old arena)
     if (h->arena) hipFree(h->arena);
     h->arena = nullptr;
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->arena), p.host.size() * sizeof(float)));
@@ -2625,6 +2685,10 @@ int tts_debug_gemm(tts_handle_t h, const float* A, const float* Wt, float* C, in
     DeviceScope dev_scope(h);
     if (!h || !A || !Wt || !C || M < 1 || N < 1 || Cin < 4 || (Cin & 3) || ktaps < 1 || T < 1 || M % T) return TTS_ERR_INVALID;
     GemmGroup g = conv_group(A, Cin, ktaps, T, Wt, nullptr, nullptr, nullptr, C, N, 0, M, N, ACT_NONE, pool);
+    {   // the caller's weights: their image is made again on every call (outside the timed span)
+        int rc = gemm_attach_image(h, g, true);
+        if (rc) return rc;
+    }
     ProfScope ps(h, ST_DEBUG_GEMM, 1);
     const int slices = gemm_splitk_slices(g.K);   // same rule as the CBHG projections
     if (slices > 1) {
@@ -2632,7 +2696,11 @@ int tts_debug_gemm(tts_handle_t h, const float* A, const float* Wt, float* C, in
         HIPCHK(h, launch_gemm_splitk(h->stream, g, slices, part));
         return TTS_OK;
     }
-    return run_single(h, g);
+    GemmBatch b;
+    std::memset(&b, 0, sizeof(b));
+    b.g[0] = g;
+    HIPCHK(h, launch_gemm(h->stream, b, 1));
+    return TTS_OK;
 }
 
 // Diagnostic: occupy `n_wgs` workgroup slots of `lds_kb` KB LDS each for `ms` milliseconds on a private

@@ -76,7 +76,12 @@ __device__ __forceinline__ float4 max4(float4 a, float4 b) {
 // powf out of the register allocation of every other GEMM)
 // POOL: instantiation whose A loader takes max(x[t], x[t+1]) (the two k = 3 projections that follow a max-pool): kept
 // apart so that every other GEMM carries neither its second load nor its registers.
-template <bool DENORM, bool POOL>
+// PRE: the weights come PRE-SPLIT (round 5): `g.Wimg` holds, per 128-row block of N and per k tile in the order the k loop
+// visits them, the 24 KB LDS image of the B tile itself -- [split][row][4 chunks, swizzled][8 bf16], made once per weight by
+// gemm_pack_weights_kernel with the same split3 -- so staging the B tile is six 16-byte loads and six linear ds_write_b128
+// per thread and no VALU work: the constants are no longer re-split in every k tile of every workgroup of every call
+// (round 4: half of the kernel's 85.5 M VALU instructions per launch, profiles/r04_gemm_mfma_counters.txt).
+template <bool DENORM, bool POOL, bool PRE>
 __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
     const GemmGroup& g = batch.g[blockIdx.z];
     const int M = g.M, N = g.N, K = g.K;
@@ -113,7 +118,11 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
     // which the buffer range check turns into a zero result -- the loader has no branches and no selects on data.
     typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
     const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, (int)0xFFFFFFF0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wt), 0, (int)0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rs = PRE ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(g.Wimg), 0, (int)0xFFFFFFF0u, 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wt), 0, (int)0xFFFFFFF0u, 0x00020000);
+    auto buf16 = [](const __amdgpu_buffer_rsrc_t& rs, unsigned byte_off) {
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 0));
+    };
     auto buf4 = [](const __amdgpu_buffer_rsrc_t& rs, unsigned byte_off) {
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 0));
     };
@@ -147,7 +156,16 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
         b_off[i] = (b_ok[i] ? n : 0) * K;
     }
 
-    float4 ra[4], rb[4];
+    float4 ra[4], rb[PRE ? 1 : 4];
+    uint4 rbi[PRE ? 6 : 1];      // PRE: this thread's six 16-byte pieces of the B tile's image
+    // PRE: byte offset of the next tile's image (tiles are requested in the order the image was made in)
+    unsigned img_off = PRE ? ((unsigned)(n0 / BN) * (unsigned)((K + BK - 1) / BK) + (unsigned)((g.kt1 > 0 ? g.kt0 : 0) / BK)) * (unsigned)(3 * BN * 64) + (unsigned)tid * 16u
+                           : 0u;
+    auto load_b_image = [&]() {
+#pragma unroll
+        for (int i = 0; i < (PRE ? 6 : 0); ++i) rbi[i] = buf16(b_rs, img_off + (unsigned)(4096 * i));
+        img_off += 3 * BN * 64;
+    };
     float4 ra4 = make_float4(0.f, 0.f, 0.f, 0.f);   // POOL: the raw row behind this thread's four
     unsigned pool_own = 0, pool_nxt = 0;            // POOL (fast path): validity bits of the loaded tile's tap, per row
     bool pool_raw = false;                          // POOL: ra holds raw rows (fast path), to be pooled when stored
@@ -225,17 +243,21 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
                 // land before the MFMAs of the tile in front of them are even issued
                 pool_own = (own[0] ? 1u : 0u) | (own[1] ? 2u : 0u) | (own[2] ? 4u : 0u) | (own[3] ? 8u : 0u);
                 pool_nxt = (nxt[0] ? 1u : 0u) | (nxt[1] ? 2u : 0u) | (nxt[2] ? 4u : 0u) | (nxt[3] ? 8u : 0u);
+                if (PRE) load_b_image();
+                else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    rb[i] = buf4(b_rs, (b_ok[i] && kin) ? (unsigned)(b_off[i] + kk) * 4u : 0xFFFFFFFFu);
+                    for (int i = 0; i < (PRE ? 0 : 4); ++i)
+                        rb[i] = buf4(b_rs, (b_ok[i] && kin) ? (unsigned)(b_off[i] + kk) * 4u : 0xFFFFFFFFu);
+                }
             } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool ok = kin && ((tapmask[i] >> tap) & 1u);
                 const unsigned off = ok ? (unsigned)(a_off[i] + kk) * 4u : 0xFFFFFFFFu;
                 ra[i] = buf4(a_rs, off);
-                rb[i] = buf4(b_rs, (b_ok[i] && kin) ? (unsigned)(b_off[i] + kk) * 4u : 0xFFFFFFFFu);
+                if (!PRE) rb[PRE ? 0 : i] = buf4(b_rs, (b_ok[i] && kin) ? (unsigned)(b_off[i] + kk) * 4u : 0xFFFFFFFFu);
             }
+            if (PRE) load_b_image();
             }
             // advance to the next tile
             if (tap_inner) {          // tap inner, channel chunk outer
@@ -260,8 +282,9 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
             float4 v = buf4(a_rs, off);
             if (POOL) v = max4(v, buf4(a_rs, (ok && ts + 1 < g.T) ? off + (unsigned)g.lda * 4u : off));
             ra[i] = v;
-            rb[i] = buf4(b_rs, (b_ok[i] && kin) ? (unsigned)(b_off[i] + kk) * 4u : 0xFFFFFFFFu);
+            if (!PRE) rb[PRE ? 0 : i] = buf4(b_rs, (b_ok[i] && kin) ? (unsigned)(b_off[i] + kk) * 4u : 0xFFFFFFFFu);
         }
+        if (PRE) load_b_image();
     };
     auto store_tile = [&]() {
         if (POOL && pool_raw) {   // pooled_i = nxt_i ? max(x_i, x_{i+1}) : x_i with x_i = own_i ? raw_i : 0 (x_{i+1}: the raw value)
@@ -282,9 +305,13 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
             *reinterpret_cast<float4*>(&Bs[row * LDS_LD + 4 * kq]) = rb[i];
 #else
             store_split4(As, arow, kq, ra[i]);
-            store_split4(Bs, row, kq, rb[i]);
+            if (!PRE) store_split4(Bs, row, kq, rb[PRE ? 0 : i]);
 #endif
         }
+#ifndef GEMM_F32_MFMA
+#pragma unroll
+        for (int i = 0; i < (PRE ? 6 : 0); ++i) *reinterpret_cast<uint4*>(Bs + tid * 16 + 4096 * i) = rbi[i];
+#endif
     };
 
     // 32 x 32 blocks of this wave that lie entirely past M or N get no MFMAs (wave-uniform): the final Dense has
@@ -354,6 +381,52 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
         // Two 16-deep steps per tile.  Lane (li, lh) of a 32-row block holds k = 16 q + 8 lh .. + 7 of row li: chunk
         // 2 q + lh of the row, one ds_read_b128 per split.  The A fragments of both row blocks stay for the step, the B
         // fragments of one column block at a time (36 fragment registers).
+#ifdef GEMM_FRAG_PIPE
+        // Round 5: the fragment reads of a step are requested one step ahead of its MFMAs, in second register sets (a step =
+        // one column block of one 16-deep half: twelve MFMAs).  Written as reads-then-MFMAs per step, every step began by
+        // waiting for its own ds_read_b128 -- six exposed LDS round trips per tile and wave.
+        auto ld_a = [&](int q, uint4 (&fa)[2][3]) {
+            const int ch = 2 * q + lh;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const int row = wm * 64 + tm * 32 + li;
+                const int off = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) fa[tm][sp] = *reinterpret_cast<const uint4*>(As + sp * BM * 64 + off);
+            }
+        };
+        auto ld_b = [&](int q, int tn, uint4 (&fb)[3]) {
+            const int ch = 2 * q + lh;
+            const int row = wn * 64 + tn * 32 + li;
+            const int off = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) fb[sp] = *reinterpret_cast<const uint4*>(Bs + sp * BN * 64 + off);
+        };
+        auto mma_step = [&](const uint4 (&fa)[2][3], const uint4 (&fb)[3], int tn) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                if (EDGE && !blk_live[tm][tn]) continue;   // wave-uniform
+#define GEMM_MMA(SA, SB)                                                                                              \
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[tm][SA]),    \
+                                                                      __builtin_bit_cast(bf16x8_t, fb[SB]), acc[tm][tn], 0, 0, 0);
+                GEMM_MMA(0, 2) GEMM_MMA(2, 0) GEMM_MMA(1, 1) GEMM_MMA(0, 1) GEMM_MMA(1, 0) GEMM_MMA(0, 0)
+#undef GEMM_MMA
+            }
+        };
+        {
+            uint4 fa0[2][3], fa1[2][3], fb0[3], fb1[3];
+            ld_a(0, fa0);
+            ld_b(0, 0, fb0);
+            ld_b(0, 1, fb1);
+            mma_step(fa0, fb0, 0);
+            ld_a(1, fa1);
+            ld_b(1, 0, fb0);
+            mma_step(fa0, fb1, 1);
+            ld_b(1, 1, fb1);
+            mma_step(fa1, fb0, 0);
+            mma_step(fa1, fb1, 1);
+        }
+#else
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int ch = 2 * q + lh;
@@ -383,6 +456,7 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
                 }
             }
         }
+#endif
 #endif
         __syncthreads();
     }
@@ -452,14 +526,47 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
     }
 }
 
-template <bool DENORM>
+#ifdef GEMM_F32_MFMA
+#define GEMM_PRE_OK false
+#else
+#define GEMM_PRE_OK true
+#endif
+template <bool DENORM, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR))) void gemm_f32_kernel(GemmBatch batch) {
-    gemm_body<DENORM, false>(batch);
+    gemm_body<DENORM, false, PRE && GEMM_PRE_OK>(batch);
 }
 // the max-pool loader keeps a fifth raw row and the validity bits of the tile in flight: a register budget of its own
 // (two waves per SIMD) instead of spilling inside the k loop -- scratch accesses queue behind the tile's global loads
+template <bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR_POOL))) void gemm_f32_pool_kernel(GemmBatch batch) {
-    gemm_body<false, true>(batch);
+    gemm_body<false, true, PRE && GEMM_PRE_OK>(batch);
+}
+
+// The pre-split image of one weight matrix Wt [N][K] (see gemm_body, PRE): grid (k tiles, 128-row blocks of N), the tiles in
+// the order the k loop of a GEMM with this (K, Cin) visits them -- linear, or for a convolution whose channel count is a
+// multiple of the tile depth: channel chunk outer, tap inner.  Rows past N and k past K are zeros.
+__global__ __launch_bounds__(256) void gemm_pack_weights_kernel(const float* __restrict__ Wt, unsigned char* __restrict__ img, int N, int K, int Cin) {
+#ifndef GEMM_F32_MFMA
+    const int it = blockIdx.x, nb = blockIdx.y, tid = threadIdx.x;
+    const int ktaps = K / Cin;
+    const bool tap_inner = ktaps > 1 && (Cin % BK) == 0;
+    const int kb = tap_inner ? (it % ktaps) * Cin + (it / ktaps) * BK : it * BK;
+    unsigned char* tile = img + ((size_t)nb * gridDim.x + it) * (3 * BN * 64);
+    const int kq = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const int n = nb * BN + row, kk = kb + 4 * kq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N && kk < K) v = ld4(Wt + (size_t)n * K + kk);
+        store_split4(tile, row, kq, v);
+    }
+#endif
+}
+size_t gemm_weight_image_bytes(int N, int K) { return (size_t)((N + BN - 1) / BN) * (size_t)((K + BK - 1) / BK) * (3 * BN * 64); }
+hipError_t launch_gemm_pack_weights(hipStream_t s, const float* Wt, unsigned char* img, int N, int K, int Cin) {
+    hipLaunchKernelGGL(gemm_pack_weights_kernel, dim3((K + BK - 1) / BK, (N + BN - 1) / BN), dim3(256), 0, s, Wt, img, N, K, Cin);
+    return hipGetLastError();
 }
 
 hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups) {
@@ -479,9 +586,19 @@ hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups) {
     for (int i = 0; i < n_groups; ++i) pool = pool || b.g[i].pool != 0;
     for (int i = 0; i < n_groups; ++i)
         if (pool && (!b.g[i].pool || b.g[i].C2)) return hipErrorInvalidValue;   // a pooled launch is homogeneous, never de-normalising
-    if (pool) hipLaunchKernelGGL(gemm_f32_pool_kernel, grid, dim3(256), 0, s, b);
-    else if (denorm) hipLaunchKernelGGL((gemm_f32_kernel<true>), grid, dim3(256), 0, s, b);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false>), grid, dim3(256), 0, s, b);
+    // pre-split weight images: all groups of a launch or none (api.hip attaches them to every weight it launches with)
+    bool pre = GEMM_PRE_OK;
+    for (int i = 0; i < n_groups; ++i) pre = pre && b.g[i].Wimg != nullptr;
+    if (pool) {
+        if (pre) hipLaunchKernelGGL((gemm_f32_pool_kernel<true>), grid, dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((gemm_f32_pool_kernel<false>), grid, dim3(256), 0, s, b);
+    } else if (denorm) {
+        if (pre) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, b);
+    } else {
+        if (pre) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, b);
+    }
     return hipGetLastError();
 }
 

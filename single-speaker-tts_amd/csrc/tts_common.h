@@ -55,6 +55,7 @@ struct GemmGroup {
     const int32_t* gather;  // optional: row m reads A + gather[m] * lda (embedding lookup)
     int gather_rows;        // rows of the gathered table: ids outside [0, gather_rows) read as a zero row
     const float* Wt;        // packed weights [N][K], k contiguous
+    const unsigned char* Wimg;   // the same weights pre-split into the kernel's bf16 LDS images (gemm_f32.hip, PRE), or null
     const float* bias;      // [N] or null
     const float* scale;     // [N] folded batch-norm scale or null
     const float* shift;     // [N] folded batch-norm shift (used with scale)
@@ -85,6 +86,9 @@ hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups);
 // few output tiles to fill the GPU); `partial` holds slices*M*N floats.  The partial sums are added in slice
 // order and the group's epilogue (bias, activation, affine, residual) is applied by a second small kernel.
 hipError_t launch_gemm_splitk(hipStream_t s, const GemmGroup& g, int slices, float* partial);
+// the pre-split image of a weight matrix used with this (K, Cin): gemm_weight_image_bytes(N, K) bytes
+size_t gemm_weight_image_bytes(int N, int K);
+hipError_t launch_gemm_pack_weights(hipStream_t s, const float* Wt, unsigned char* img, int N, int K, int Cin);
 int gemm_splitk_slices(int K);   // 1 = not worth splitting; a function of the layer only, never of the batch
 
 // ----------------------------------------------------------------------------- bi-GRU (gru.hip)
