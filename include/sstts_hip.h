@@ -80,6 +80,9 @@ typedef struct tts_config {
                                   * window that leaves the memory makes tts_decoder_forward / tts_synthesize return
                                   * TTS_ERR_UNSUPPORTED (the reference fails at run time there, attention.py:288-304);
                                   * in this mode those calls synchronise the stream to read that condition. */
+    int32_t apply_post_processing;/* 1 (default): post-net CBHG in front of the final Dense; 0: the final Dense straight on the
+                                  * mel spectrogram, manifest entry dense/kernel (n_mels, 1 + n_fft / 2) and no post_process/...
+                                  * weights (reference tacotron/model.py:388-391, params/model.py apply_post_processing) */
 } tts_config_t;
 
 enum tts_attention { TTS_ATTENTION_LUONG = 0, TTS_ATTENTION_LOCAL_LUONG = 1 };

@@ -42,7 +42,7 @@ class TtsConfig(ctypes.Structure):
         ('n_decoder_gru_units', c_int32), ('n_decoder_gru_layers', c_int32), ('n_mels', c_int32),
         ('reduction', c_int32), ('n_fft', c_int32), ('force_cudnn', c_int32),
         ('attention_mechanism', c_int32), ('luong_local_window_d', c_int32), ('luong_force_gaussian', c_int32),
-        ('luong_local_mode', c_int32),
+        ('luong_local_mode', c_int32), ('apply_post_processing', c_int32),
     ]
 
 
@@ -213,6 +213,7 @@ class Engine(object):
             cfg.attention_mechanism = 1 if att.mechanism == 'LocalLuongAttention' else 0
             cfg.luong_local_window_d = att.luong_local_window_D
             cfg.luong_force_gaussian = 1 if att.luong_force_gaussian else 0
+            cfg.apply_post_processing = 1 if hparams.apply_post_processing else 0
         self.cfg = cfg
         h = c_void_p()
         rc = self.lib.tts_create(byref(cfg), device_id, byref(h))

@@ -403,9 +403,11 @@ void build_manifest(tts_handle_t h) {
                     i == 0 ? att : c.n_decoder_gru_units, c.n_decoder_gru_units, cudnn);
     add(m, "decoder2/decoder/output_projection_wrapper/kernel", {c.n_decoder_gru_units, c.n_mels * c.reduction});
     add(m, "decoder2/decoder/output_projection_wrapper/bias", {c.n_mels * c.reduction});
-    cbhg_entries(m, "post_process", c.n_mels, c.post_n_banks, c.post_n_filters, c.post_proj_filters,
-                 c.n_highway_layers, c.n_highway_units, c.n_gru_units, cudnn);
-    add(m, "dense/kernel", {2 * c.n_gru_units, 1 + c.n_fft / 2});
+    // reference tacotron/model.py:388-398: the post-processing CBHG is optional; without it the final Dense takes the mel frames
+    if (c.apply_post_processing)
+        cbhg_entries(m, "post_process", c.n_mels, c.post_n_banks, c.post_n_filters, c.post_proj_filters,
+                     c.n_highway_layers, c.n_highway_units, c.n_gru_units, cudnn);
+    add(m, "dense/kernel", {c.apply_post_processing ? 2 * c.n_gru_units : c.n_mels, 1 + c.n_fft / 2});
     add(m, "dense/bias", {1 + c.n_fft / 2});
 }
 
@@ -1367,6 +1369,7 @@ int tts_default_config(tts_config_t* c) {
     c->luong_local_window_d = 10;
     c->luong_force_gaussian = 1;
     c->luong_local_mode = TTS_LOCAL_MONOTONIC;
+    c->apply_post_processing = 1;
     return TTS_OK;
 }
 
@@ -1695,10 +1698,11 @@ int tts_finalize_weights(tts_handle_t h) {
     const int OUT = c.n_mels * c.reduction;
     const size_t o_ow = pack_transposed(p, W(h, "decoder2/decoder/output_projection_wrapper/kernel").data(), U, OUT);
     const size_t o_ob = pack_copy(p, W(h, "decoder2/decoder/output_projection_wrapper/bias").data(), OUT);
-    const CbhgOffsets o_post =
-        pack_cbhg(h, p, "post_process", c.n_mels, c.post_n_banks, c.post_n_filters, c.post_proj_filters, cudnn);
+    CbhgOffsets o_post{};
+    if (c.apply_post_processing)
+        o_post = pack_cbhg(h, p, "post_process", c.n_mels, c.post_n_banks, c.post_n_filters, c.post_proj_filters, cudnn);
     const int F = 1 + c.n_fft / 2;
-    const size_t o_dw = pack_transposed(p, W(h, "dense/kernel").data(), mem, F);
+    const size_t o_dw = pack_transposed(p, W(h, "dense/kernel").data(), c.apply_post_processing ? mem : c.n_mels, F);
     const size_t o_db = pack_copy(p, W(h, "dense/bias").data(), F);
     const size_t o_zero = p.alloc(1024);
     // the decoder's weights once more, in the register order of the weight-stationary persistent kernel (decoder_ws.hip):
@@ -1744,7 +1748,7 @@ int tts_finalize_weights(tts_handle_t h) {
     h->enc = CbhgWeights();
     h->post = CbhgWeights();
     bind_cbhg(h->enc, o_enc, base, c.enc_prenet_units[1], c.enc_n_banks, c.enc_n_filters, c.enc_proj_filters);
-    bind_cbhg(h->post, o_post, base, c.n_mels, c.post_n_banks, c.post_n_filters, c.post_proj_filters);
+    if (c.apply_post_processing) bind_cbhg(h->post, o_post, base, c.n_mels, c.post_n_banks, c.post_n_filters, c.post_proj_filters);
     h->mem_wt = base + o_mem;
     DecoderWeights& d = h->dec;
     std::memset(&d, 0, sizeof(d));
@@ -2066,15 +2070,22 @@ static int postnet_impl(tts_handle_t h, const float* mel, int B, int T, float* l
     if (!mel || (!linear && !mag) || B < 1 || T < 1) return fail(h, TTS_ERR_INVALID, "postnet_forward: bad arguments");
     const tts_config_t& c = h->cfg;
     const int M = B * T, H2 = 2 * c.n_gru_units, F = 1 + c.n_fft / 2;
-    WS(h, "post.gru", float, (size_t)M * H2, gru);
     int64_t launches = 0;
     ProfScope ps(h, ST_POSTNET, 0);
-    if ((rc = run_cbhg(h, h->post, "post", mel, B, T, gru, &launches))) return rc;
-    GemmGroup g = dense_group(gru, H2, h->dense_wt, h->dense_b, linear, F, M, F, H2, ACT_NONE);
+    // apply_post_processing = 0 (reference tacotron/model.py:388-391): no CBHG, the final Dense reads the mel frames
+    const float* dense_in = mel;
+    int dense_k = c.n_mels;
+    if (c.apply_post_processing) {
+        WS(h, "post.gru", float, (size_t)M * H2, gru);
+        if ((rc = run_cbhg(h, h->post, "post", mel, B, T, gru, &launches))) return rc;
+        dense_in = gru;
+        dense_k = H2;
+    }
+    GemmGroup g = dense_group(dense_in, dense_k, h->dense_wt, h->dense_b, linear, F, M, F, dense_k, ACT_NONE);
     if (mag) {
         g.C2 = mag;
-        g.ldc2 = TTS_GL_FP;
-        g.N2 = TTS_GL_FP;
+        g.ldc2 = gl_fp(c.n_fft);
+        g.N2 = gl_fp(c.n_fft);
         g.d_ref = ref_db;
         g.d_range = std::fabs(ref_db) + std::fabs(max_db);
         g.d_pow = power;
@@ -2257,15 +2268,29 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     SynthScope synth_scope(h);
     const tts_config_t& c = h->cfg;
     const int T = sp->n_steps * c.reduction;
-    const int F = 1 + c.n_fft / 2, FP = TTS_GL_FP;
-    if (c.n_fft != TTS_GL_NFFT)
-        return fail(h, TTS_ERR_UNSUPPORTED, "synthesize: the network's final Dense / de-normalisation epilogue is laid out for n_fft == 2048 "
-                                             "(the audio entry points tts_griffin_lim / tts_stft* take other sizes)");
+    // n_fft is a model parameter (reference tacotron/params/model.py:13-24): the final Dense has 1 + n_fft / 2 outputs, its
+    // de-normalising epilogue writes rows padded to gl_fp(n_fft), and every size but 2048 reconstructs in the general kernels
+    if (!glg_supports(c.n_fft))
+        return fail(h, TTS_ERR_UNSUPPORTED, "synthesize: n_fft must be a power of two between 256 and 4096");
+    const int F = 1 + c.n_fft / 2, FP = gl_fp(c.n_fft);
     // the model's window / hop run in the streaming kernel; any other pair in the general kernels (same results to rounding)
     const bool gl_streaming = gl_is_streaming(c.n_fft, sp->win_length, sp->hop_length);
     if (gl_streaming && (rc = gl_prepare(h, T, sp->win_length, sp->hop_length, c.n_fft))) return rc;
     if (!gl_streaming && (sp->win_length < 2 || sp->win_length > c.n_fft || sp->hop_length < 1))
         return fail(h, TTS_ERR_INVALID, "synthesize: need 2 <= win_length <= n_fft, hop_length >= 1");
+    if (!gl_streaming) {
+        // the general kernels' tables and workspaces, sized HERE, before anything of this call is enqueued on the front or
+        // encoder streams (a growing workspace synchronises every stream; gl_run_generic finds them in place)
+        if ((long long)sp->hop_length * (T - 1) <= c.n_fft / 2)
+            return fail(h, TTS_ERR_INVALID, "griffin_lim: signal shorter than n_fft/2 (reflect padding undefined)");
+        if ((rc = glg_prepare(h, T, sp->win_length, sp->hop_length, c.n_fft))) return rc;
+        const float2* tw_unused = nullptr;
+        if ((rc = glg_twiddles(h, c.n_fft, &tw_unused))) return rc;
+        WS(h, "glg.phase", float2, (size_t)B * T * FP, glg_ph);
+        WS(h, "glg.frames", float, (size_t)B * T * sp->win_length, glg_fr);
+        WS(h, "glg.mse_partial", float, (size_t)B * T, glg_ms);
+        (void)glg_ph; (void)glg_fr; (void)glg_ms;
+    }
     // (one encoder output per call parity: the encoder of call k + 1 writes one while the decoder of call k reads the other)
     WS(h, "syn.memory.even", float, (size_t)B * Ts * 2 * c.n_gru_units, memory_e);
     WS(h, "syn.memory.odd", float, (size_t)B * Ts * 2 * c.n_gru_units, memory_o);

@@ -146,3 +146,57 @@ def synthesize_sentences(raw_sentences, weights, dataset=None, out_dir=None, dev
     for i, wav in enumerate(wavs):
         save_wav(os.path.join(out_dir, '{}.wav'.format(i + 1)), wav, model_params.sampling_rate, True)
     return list(wavs)
+
+
+def read_sentences(path):
+    """reference tacotron/inference.py:139-143: one sentence per line, the newline removed (nothing else stripped)."""
+    raw_sentences = []
+    with open(path, 'r') as f_sent:
+        for line in f_sent:
+            raw_sentences.append(line.replace('\n', ''))
+    return raw_sentences
+
+
+def main(argv=None):
+    """The reference's ``python tacotron/inference.py`` (tacotron/inference.py:130-200): read
+    ``inference_params.synthesis_file``, restore the checkpoint named by ``inference_params`` (``checkpoint_file``, or the
+    latest one of ``checkpoint_dir/checkpoint_load_run``: :44-55), synthesize, write ``{i+1}.wav`` into ``synthesis_dir``.
+
+        python -m single-speaker-tts_amd.tacotron.inference [--synthesis-file F] [--synthesis-dir D]
+                                                            [--weights CKPT | --synthetic-weights SEED]
+
+    The options override the ``inference_params`` fields of the same name.  ``--weights`` takes what
+    ``Tacotron.restore`` takes (a TensorFlow checkpoint prefix or run directory, or an ``.npz`` of the manifest's
+    variables); ``--synthetic-weights`` a seed for the synthetic initialiser (no checkpoint ships with the reference)."""
+    import argparse
+    ap = argparse.ArgumentParser(prog='tacotron.inference')
+    ap.add_argument('--synthesis-file', default=None)
+    ap.add_argument('--synthesis-dir', default=None)
+    ap.add_argument('--weights', default=None)
+    ap.add_argument('--synthetic-weights', type=int, default=None)
+    ap.add_argument('--device', type=int, default=0)
+    ap.add_argument('--seed', type=int, default=0, help='seed of the Griffin-Lim start phases (the reference draws them unseeded)')
+    args = ap.parse_args(argv)
+    out_dir = args.synthesis_dir or inference_params.synthesis_dir
+    # Before we start doing anything we check if the required target folder actually exists (:131-133)
+    if not os.path.isdir(out_dir):
+        raise NotADirectoryError('The specified synthesis target folder does not exist.')
+    raw_sentences = read_sentences(args.synthesis_file or inference_params.synthesis_file)
+    print('{} sentences were loaded for inference.'.format(len(raw_sentences)))
+    if args.synthetic_weights is not None:
+        from .weights import synthetic_weights
+        weights = synthetic_weights(args.synthetic_weights, model_params)
+    elif args.weights is not None:
+        weights = args.weights
+    elif inference_params.checkpoint_file is not None:
+        weights = inference_params.checkpoint_file
+    else:
+        weights = os.path.join(inference_params.checkpoint_dir, inference_params.checkpoint_load_run)
+    wavs = synthesize_sentences(raw_sentences, weights, out_dir=out_dir, device_id=args.device, seed=args.seed)
+    for i in range(len(wavs)):
+        print('Saved: "{}"'.format(os.path.join(out_dir, '{}.wav'.format(i + 1))))
+    return 0
+
+
+if __name__ == '__main__':
+    raise SystemExit(main())

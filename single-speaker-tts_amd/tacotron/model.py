@@ -113,9 +113,9 @@ class Tacotron(object):
         mel, align = eng.decoder_forward(memory, S)
         B = sentences.shape[0]
         mel.shape = (B, S * self.hparams.reduction, self.hparams.n_mels)  # model.py:383 reshape
-        linear = eng.postnet_forward(mel) if self.hparams.apply_post_processing else None
-        if linear is None:
-            raise NotImplementedError('apply_post_processing=False is not implemented')
+        # (apply_post_processing=False, reference tacotron/model.py:388-391: the engine was created with the flag, its
+        #  postnet_forward is then the final Dense alone, kernel (n_mels, 1 + n_fft / 2))
+        linear = eng.postnet_forward(mel)
         return dict(memory=memory, mel=mel, alignments=align, linear=linear, n_steps=S)
 
     def run(self, fetches, feed_dict, n_steps=None):

@@ -104,8 +104,10 @@ def manifest(hp=None):
                                                                dec.target_size * hp.reduction)
     m['decoder2/decoder/output_projection_wrapper/bias'] = (dec.target_size * hp.reduction,)
 
-    _cbhg_entries(m, 'post_process', hp.n_mels, hp.post, cudnn)
-    m['dense/kernel'] = (2 * hp.post.n_gru_units, 1 + hp.n_fft // 2)
+    # reference tacotron/model.py:388-398: without the post-processing CBHG the final Dense takes the mel frames
+    if hp.apply_post_processing:
+        _cbhg_entries(m, 'post_process', hp.n_mels, hp.post, cudnn)
+    m['dense/kernel'] = (2 * hp.post.n_gru_units if hp.apply_post_processing else hp.n_mels, 1 + hp.n_fft // 2)
     m['dense/bias'] = (1 + hp.n_fft // 2,)
     return m
 
