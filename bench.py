@@ -383,6 +383,7 @@ def main():
     ap.add_argument('--hold-lds-kb', type=int, default=None)
     ap.add_argument('--persistent-decoder', type=int, default=None, help='override the library default (0 never, 1 pipelined, 2 always)')
     ap.add_argument('--pd-ws', type=int, default=None, help='override the library default (1: the weight-stationary persistent decoder, 0: decoder_persistent.hip)')
+    ap.add_argument('--set', action='append', default=[], metavar='KEY=VALUE', help='any other tts_set_option (A/B runs)')
     ap.add_argument('--gl-pair', type=int, default=None, help='override the library default (Griffin-Lim iterations per launch, 1..3)')
     ap.add_argument('--enc-stream', type=int, default=None, help='override the library default (1: the encoder on a stream of its own, a gap ahead of its decoder)')
     ap.add_argument('--through-facade', action='store_true',
@@ -491,6 +492,9 @@ def main():
         eng.set_option('persistent_decoder', args.persistent_decoder)
     if args.pd_ws is not None:
         eng.set_option('pd_ws', args.pd_ws)
+    for kv in args.set:
+        k, v = kv.split('=')
+        eng.set_option(k, int(v))
     if args.gl_pair is not None:
         eng.set_option('gl_pair', args.gl_pair)
     if args.enc_stream is not None:

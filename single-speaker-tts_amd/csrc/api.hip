@@ -126,6 +126,10 @@ struct tts_handle_s {
     // utterances, weights in registers) wherever it covers the configuration and its 16 * ceil(B / 32) workgroups fit the
     // budget, else decoder_persistent.hip (8 x 16, weights streamed from L2 every step); 0 = always the latter
     int pd_ws = 1;
+    // the decoder's output projection (one GEMM over all steps) on the MAIN stream in front of the post-net (1: rounds 2-4,
+    // when the front stream bounded the step) or on the front stream behind its decoder (0).  Round 5, with the front stream
+    // 5 ms short of the main one: 14.45 ms per step either way (two same-box pairs): stays as it was
+    int defer_proj = 1;
     bool ws_configured = false;
     // GEMM weights pre-split into the kernel's bf16 LDS images (gemm_f32.hip, PRE): made on first use per weight matrix
     // (keyed by its address in the arena; tts_finalize_weights drops them).  Option "gemm_presplit", OFF by default: built
@@ -1535,6 +1539,11 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     }
     else if (!std::strcmp(key, "gl_pair")) h->gl_pair = value;
     else if (!std::strcmp(key, "gemm_presplit")) h->gemm_presplit = value;
+    else if (!std::strcmp(key, "defer_proj")) {
+        int rc = sync_all(h);
+        if (rc) return rc;
+        h->defer_proj = value;
+    }
     else if (!std::strcmp(key, "pd_ws")) {
         if (value != h->pd_ws) {   // (may change whether a pipelined call's decoder is a persistent kernel at all)
             int rc = sync_all(h);
@@ -2448,7 +2457,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     }
     h->cur_hold_flag = hold_flag;
     h->cur_cu_budget = (pipelined && h->reserve_cus > 0) ? h->reserve_cus : 0;
-    h->defer_projection = pipelined;
+    h->defer_projection = pipelined && h->defer_proj;
     h->defer_parity = parity;
     h->has_pending_proj = false;
     h->pre_keys = (pipelined && keys_ahead) ? keys_ahead : nullptr;
