@@ -114,13 +114,8 @@ struct tts_handle_s {
     int syn_shape[3] = {0, 0, 0};   // (B, Ts, n_steps) of the previous tts_synthesize call
     int last_enc_ahead = -1;        // did the previous PIPELINED call run its encoder ahead on `encs` (1) or on `front` (0)?
     bool in_synthesize = false;     // the stage entry points are being called by tts_synthesize (which orders the streams itself)
-    // persistent decoder (decoder_persistent.hip).  1 (default): under the call pipeline AND with more than 48
-    // utterances per call -- there the step is bound by post-net + Griffin-Lim, and the persistent kernel (17 ms
-    // under that load against 21 for the launch-per-layer graph, no launch boundaries that disturb Griffin-Lim, no
-    // sleeper workgroups) is worth 0.1-0.4 ms per step.  With fewer utterances the step is bound by the decoder
-    // itself, and on a lightly loaded chip the launch-per-layer graph is the faster decoder (9.4 against 15 ms alone
-    // at B = 64; tools/pipeline_sweep.py: 16.0 against 19.6 ms per call at B = 32), so it stays.  2: whenever the
-    // configuration allows it.  0: never.
+    // persistent decoder (decoder_ws.hip / decoder_persistent.hip): 0 never, 2 whenever a kernel covers the configuration,
+    // 1 (default) where it was measured to be the faster choice: pd_choice() below has the rule and the numbers.
     int persistent_decoder = 1;
     // which persistent kernel: 1 (default) = the weight-stationary one (decoder_ws.hip: clusters of 16 workgroups x 32
     // utterances, weights in registers) wherever it covers the configuration and its 16 * ceil(B / 32) workgroups fit the
@@ -1898,6 +1893,24 @@ static int pd_kernel_for(tts_handle_t h, int B, int Ts, int budget) {
     return 0;
 }
 
+// ... and which one the option "persistent_decoder" picks for a call: 0 never; 2 whenever a kernel covers the configuration;
+// 1 (default) by what was measured (tools/pipeline_sweep.py, tools/latency_bench.py, round 5): the weight-stationary kernel
+// under the call pipeline at EVERY batch size (8.5 against 10.1 ms per call at B = 1, 9.6 against 13.7 at 32, 12.4 against
+// 16.4 at 48: the launch-per-layer decoder's ~2000 launches queue behind Griffin-Lim); unpipelined calls keep the
+// launch-per-layer decoder at every batch size -- on an idle chip the two are within 0.5 ms of each other (7.9 against 8.3 ms
+// at B = 1, 8.8 against 8.4 at 16 and more), and a choice by batch size would make an utterance's bits depend on how many
+// others share its call (tests/test_gpu_full_size.py::test_shard_invariance); decoder_persistent.hip (streamed weights:
+// CudnnCompatibleGRUCell, LocalLuongAttention) only under the pipeline with more than 48 utterances, where the step is
+// bound by post-net + Griffin-Lim (rounds 2-4).
+static int pd_choice(tts_handle_t h, int B, int Ts, int budget, bool pipelined) {
+    if (h->persistent_decoder <= 0) return 0;
+    const int k = pd_kernel_for(h, B, Ts, budget);
+    if (h->persistent_decoder >= 2) return k;
+    if (k == 2) return pipelined ? 2 : 0;
+    if (k == 1) return (pipelined && B > 48) ? 1 : 0;
+    return 0;
+}
+
 // keys = memory_layer(memory), no bias (LuongAttention, reference tacotron/model.py:205-223; the values stay the raw memory)
 static int attention_keys(tts_handle_t h, const float* memory, int B, int Ts, float* keys) {
     const int A = h->cfg.n_attention_units, mem = 2 * h->cfg.n_gru_units;
@@ -1937,8 +1950,7 @@ static int decoder_impl(tts_handle_t h, const float* memory, int B, int Ts, int 
     WS(h, "dec.att_stats", float, (size_t)n_steps * B * TTS_ATT_PARTS * 2, att_stats);
     // (the launch-per-layer path replays a captured graph with its buffers baked in: one y history there)
     const int pd_budget = h->cur_cu_budget > 0 ? h->cur_cu_budget : h->n_cus_dev;
-    const bool pd_wanted = h->persistent_decoder >= 2 || (h->persistent_decoder == 1 && h->cur_cu_budget > 0 && B > 48);
-    const int pd_kernel = pd_wanted ? pd_kernel_for(h, B, Ts, pd_budget) : 0;
+    const int pd_kernel = pd_choice(h, B, Ts, pd_budget, h->cur_cu_budget > 0);
     const bool use_pd = pd_kernel != 0;
     const bool defer_proj = h->defer_projection && use_pd;
     WS(h, defer_proj ? (h->defer_parity ? "dec.yhist.odd" : "dec.yhist.even") : "dec.yhist", float, (size_t)B * n_steps * U, yhist);
@@ -2307,8 +2319,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     //  launch-per-layer decoder replays a hipGraph with its buffers baked in -- a second `memory` would re-capture it every call)
     const bool enc_ahead_cfg = h->enc_stream && h->pipeline && (h->own_stream || h->pipeline >= 2) &&
                                h->syn_shape[0] == B && h->syn_shape[1] == Ts && h->syn_shape[2] == sp->n_steps &&
-                               (h->persistent_decoder >= 2 || (h->persistent_decoder == 1 && B > 48)) && h->reserve_cus > 0 &&
-                               pd_kernel_for(h, B, Ts, h->reserve_cus) != 0;
+                               h->reserve_cus > 0 && pd_choice(h, B, Ts, h->reserve_cus, true) != 0;
     float* memory = (enc_ahead_cfg && (h->syn_calls & 1)) ? memory_o : memory_e;   // (syn_calls is advanced below: this call's parity)
     // the attention keys of that memory, likewise: made behind the encoder on ITS stream, so that nothing but two fills
     // stands between two decoders on the front stream (the 0.04 ms GEMM was on the step's critical path there)
@@ -2382,8 +2393,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         // the other n_cus - reserve_cus), and the encoder in front of it may queue behind Griffin-Lim workgroups
         // without costing the step anything: no sleepers then.  The launch-per-layer decoder (configurations the
         // persistent kernel does not cover) still needs the reservation for its ~2000 dependent launches.
-        const bool pd_path = (h->persistent_decoder >= 2 || (h->persistent_decoder == 1 && B > 48)) && h->reserve_cus > 0 &&
-                             pd_kernel_for(h, B, Ts, h->reserve_cus) != 0;
+        const bool pd_path = h->reserve_cus > 0 && pd_choice(h, B, Ts, h->reserve_cus, true) != 0;
         // the post-net of the call two back read the mel buffer this call's decoder writes; with a caller's
         // mel buffer (possibly the same one every call) the previous call's post-net has to finish as well
         if (h->post_pending[parity]) HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_post_done[parity], 0));

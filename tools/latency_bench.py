@@ -9,6 +9,8 @@ W = importlib.import_module('single-speaker-tts_amd.tacotron.weights')
 eng = sstts.Engine()
 eng.load_weights(W.synthetic_weights(0))
 eng.set_option('pipeline', 0)
+if len(sys.argv) > 1:
+    eng.set_option('persistent_decoder', int(sys.argv[1]))   # 2: the persistent decoder also for unpipelined calls
 rng = np.random.default_rng(0)
 for B in (1, 2, 4, 8, 16, 32, 64):
     ids = rng.integers(2, 39, (B, 150)).astype(np.int32)
