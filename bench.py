@@ -41,6 +41,12 @@ MFMA_BF16_PEAK_TFLOPS = 16 * 157.3   # dense bf16 MFMA = 16 x the f32 rate (same
 GEMM_PRODUCTS = 6              # bf16 MFMAs per f32-equivalent product block (csrc/gemm_f32.hip: hi/mid/lo split, six products)
 DEC_MFLOP_PER_UTT_STEP = 3.02  # decoder loop, MFLOP per step and utterance
 DEC_PHASES_PER_STEP = 10       # hand-off phases of the persistent decoder per step (GRUCell form)
+DEC_KERNELS = {   # tts_decoder_kernel_choice
+    0: 'dec_gemm_kernel / dec_attention_kernel (launch per layer: 200 steps x {} dependent launches)',
+    1: 'dec_persistent_kernel (200 steps x {} hand-off phases, clusters of 8 workgroups x 16 utterances, weights streamed from L2 every step)',
+    2: 'dec_ws_kernel (200 steps x {} hand-off phases, clusters of 16 workgroups x 32 utterances, each workgroup\'s share of the '
+       'weights resident in registers: 172 per lane)',
+}
 
 
 def _sha16(paths):
@@ -645,6 +651,7 @@ def main():
             gl_cus = max(1, dev_cus - (args.reserve_cus if args.reserve_cus is not None else 32))
             clock_hz = 1e6 * (valu_rec.get('shader_clock_mhz') or 2400.0)
             valu_issue_frac = valu_rec['valu_wave_insts_per_launch'] * 4.0 / (4 * gl_cus * gl_launch_ms * 1e-3 * clock_hz)
+        dec_choice = eng.decoder_kernel_choice(B_PER_GPU, TS, pipelined=(args.pipeline is None or args.pipeline != 0))
         dec_ms = stage_ms['decoder']
         dec_flop = DEC_MFLOP_PER_UTT_STEP * 1e6 * B_PER_GPU * N_STEPS
         gemm_tflops = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -714,8 +721,8 @@ def main():
                                           'kernel_sha16': valu_rec.get('kernel_sha16')}} if valu_rec else
                               {'kernel': 'gl_stream_kernel', 'stale': valu_why}),
             # the latency-bound loop ("report achieved MFMA fraction and steps/s")
-            'roofline_decoder': {'kernel': 'dec_persistent_kernel (200 steps x {} hand-off phases, clusters of 8 workgroups x 16 '
-                                           'utterances)'.format(DEC_PHASES_PER_STEP),
+            'roofline_decoder': {'kernel': DEC_KERNELS[dec_choice].format(DEC_PHASES_PER_STEP),
+                                 'kernel_choice': dec_choice,
                                  'bound': 'latency',
                                  'ms': dec_ms,
                                  'steps_per_s': N_STEPS / (dec_ms * 1e-3) if dec_ms > 0 else None,

@@ -256,6 +256,11 @@ int tts_wait_host_outputs(tts_handle_t h, int ticket, const float** linear_host,
  * Returns accumulated milliseconds and the number of kernel launches covered since the last
  * tts_profile_reset.  Synchronises the stream. */
 int tts_profile_reset(tts_handle_t h);
+/* Which decoder a call of this shape takes with the handle's current options: 0 = launch per layer (decoder.hip),
+ * 1 = persistent with streamed weights (decoder_persistent.hip), 2 = persistent, weight-stationary (decoder_ws.hip);
+ * `pipelined` != 0: as a call under tts_synthesize's call pipeline (reserve_cus compute units), else a stand-alone call.
+ * Host-only (reads the configuration; nothing is enqueued). */
+int tts_decoder_kernel_choice(tts_handle_t h, int B, int T_sent, int pipelined);
 /* Test hook: device pointer and size of a named internal scratch buffer of the last call
  * ("enc.bank", "enc.p1", "post.xproj", ...); contents are only valid until the next call. */
 int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* bytes);

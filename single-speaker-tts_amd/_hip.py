@@ -95,6 +95,7 @@ _PROTOTYPES = {
     'tts_wait_host_outputs': (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_void_p), POINTER(c_size_t)]),
     'tts_profile_reset': (c_int, [c_void_p]),
     'tts_profile_get': (c_int, [c_void_p, c_char_p, POINTER(c_float), POINTER(c_int64)]),
+    'tts_decoder_kernel_choice': (c_int, [c_void_p, c_int, c_int, c_int]),
     'tts_debug_workspace': (c_int, [c_void_p, c_char_p, POINTER(c_void_p), POINTER(c_size_t)]),
     'tts_debug_hold': (c_int, [c_void_p, c_int, c_int, ctypes.c_double]),
     'tts_debug_gemm': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
@@ -483,6 +484,13 @@ class Engine(object):
     # ------------------------------------------------------------------ profiling / debug
     def profile_reset(self):
         self._check(self.lib.tts_profile_reset(self.handle))
+
+    def decoder_kernel_choice(self, B, Ts, pipelined=True):
+        """0 launch per layer, 1 persistent (streamed weights), 2 persistent (weight-stationary): what a call of this shape takes"""
+        rc = self.lib.tts_decoder_kernel_choice(self.handle, int(B), int(Ts), 1 if pipelined else 0)
+        if rc < 0:
+            self._check(rc)
+        return rc
 
     def device_info(self):
         """(uuid as 32 hex digits, compute units) of the handle's device"""

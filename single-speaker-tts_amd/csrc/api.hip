@@ -2689,6 +2689,12 @@ int tts_wait_host_outputs(tts_handle_t h, int ticket, const float** linear_host,
     return TTS_OK;
 }
 
+int tts_decoder_kernel_choice(tts_handle_t h, int B, int Ts, int pipelined) {
+    if (!h || B < 1 || Ts < 1) return TTS_ERR_INVALID;
+    if (!h->finalized) return fail(h, TTS_ERR_NOT_LOADED, "decoder_kernel_choice: weights not finalised");
+    return pd_choice(h, B, Ts, pipelined ? h->reserve_cus : h->n_cus_dev, pipelined != 0);
+}
+
 int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* bytes) {
     DeviceScope dev_scope(h);
     if (!h || !name) return TTS_ERR_INVALID;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over the persistent decoder alone (tools/dec_bench.py): L2 hits / misses and the bytes fetched from and
+# PMC passes over the persistent decoder alone (tools/dec_bench.py: the weight-stationary kernel; add "streamed" to DEC_ARGS for decoder_persistent.hip): L2 hits / misses and the bytes fetched from and
 # written to memory per launch, one rocprofv3 run per counter group.  Summary in gpurun_out/<tag>_dec_pmc.txt.
 #   bash tools/dec_pmc.sh r04
 set -e
@@ -17,8 +17,8 @@ i=0
 for G in "$G1" "$G2" "$G3" "$G4" "$G5"; do
   i=$((i+1))
   rm -rf $OUT/p$i
-  rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT/p$i -- python3 $R/tools/dec_bench.py 64 persistent > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
+  rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT/p$i -- python3 $R/tools/dec_bench.py 64 persistent $DEC_ARGS > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
   echo "pass $i done"
 done
-python3 $R/tools/pmc_summary.py $OUT dec_persistent_kernel > $R/gpurun_out/${TAG}_dec_pmc.txt
+python3 $R/tools/pmc_summary.py $OUT dec_ws_kernel dec_persistent_kernel > $R/gpurun_out/${TAG}_dec_pmc.txt
 cat $R/gpurun_out/${TAG}_dec_pmc.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/ holds for a round, in one gpurun call:   bash tools/profile_round.sh r02
 # (counter passes never share a run with a trace domain other than the kernel trace)
-TAG=${1:-r03}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
