@@ -140,7 +140,11 @@ __device__ __forceinline__ int ws_a_off(int kk, int r, int q, int* rbs) {
 
 // One GEMM-shaped phase: out[32 rows][this workgroup's UBO units (x TILES gates)] = epi([a0 | a1] . W^T + bias), the
 // weights in registers w[ROFF ...].
-template <int K0, int UB0, int K1, int TILES, int UBO, int EPI, int ACT, int ROFF>
+// KEEP0: segment 0 of the tile is what the phase before staged there (a GRU's candidate phase behind its gates phase: the
+// cell's input x) -- it is not loaded again, and the waves whose K slice lies inside it run their MFMAs BEFORE the wait for
+// the cluster: they only need x and the weights.  SROT rotates the wave -> K slice map so that those are waves 4..7: waves
+// 0 and 1 come out of the previous phase's epilogue last, and lane 0 of wave 0 polls.
+template <int K0, int UB0, int K1, int TILES, int UBO, int EPI, int ACT, int ROFF, bool KEEP0 = false, int SROT = 0>
 __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const WsPhase& ph, float* lds, int j, int b0, int B,
                                          unsigned* cnt, int* status) {
     constexpr int K = K0 + K1, KSL = WS_NW / TILES, KW = K / KSL, CH = KW / 16, NLD = K / 64, NLD0 = K0 / 64;
@@ -159,48 +163,56 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
     const float* bias = lds + WS_OFF_BIAS + ph.bias_slot * 32;
     int* ctrl = reinterpret_cast<int*>(lds + WS_OFF_CTRL);
 
+    // ---- this wave's K slice of one 16-column tile, both 16-row blocks
+    const int tile = wave % TILES, slice = (wave / TILES + SROT) % KSL;
+    const int kb = slice * KW;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto mma_slice = [&]() {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            int rbs;
+            const int off = ws_a_off<K0, UB0>(kb + 16 * c, r, q, &rbs);
+            const float4 a0v = *reinterpret_cast<const float4*>(As + off);
+            const float4 a1v = *reinterpret_cast<const float4*>(As + off + rbs);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.x, w[ROFF + 4 * c + 0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.x, w[ROFF + 4 * c + 0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.y, w[ROFF + 4 * c + 1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.y, w[ROFF + 4 * c + 1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.z, w[ROFF + 4 * c + 2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.z, w[ROFF + 4 * c + 2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.w, w[ROFF + 4 * c + 3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.w, w[ROFF + 4 * c + 3], acc1, 0, 0, 0);
+        }
+    };
+    // KEEP0: the slices inside segment 0 need nothing the cluster is still working on (wave-uniform)
+    const bool early = KEEP0 && kb + KW <= K0;
+    if (early) mma_slice();
+
     ws_wait(cnt, ph.target, status, ctrl);
     if (ph.delay && j == 3)   // a late stager: what a workgroup that clears its poll late looks like to its peers
         for (int i = 0; i < ph.delay; ++i) __builtin_amdgcn_s_sleep(127);
 
     // ---- stage the cluster's A tile: a linear copy of the (at most two) block-format buffers, all loads in flight together
+    // (KEEP0: segment 0 is in place)
     {
+        constexpr int U0 = KEEP0 ? NLD0 : 0;
         const __amdgpu_buffer_rsrc_t r0 = ws_rsrc(ph.a0), r1 = ws_rsrc(K1 > 0 ? ph.a1 : ph.a0);
         float4 sv[NLD];
 #pragma unroll
-        for (int u = 0; u < NLD; ++u)
+        for (int u = U0; u < NLD; ++u)
             sv[u] = u < NLD0 ? ws_ld4(r0, (unsigned)(tid + WS_THREADS * u) * 16u)
                              : ws_ld4(r1, (unsigned)(tid + WS_THREADS * (u - NLD0)) * 16u);
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) *reinterpret_cast<float4*>(As + 4 * (tid + WS_THREADS * u)) = sv[u];
+        for (int u = U0; u < NLD; ++u) *reinterpret_cast<float4*>(As + 4 * (tid + WS_THREADS * u)) = sv[u];
         __syncthreads();
     }
-
-    // ---- this wave's K slice of one 16-column tile, both 16-row blocks
-    const int tile = wave % TILES, slice = wave / TILES;
-    const int kb = slice * KW;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        int rbs;
-        const int off = ws_a_off<K0, UB0>(kb + 16 * c, r, q, &rbs);
-        const float4 a0v = *reinterpret_cast<const float4*>(As + off);
-        const float4 a1v = *reinterpret_cast<const float4*>(As + off + rbs);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.x, w[ROFF + 4 * c + 0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.x, w[ROFF + 4 * c + 0], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.y, w[ROFF + 4 * c + 1], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.y, w[ROFF + 4 * c + 1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.z, w[ROFF + 4 * c + 2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.z, w[ROFF + 4 * c + 2], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.w, w[ROFF + 4 * c + 3], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.w, w[ROFF + 4 * c + 3], acc1, 0, 0, 0);
-    }
-    (void)tile;
-    // C/D map of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
+    if (!early) mma_slice();
+    // C/D map of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg.  The partial tiles are indexed by (slice, tile).
+    const int rslot = slice * TILES + tile;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        red[((wave * 2 + 0) * 16 + q * 4 + i) * WS_RED_LD + r] = acc0[i];
-        red[((wave * 2 + 1) * 16 + q * 4 + i) * WS_RED_LD + r] = acc1[i];
+        red[((rslot * 2 + 0) * 16 + q * 4 + i) * WS_RED_LD + r] = acc0[i];
+        red[((rslot * 2 + 1) * 16 + q * 4 + i) * WS_RED_LD + r] = acc1[i];
     }
     __syncthreads();
 
@@ -449,7 +461,7 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
         ph.a0 = p2; ph.a1 = h_att; ph.out = rh; ph.bias_slot = 3; ph.target = per * g++;
         ws_phase<WS_P2, 8, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R2>(w, ph, lds, j, b0, p.B, cnt, p.status);
         ph.a0 = p2; ph.a1 = rh; ph.out = h_att; ph.bias_slot = 4; ph.target = per * g++;
-        ws_phase<WS_P2, 8, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R3>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        ws_phase<WS_P2, 8, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R3, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
         ws_attention(h_att, p.keys, p.memory, ctx, p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr, p.Ts, lds, j, b0, p.B,
                      cnt, per * g++, p.status);
         // attention_layer(concat([cell_output, context])), no bias
@@ -460,13 +472,13 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
         ph.a0 = att; ph.a1 = h_d1; ph.out = rh; ph.bias_slot = 6; ph.target = per * g++;
         ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R6>(w, ph, lds, j, b0, p.B, cnt, p.status);
         ph.a0 = att; ph.a1 = rh; ph.out = h_d1; ph.yout = y0; ph.bias_slot = 7; ph.target = per * g++;
-        ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R7>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R7, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
         ph.layer = 2; ph.yout = nullptr;
         ph.a0 = y0; ph.a1 = h_d2; ph.out = rh; ph.bias_slot = 8; ph.target = per * g++;
         ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R8>(w, ph, lds, j, b0, p.B, cnt, p.status);
         ph.a0 = y0; ph.a1 = rh; ph.out = h_d2; ph.yout = ycur; ph.yhist = p.yhist + (size_t)t * WS_D; ph.bias_slot = 9;
         ph.target = per * g++;
-        ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R9>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R9, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
     }
 }
 
@@ -488,20 +500,20 @@ hipError_t decoder_ws_configure() {
 // [N][K] matrices of decoder.hip (k contiguous, K = the concatenated A operand).  wimg [16 workgroups][8 waves]
 // [DEC_WS_NREG / 4 float4][64 lanes][4]: lane (n = lane & 15, q = lane >> 4) of wave w holds, in register ROFF + 4 c + e
 // of a phase with TILES column tiles, W[gate * 256 + j * UBO + n][slice * KW + 16 c + 4 q + e] with gate = w % TILES,
-// slice = w / TILES -- exactly what ws_phase multiplies the staged element (row, that k) with.  bimg [16][slots][32].
+// slice = (w / TILES + SROT) % (8 / TILES) -- exactly what ws_phase multiplies the staged element (row, that k) with.  bimg [16][slots][32].
 void decoder_ws_pack(const DecWsHostWeights& hw, float* wimg, float* bimg) {
-    struct Ph { const float* Wt; int K, tiles, ubo, roff; };
+    struct Ph { const float* Wt; int K, tiles, ubo, roff, srot; };   // srot: ws_phase's SROT (the candidate phases)
     const Ph phs[9] = {
-        {hw.w1f, 512, 1, 16, WS_R0}, {hw.w2, 256, 1, 8, WS_R1}, {hw.ag_w, 384, 2, 16, WS_R2}, {hw.ac_w, 384, 1, 16, WS_R3},
-        {hw.al_w, 512, 1, 16, WS_R5}, {hw.g_gw[0], 512, 2, 16, WS_R6}, {hw.g_cw[0], 512, 1, 16, WS_R7},
-        {hw.g_gw[1], 512, 2, 16, WS_R8}, {hw.g_cw[1], 512, 1, 16, WS_R9}};
+        {hw.w1f, 512, 1, 16, WS_R0, 0}, {hw.w2, 256, 1, 8, WS_R1, 0}, {hw.ag_w, 384, 2, 16, WS_R2, 0}, {hw.ac_w, 384, 1, 16, WS_R3, 4},
+        {hw.al_w, 512, 1, 16, WS_R5, 0}, {hw.g_gw[0], 512, 2, 16, WS_R6, 0}, {hw.g_cw[0], 512, 1, 16, WS_R7, 4},
+        {hw.g_gw[1], 512, 2, 16, WS_R8, 0}, {hw.g_cw[1], 512, 1, 16, WS_R9, 4}};
     std::memset(wimg, 0, sizeof(float) * decoder_ws_wimg_floats());
     for (int j = 0; j < WS_W; ++j)
         for (int wv = 0; wv < WS_NW; ++wv) {
             float* base = wimg + (size_t)(j * WS_NW + wv) * DEC_WS_NREG * 64;
             for (const Ph& ph : phs) {
                 const int ksl = WS_NW / ph.tiles, kw = ph.K / ksl, ch = kw / 16;
-                const int gate = wv % ph.tiles, slice = wv / ph.tiles;
+                const int gate = wv % ph.tiles, slice = (wv / ph.tiles + ph.srot) % ksl;
                 for (int c = 0; c < ch; ++c)
                     for (int e = 0; e < 4; ++e) {
                         const int reg = ph.roff + 4 * c + e;

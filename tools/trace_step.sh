@@ -15,7 +15,7 @@ f=glob.glob('gpurun_out/%s/steptrace/**/*kernel_trace.csv'%tag,recursive=True)[0
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 # find the last-but-two persistent decoder launch and print everything from there for ~50 ms
-pd=[i for i,r in enumerate(rows) if 'dec_persistent' in r['Kernel_Name']]
+pd=[i for i,r in enumerate(rows) if 'dec_persistent' in r['Kernel_Name'] or 'dec_ws' in r['Kernel_Name']]
 i0=pd[-3]; t0=int(rows[i0]['Start_Timestamp'])
 last=None
 for r in rows[i0:]:
