@@ -27,6 +27,7 @@
 #include "tts_common.h"
 #include "decoder.h"
 #include <cstring>
+#include <cstdio>
 
 namespace tts {
 
@@ -87,6 +88,16 @@ __device__ __forceinline__ void ws_st4(const __amdgpu_buffer_rsrc_t& rs, unsigne
 }
 
 enum WsEpi { WS_ACT = 0, WS_GATES = 1, WS_CAND = 2 };
+
+#ifdef WS_TIMELINE   // tools only: s_memrealtime stamps (100 MHz) of workgroup 0, thread 0 in step 100: [phase 0..9][8]
+__device__ unsigned long long ws_dbg[10 * 8];
+__device__ __shared__ int ws_tl_step, ws_tl_phase;
+#define WS_STAMP(I) if (blockIdx.x == 0 && threadIdx.x == 0 && ws_tl_step == 100) ws_dbg[ws_tl_phase * 8 + (I)] = __builtin_amdgcn_s_memrealtime();
+#define WS_TL_PHASE(T, K) if (threadIdx.x == 0) { ws_tl_step = (T); ws_tl_phase = (K); }
+#else
+#define WS_STAMP(I)
+#define WS_TL_PHASE(T, K)
+#endif
 
 // Start of a phase: wait until `target` arrivals have been counted on the cluster's counter (one lane polls, everybody
 // meets at the barrier).
@@ -186,9 +197,11 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
     };
     // KEEP0: the slices inside segment 0 need nothing the cluster is still working on (wave-uniform)
     const bool early = KEEP0 && kb + KW <= K0;
+    WS_STAMP(0)
     if (early) mma_slice();
 
     ws_wait(cnt, ph.target, status, ctrl);
+    WS_STAMP(1)
     if (ph.delay && j == 3)   // a late stager: what a workgroup that clears its poll late looks like to its peers
         for (int i = 0; i < ph.delay; ++i) __builtin_amdgcn_s_sleep(127);
 
@@ -206,7 +219,9 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
         for (int u = U0; u < NLD; ++u) *reinterpret_cast<float4*>(As + 4 * (tid + WS_THREADS * u)) = sv[u];
         __syncthreads();
     }
+    WS_STAMP(2)
     if (!early) mma_slice();
+    WS_STAMP(3)
     // C/D map of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg.  The partial tiles are indexed by (slice, tile).
     const int rslot = slice * TILES + tile;
 #pragma unroll
@@ -215,6 +230,7 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
         red[((rslot * 2 + 1) * 16 + q * 4 + i) * WS_RED_LD + r] = acc1[i];
     }
     __syncthreads();
+    WS_STAMP(4)
 
     // ---- epilogue: thread e owns (row, 4 consecutive units) of every gate; the K slices are added in a fixed order.
     // Eight consecutive threads cover one 128-byte line of the output block (two rows x 16 units, four rows x 8).
@@ -267,7 +283,9 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
             }
         }
         // (a plain yhist store drains with the others: one wait covers both)
+        WS_STAMP(5)
         ws_publish_wave(cnt, WS_ARRIVALS / (unsigned)(NT / 64));
+        WS_STAMP(6)
     }
 }
 
@@ -309,8 +327,10 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
     };
     const float* kb = keys + (size_t)mr * Ts * WS_D;
     load_keys(kb, 0);
+    WS_STAMP(0)
 
     ws_wait(cnt, target, status, ctrl);
+    WS_STAMP(1)
 
     // the query: row rl of the attention GRU's new state (block format: unit u at ((u / 16) * 32 + row) * 16 + u % 16)
     if (t256 < 64)
@@ -341,6 +361,7 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
         }
     }
     __syncthreads();
+    WS_STAMP(2)
 
     float m = -INFINITY;
     for (int jj = t256; jj < Ts; jj += 256) m = fmaxf(m, sc[jj]);
@@ -366,6 +387,7 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
 
     // context: wave hw takes positions hw, hw + 4, ...; a lane owns 4 consecutive depth elements (1 KB rows, coalesced);
     // WS_VB rows requested together
+    WS_STAMP(3)
     const float* vb = values + (size_t)mr * Ts * WS_D + 4 * lane;
     float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j0 = hw; j0 < Ts; j0 += 4 * WS_VB) {
@@ -384,6 +406,7 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
     }
     *reinterpret_cast<float4*>(part + hw * WS_D + 4 * lane) = c0;
     __syncthreads();
+    WS_STAMP(4)
     // wave 0 hands over both rows: a lane's 16 bytes are (block j', row 2j + hf, units 4c..4c+3), eight lanes one
     // 128-byte line of the context buffer (block format), two store instructions
     if (wave == 0) {
@@ -401,7 +424,9 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
             a.x *= iv; a.y *= iv; a.z *= iv; a.w *= iv;
             ws_st4(ws_rsrc(ctx), (unsigned)((jb * WS_M + 2 * j + hf) * 16 + 4 * c) * 4u, a);
         }
+        WS_STAMP(5)
         ws_publish_wave(cnt, WS_ARRIVALS);
+        WS_STAMP(6)
     }
     if (align_t && row_ok)
         for (int k = t256; k < Ts; k += 256) align_t[(size_t)row * Ts + k] = sc[k] * inv;
@@ -454,30 +479,40 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
         // into the pre-net matrix (decoder.hip); x_0 = GO frame = zeros (helpers.py:108): y and attention are zero at step 0,
         // so only the bias differs there (the un-folded one)
         ph.a0 = ycur; ph.a1 = att; ph.out = p1; ph.bias_slot = t == 0 ? 1 : 0; ph.target = per * g++;
+        WS_TL_PHASE(t, 0)
         ws_phase<WS_D, 16, WS_D, 1, 16, WS_ACT, ACT_RELU, WS_R0>(w, ph, lds, j, b0, p.B, cnt, p.status);
         ph.a0 = p1; ph.a1 = nullptr; ph.out = p2; ph.bias_slot = 2; ph.target = per * g++;
+        WS_TL_PHASE(t, 1)
         ws_phase<WS_D, 16, 0, 1, 8, WS_ACT, ACT_RELU, WS_R1>(w, ph, lds, j, b0, p.B, cnt, p.status);
         // attention GRU (model.py:226-229): gates on [p2 ; h_att], candidate on [p2 ; r*h_att]; the new state is the query
         ph.a0 = p2; ph.a1 = h_att; ph.out = rh; ph.bias_slot = 3; ph.target = per * g++;
+        WS_TL_PHASE(t, 2)
         ws_phase<WS_P2, 8, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R2>(w, ph, lds, j, b0, p.B, cnt, p.status);
         ph.a0 = p2; ph.a1 = rh; ph.out = h_att; ph.bias_slot = 4; ph.target = per * g++;
+        WS_TL_PHASE(t, 3)
         ws_phase<WS_P2, 8, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R3, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        WS_TL_PHASE(t, 4)
         ws_attention(h_att, p.keys, p.memory, ctx, p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr, p.Ts, lds, j, b0, p.B,
                      cnt, per * g++, p.status);
         // attention_layer(concat([cell_output, context])), no bias
         ph.a0 = h_att; ph.a1 = ctx; ph.out = att; ph.bias_slot = 5; ph.target = per * g++;
+        WS_TL_PHASE(t, 5)
         ws_phase<WS_D, 16, WS_D, 1, 16, WS_ACT, ACT_NONE, WS_R5>(w, ph, lds, j, b0, p.B, cnt, p.status);
         // two ResidualWrapper(GRU cell) layers (model.py:254-269); the top one writes the y history
         ph.layer = 1;
         ph.a0 = att; ph.a1 = h_d1; ph.out = rh; ph.bias_slot = 6; ph.target = per * g++;
+        WS_TL_PHASE(t, 6)
         ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R6>(w, ph, lds, j, b0, p.B, cnt, p.status);
         ph.a0 = att; ph.a1 = rh; ph.out = h_d1; ph.yout = y0; ph.bias_slot = 7; ph.target = per * g++;
+        WS_TL_PHASE(t, 7)
         ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R7, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
         ph.layer = 2; ph.yout = nullptr;
         ph.a0 = y0; ph.a1 = h_d2; ph.out = rh; ph.bias_slot = 8; ph.target = per * g++;
+        WS_TL_PHASE(t, 8)
         ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R8>(w, ph, lds, j, b0, p.B, cnt, p.status);
         ph.a0 = y0; ph.a1 = rh; ph.out = h_d2; ph.yout = ycur; ph.yhist = p.yhist + (size_t)t * WS_D; ph.bias_slot = 9;
         ph.target = per * g++;
+        WS_TL_PHASE(t, 9)
         ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R9, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
     }
 }
@@ -563,6 +598,18 @@ hipError_t decoder_ws_enqueue(hipStream_t s, const DecoderWeights& w, float* scr
     p.hold_flag = hold_flag;
     p.B = B; p.Ts = Ts; p.n_steps = n_steps; p.dbg_delay = dbg_delay;
     hipLaunchKernelGGL(dec_ws_kernel, dim3(WS_W * clusters), dim3(WS_THREADS), ws_lds_bytes(Ts), s, p);
+#ifdef WS_TIMELINE
+    {
+        (void)hipStreamSynchronize(s);
+        unsigned long long hst[80];
+        (void)hipMemcpyFromSymbol(hst, HIP_SYMBOL(ws_dbg), sizeof(hst));
+        for (int k = 0; k < 10; ++k) {
+            fprintf(stderr, "phase %d:", k);
+            for (int i = 0; i < 7; ++i) fprintf(stderr, " [%d]%.2f", i, (double)(hst[k * 8 + i] - hst[0]) / 100.0);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     return hipGetLastError();
 }
 
