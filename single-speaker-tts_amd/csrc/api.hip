@@ -137,6 +137,11 @@ struct tts_handle_s {
     struct WeightImage { unsigned char* p = nullptr; size_t bytes = 0; int N = 0, K = 0, Cin = 0; };
     std::map<const float*, WeightImage> wimg;
     int gemm_presplit = 0;
+    // option "gemm_ps": the producer / consumer form of the GEMM kernel (gemm_f32.hip, PS: 512 threads, four multiplying and
+    // four staging waves, two LDS image pairs).  OFF: measured slower than the 256-thread form on every layer shape (145
+    // against 165 TFLOP/s on the long-K layers, 157 with pre-split weights; 65 against 105 on the final Dense: one workgroup
+    // per compute unit has nothing to cover its pipeline fill and its epilogue) -- profiles/r05_experiment_gemm_presplit.txt
+    int gemm_ps = 0;
     int gl_pair = 3;                 // Griffin-Lim iterations per launch (1..3) where nothing per-iteration is asked for
     int n_cus_dev = 0;
     bool pd_configured = false;
@@ -812,6 +817,7 @@ int run_single(tts_handle_t h, const GemmGroup& g) {
     GemmBatch b;
     std::memset(&b, 0, sizeof(b));
     b.g[0] = g;
+    b.ps = h->gemm_ps;
     {
         int rc = gemm_attach_image(h, b.g[0]);
         if (rc) return rc;
@@ -851,6 +857,7 @@ int run_cbhg(tts_handle_t h, const CbhgWeights& w, const char* tag, const float*
             int rc = gemm_attach_image(h, b.g[i]);
             if (rc) return rc;
         }
+        b.ps = h->gemm_ps;
         HIPCHK(h, launch_gemm(h->stream, b, ng));
         ++*launches;
     }
@@ -866,7 +873,7 @@ int run_cbhg(tts_handle_t h, const CbhgWeights& w, const char* tag, const float*
                 int rc = gemm_attach_image(h, g);
                 if (rc) return rc;
             }
-            HIPCHK(h, launch_gemm_splitk(h->stream, g, slices, part));
+            HIPCHK(h, launch_gemm_splitk(h->stream, g, slices, part, h->gemm_ps));
             ++*launches;
         } else {
             int rc = run_single(h, g);
@@ -1534,6 +1541,7 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     }
     else if (!std::strcmp(key, "gl_pair")) h->gl_pair = value;
     else if (!std::strcmp(key, "gemm_presplit")) h->gemm_presplit = value;
+    else if (!std::strcmp(key, "gemm_ps")) h->gemm_ps = value;
     else if (!std::strcmp(key, "defer_proj")) {
         int rc = sync_all(h);
         if (rc) return rc;
@@ -2743,12 +2751,13 @@ int tts_debug_gemm(tts_handle_t h, const float* A, const float* Wt, float* C, in
     const int slices = gemm_splitk_slices(g.K);   // same rule as the CBHG projections
     if (slices > 1) {
         WS(h, "debug.splitk", float, (size_t)slices * M * N, part);
-        HIPCHK(h, launch_gemm_splitk(h->stream, g, slices, part));
+        HIPCHK(h, launch_gemm_splitk(h->stream, g, slices, part, h->gemm_ps));
         return TTS_OK;
     }
     GemmBatch b;
     std::memset(&b, 0, sizeof(b));
     b.g[0] = g;
+    b.ps = h->gemm_ps;
     HIPCHK(h, launch_gemm(h->stream, b, 1));
     return TTS_OK;
 }

@@ -87,7 +87,14 @@ __device__ __forceinline__ float4 max4(float4 a, float4 b) {
 // gemm_pack_weights_kernel with the same split3 -- so staging the B tile is six 16-byte loads and six linear ds_write_b128
 // per thread and no VALU work: the constants are no longer re-split in every k tile of every workgroup of every call
 // (round 4: half of the kernel's 85.5 M VALU instructions per launch, profiles/r04_gemm_mfma_counters.txt).
-template <bool DENORM, bool POOL, bool PRE>
+// PS (round 5): PRODUCER / CONSUMER split inside the workgroup.  512 threads: waves 0..3 only multiply (the 2 x 2 wave tile of
+// the 256-thread form), waves 4..7 only stage (global loads, the three-way split, LDS stores) into the OTHER of two LDS image
+// pairs; one barrier per k tile.  In the 256-thread form every wave splits, then every wave multiplies, and the three
+// workgroups of a compute unit fall into step with each other (the matrix pipe serialises their MFMA phases, so they reach
+// their VALU phases together): matrix pipe and vector pipe take turns instead of running side by side -- 41 % matrix-pipe
+// busy with neither pipe, nor LDS latency, nor occupancy as the limit (profiles/r05_experiment_gemm_presplit.txt).  Here every
+// SIMD holds one multiplying and one staging wave for the whole k loop.
+template <bool DENORM, bool POOL, bool PRE, bool PS = false>
 __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
     const GemmGroup& g = batch.g[blockIdx.z];
     const int M = g.M, N = g.N, K = g.K;
@@ -107,11 +114,20 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
     __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
 #else
-    __shared__ __attribute__((aligned(16))) unsigned char As[3 * BM * 64];   // [split][row][32 bf16], chunks swizzled
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * BN * 64];
+    // [split][row][32 bf16], chunks swizzled; PS: two such pairs in dynamic LDS (96 KB), As / Bs = the pair being read,
+    // As_w / Bs_w = the pair being written
+    __shared__ __attribute__((aligned(16))) unsigned char As_static[PS ? 16 : 3 * BM * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs_static[PS ? 16 : 3 * BN * 64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];
+    unsigned char* As = PS ? ps_smem : As_static;
+    unsigned char* Bs = PS ? ps_smem + 3 * BM * 64 : Bs_static;
+    unsigned char* As_w = As;
+    unsigned char* Bs_w = Bs;
 #endif
 
-    const int tid = threadIdx.x;
+    // PS: both roles index their work with 0..255 (a consumer's wave tile, a producer's staging rows)
+    const bool producer = PS && threadIdx.x >= 256;
+    const int tid = PS ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -310,13 +326,13 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
             *reinterpret_cast<float4*>(&As[arow * LDS_LD + 4 * kq]) = ra[i];
             *reinterpret_cast<float4*>(&Bs[row * LDS_LD + 4 * kq]) = rb[i];
 #else
-            store_split4(As, arow, kq, ra[i]);
-            if (!PRE) store_split4(Bs, row, kq, rb[PRE ? 0 : i]);
+            store_split4(As_w, arow, kq, ra[i]);
+            if (!PRE) store_split4(Bs_w, row, kq, rb[PRE ? 0 : i]);
 #endif
         }
 #ifndef GEMM_F32_MFMA
 #pragma unroll
-        for (int i = 0; i < (PRE ? 6 : 0); ++i) *reinterpret_cast<uint4*>(Bs + tid * 16 + 4096 * i) = rbi[i];
+        for (int i = 0; i < (PRE ? 6 : 0); ++i) *reinterpret_cast<uint4*>(Bs_w + tid * 16 + 4096 * i) = rbi[i];
 #endif
     };
 
@@ -339,15 +355,10 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
 
     const int k_begin = g.kt1 > 0 ? g.kt0 : 0;
     const int k_end = g.kt1 > 0 ? g.kt1 : K;
-    load_tile(k_begin);
-    // the k loop, instantiated twice: EDGE = false is the loop of every full tile (no tests between the MFMAs),
-    // EDGE = true the one of a wave that owns a padded block
-    auto k_loop = [&](auto edge_c) {
-    constexpr bool EDGE = decltype(edge_c)::value;
-    for (int kt = k_begin; kt < k_end; kt += BK) {
-        store_tile();
-        __syncthreads();
-        if (kt + BK < k_end) load_tile(kt + BK);
+    // the MFMAs of one k tile on the LDS images As / Bs, instantiated twice: EDGE = false is the form of every full tile (no
+    // tests between the MFMAs), EDGE = true the one of a wave that owns a padded block
+    auto mma_tile = [&](auto edge_c) {
+        constexpr bool EDGE = decltype(edge_c)::value;
 #ifdef GEMM_F32_MFMA
         // Two register sets for the LDS fragments: the ds_read_b128 of MFMA step q + 1 are requested before the 16 MFMAs
         // of step q are issued, so a step never starts by waiting for LDS (hipcc leaves part of that latency exposed
@@ -464,11 +475,50 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
         }
 #endif
 #endif
+    };
+    auto k_loop = [&](auto edge_c) {
+        if (!PS) {
+            load_tile(k_begin);
+            for (int kt = k_begin; kt < k_end; kt += BK) {
+                store_tile();
+                __syncthreads();
+                if (kt + BK < k_end) load_tile(kt + BK);
+                mma_tile(edge_c);
+                __syncthreads();
+            }
+            return;
+        }
+#ifndef GEMM_F32_MFMA
+        // PS: the producers are one tile ahead in LDS and one more in registers
+        unsigned char* const A0 = ps_smem, * const B0 = ps_smem + 3 * BM * 64;
+        unsigned char* const A1 = ps_smem + 3 * (BM + BN) * 64, * const B1 = A1 + 3 * BM * 64;
+        if (producer) {
+            load_tile(k_begin);
+            As_w = A0; Bs_w = B0;
+            store_tile();
+            if (k_begin + BK < k_end) load_tile(k_begin + BK);
+        }
         __syncthreads();
-    }
+        int cur = 0;
+        for (int kt = k_begin; kt < k_end; kt += BK) {
+            if (producer) {
+                if (kt + BK < k_end) {
+                    As_w = cur ? A0 : A1; Bs_w = cur ? B0 : B1;
+                    store_tile();
+                    if (kt + 2 * BK < k_end) load_tile(kt + 2 * BK);
+                }
+            } else {
+                As = cur ? A1 : A0; Bs = cur ? B1 : B0;
+                mma_tile(edge_c);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+#endif
     };
     if (blk_live[0][0] && blk_live[0][1] && blk_live[1][0] && blk_live[1][1]) k_loop(std::false_type{});
     else k_loop(std::true_type{});
+    if (producer) return;   // (PS: the staging waves have no part in the epilogue)
 
     // ---- epilogue.  C/D map of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     if (g.epi == EPI_HIGHWAY) {
@@ -548,6 +598,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR_P
     gemm_body<false, true, PRE && GEMM_PRE_OK>(batch);
 }
 
+// the producer / consumer form (gemm_body, PS): 512 threads, two LDS image pairs in dynamic shared memory
+#define GEMM_PS_LDS (2 * 3 * (BM + BN) * 64)
+template <bool DENORM, bool PRE>
+__global__ __launch_bounds__(512) void gemm_ps_kernel(GemmBatch batch) {
+    gemm_body<DENORM, false, PRE && GEMM_PRE_OK, GEMM_PRE_OK>(batch);
+}
+template <bool PRE>
+__global__ __launch_bounds__(512) void gemm_ps_pool_kernel(GemmBatch batch) {
+    gemm_body<false, true, PRE && GEMM_PRE_OK, GEMM_PRE_OK>(batch);
+}
+template <typename K>
+static hipError_t gemm_ps_launch(K kernel, dim3 grid, hipStream_t s, const GemmBatch& b) {
+    // (more than 64 KB of dynamic LDS needs the attribute; per device and kernel, cheap: set on every launch)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_PS_LDS);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, grid, dim3(512), GEMM_PS_LDS, s, b);
+    return hipGetLastError();
+}
+
 // The pre-split image of one weight matrix Wt [N][K] (see gemm_body, PRE): grid (k tiles, 128-row blocks of N), the tiles in
 // the order the k loop of a GEMM with this (K, Cin) visits them -- linear, or for a convolution whose channel count is a
 // multiple of the tile depth: channel chunk outer, tap inner.  Rows past N and k past K are zeros.
@@ -595,6 +664,11 @@ hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups) {
     // pre-split weight images: all groups of a launch or none (api.hip attaches them to every weight it launches with)
     bool pre = GEMM_PRE_OK;
     for (int i = 0; i < n_groups; ++i) pre = pre && b.g[i].Wimg != nullptr;
+    if (b.ps && GEMM_PRE_OK) {
+        if (pool) return pre ? gemm_ps_launch(gemm_ps_pool_kernel<true>, grid, s, b) : gemm_ps_launch(gemm_ps_pool_kernel<false>, grid, s, b);
+        if (denorm) return pre ? gemm_ps_launch(gemm_ps_kernel<true, true>, grid, s, b) : gemm_ps_launch(gemm_ps_kernel<true, false>, grid, s, b);
+        return pre ? gemm_ps_launch(gemm_ps_kernel<false, true>, grid, s, b) : gemm_ps_launch(gemm_ps_kernel<false, false>, grid, s, b);
+    }
     if (pool) {
         if (pre) hipLaunchKernelGGL((gemm_f32_pool_kernel<true>), grid, dim3(256), 0, s, b);
         else hipLaunchKernelGGL((gemm_f32_pool_kernel<false>), grid, dim3(256), 0, s, b);
@@ -626,10 +700,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int slic
 // not depend on how many others share the batch (the summation order over k is part of the result).
 int gemm_splitk_slices(int K) { return K >= 4096 ? 8 : 1; }   // (8: 600 workgroups for the encoder projection at 64 x 150 tokens; 4 left a CU with 1.2)
 
-hipError_t launch_gemm_splitk(hipStream_t s, const GemmGroup& g, int slices, float* partial) {
+hipError_t launch_gemm_splitk(hipStream_t s, const GemmGroup& g, int slices, float* partial, int ps) {
     if (slices < 2 || slices > TTS_GEMM_MAX_GROUPS || g.epi != EPI_STD || g.C2) return hipErrorInvalidValue;
     GemmBatch b;
     memset(&b, 0, sizeof(b));
+    b.ps = ps;
     const int k_tiles = (g.K + BK - 1) / BK;
     for (int i = 0; i < slices; ++i) {
         GemmGroup p = g;

@@ -79,13 +79,14 @@ struct GemmGroup {
 #define TTS_GEMM_MAX_GROUPS 16
 struct GemmBatch {
     GemmGroup g[TTS_GEMM_MAX_GROUPS];
+    int ps;   // 1: the producer / consumer form of the kernel (512 threads: four multiplying, four staging waves; gemm_f32.hip, PS)
 };
 // Launches one grouped GEMM; all groups must share M (grid.x) and have N <= max_n.
 hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups);
 // One GEMM whose K range is cut into `slices` parts computed by separate workgroups (for problems with too
 // few output tiles to fill the GPU); `partial` holds slices*M*N floats.  The partial sums are added in slice
 // order and the group's epilogue (bias, activation, affine, residual) is applied by a second small kernel.
-hipError_t launch_gemm_splitk(hipStream_t s, const GemmGroup& g, int slices, float* partial);
+hipError_t launch_gemm_splitk(hipStream_t s, const GemmGroup& g, int slices, float* partial, int ps = 0);
 // the pre-split image of a weight matrix used with this (K, Cin): gemm_weight_image_bytes(N, K) bytes
 size_t gemm_weight_image_bytes(int N, int K);
 hipError_t launch_gemm_pack_weights(hipStream_t s, const float* Wt, unsigned char* img, int N, int K, int Cin);

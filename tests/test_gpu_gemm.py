@@ -47,3 +47,25 @@ def test_gemm_conv_matches_numpy(engine, B, T, Cin, ktaps, N, pool):
     print('gemm B={} T={} Cin={} k={} N={} pool={}: rel-L2 {:.2e}'.format(B, T, Cin, ktaps, N, pool, e))
     assert e < 1e-5
     dx.free(); dw.free(); dc.free()
+
+
+@pytest.mark.parametrize('option', ['gemm_ps', 'gemm_presplit'])
+def test_gemm_variant_forms_match_numpy(engine, option):
+    """The two GEMM forms that are in the source but off (measured, not faster: profiles/r05_experiment_gemm_presplit.txt) --
+    producer / consumer waves (`gemm_ps`) and pre-split weight images (`gemm_presplit`) -- stay correct: dense, conv3 with
+    the max-pool loader, and the split-K shape."""
+    try:
+        engine.set_option(option, 1)
+        for B, T, Cin, ktaps, N, pool in [(3, 50, 128, 1, 256, 0), (2, 77, 256, 3, 128, 1), (5, 30, 2048, 3, 128, 1), (4, 40, 80, 5, 128, 0)]:
+            rng = np.random.default_rng(B * 1000 + Cin)
+            M = B * T
+            x = rng.standard_normal((M, Cin)).astype(np.float32)
+            w = (rng.standard_normal((N, ktaps * Cin)) * 0.05).astype(np.float32)
+            ref = _conv_ref(x, w, ktaps, T, pool)
+            dx, dw = engine.to_device(x), engine.to_device(w)
+            dc = engine.empty((M, N))
+            engine._check(engine.lib.tts_debug_gemm(engine.handle, dx.data_ptr(), dw.data_ptr(), dc.data_ptr(), M, N, Cin, ktaps, T, pool))
+            assert rel_l2(dc.to_host(), ref) < 1e-5, (option, B, T, Cin, ktaps, N, pool)
+            dx.free(); dw.free(); dc.free()
+    finally:
+        engine.set_option(option, 0)

@@ -8,6 +8,8 @@ sstts = importlib.import_module('single-speaker-tts_amd')
 eng = sstts.Engine()
 if len(sys.argv) > 1:
     eng.set_option('gemm_presplit', int(sys.argv[1]))   # 0: the weights split in the kernel, tile by tile (round 4)
+if len(sys.argv) > 2:
+    eng.set_option('gemm_ps', int(sys.argv[2]))         # 1: producer / consumer form (512 threads), 0: 256 threads (round 4)
 rng = np.random.default_rng(0)
 shapes = [  # name, M, N, Cin, ktaps, T, pool
     ('dense 64000x256x3072', 64000, 256, 3072, 1, 1000, 0),
