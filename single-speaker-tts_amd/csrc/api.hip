@@ -1720,7 +1720,7 @@ int tts_finalize_weights(tts_handle_t h) {
     // the decoder's weights once more, in the register order of the weight-stationary persistent kernel (decoder_ws.hip):
     // TF GRUCell form, the default layer sizes (decoder_ws_supports checks the rest per call)
     size_t o_wsw = 0, o_wsb = 0;
-    const bool ws_image = !cudnn && c.n_decoder_gru_layers == 2 && att == 256 && U == 256 && mem == 256 &&
+    const bool ws_image = c.n_decoder_gru_layers == 2 && att == 256 && U == 256 && mem == 256 &&
                           c.dec_prenet_units[0] == 256 && c.dec_prenet_units[1] == 128 && c.n_mels <= 256;
     if (ws_image) {
         o_wsw = p.alloc(decoder_ws_wimg_floats());
@@ -1734,6 +1734,7 @@ int tts_finalize_weights(tts_handle_t h) {
             hw.g_gw[l] = hb + o_dg[l].gates_wt; hw.g_gb[l] = hb + o_dg[l].gates_b;
             hw.g_cw[l] = hb + o_dg[l].cand_wt; hw.g_cb[l] = hb + o_dg[l].cand_b;
         }
+        hw.cudnn = cudnn ? 1 : 0;
         decoder_ws_pack(hw, p.host.data() + o_wsw, p.host.data() + o_wsb);
     }
 
@@ -2014,7 +2015,7 @@ static int decoder_impl(tts_handle_t h, const float* memory, int B, int Ts, int 
         if (ws_sync != h->pd_sync || clusters != h->pd_clusters)   // new buffer / new layout: the sticky status word starts clean
             HIPCHK(h, hipMemsetAsync(ws_sync + 64 * clusters + 1, 0, sizeof(unsigned), h->stream));
         HIPCHK(h, decoder_ws_enqueue(h->stream, h->dec, ws_scratch, yhist, memory, keys, B, Ts, n_steps, alignments, ws_sync,
-                                     h->cur_hold_flag, h->debug_hooks ? h->pd_debug_delay : 0));
+                                     h->cur_hold_flag, c.force_cudnn, h->debug_hooks ? h->pd_debug_delay : 0));
         h->pd_sync = ws_sync;
         h->pd_clusters = clusters;
         h->pd_used = true;

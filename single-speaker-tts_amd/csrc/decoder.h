@@ -109,22 +109,24 @@ hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, co
                                       int* hold_flag, int cudnn, int dbg_delay);
 
 // ---- weight-stationary persistent form (decoder_ws.hip, round 5): clusters of 16 workgroups x 32 utterances, every
-// workgroup's share of the weights resident in registers; TF GRUCell arithmetic and global attention only
-#define DEC_WS_NREG 172          // weight registers per lane
+// workgroup's share of the weights resident in registers; both GRU formulations, global attention only
+#define DEC_WS_NREG 176          // weight registers per lane (172 used by the GRUCell form, 176 by the CudnnCompatibleGRUCell form)
 #define DEC_WS_BIAS_SLOTS 10     // b1 folded | b1 (step 0) | b2 | attention GRU gates, candidate | (attention layer: none) | 2 x (gates, candidate)
 struct WsParams {
     const float* wimg; const float* bimg;
     const float *memory, *keys;                   // [B][Ts][256]
-    float* state;                                 // [clusters][5 x 32 x 256]: att | h_att | h_dec1 | h_dec2 | y, zeroed per call
+    float* state;                                 // [clusters][8 x 32 x 256]: att | h_att x 2 | h_dec1 x 2 | h_dec2 x 2 (by step parity) | y, zeroed per call
     float* rest;                                  // [clusters][p1 | r*h | ctx | y0 | p2]
     float* yhist;                                 // [B][n_steps][256]
     float* align;                                 // [n_steps][B][Ts] or null
     unsigned* counters; unsigned* resident; int* status; int* hold_flag;   // as PdParams
     int B, Ts, n_steps, dbg_delay;
+    int cudnn;                                    // CudnnCompatibleGRUCell arithmetic (the register image is packed for it)
 };
 struct DecWsHostWeights {                         // host pointers to the packed [N][K] matrices and biases of DecoderWeights
     const float *w1f, *b1f, *b1, *w2, *b2, *ag_w, *ag_b, *ac_w, *ac_b, *al_w;
     const float *g_gw[2], *g_gb[2], *g_cw[2], *g_cb[2];
+    int cudnn;                                    // CudnnCompatibleGRUCell: *g_w / *g_b are the [4U][K] / [4U] blocks r | u | hh | xi, *c_* unused
 };
 size_t decoder_ws_wimg_floats();
 size_t decoder_ws_bimg_floats();
@@ -136,6 +138,6 @@ hipError_t decoder_ws_configure();                // per device
 // `sync`: 64 * ceil(B / 32) + 2 unsigned words (counters, resident count, sticky status word)
 hipError_t decoder_ws_enqueue(hipStream_t s, const DecoderWeights& w, float* scratch, float* yhist, const float* memory,
                               const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync, int* hold_flag,
-                              int dbg_delay);
+                              int cudnn, int dbg_delay);
 
 }  // namespace tts

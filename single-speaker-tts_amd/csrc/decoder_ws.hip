@@ -50,12 +50,12 @@ namespace tts {
 #define WS_R0 0      // pre-net 1 (folded)        K 512, 1 tile : 16
 #define WS_R1 16     // pre-net 2                 K 256, 1 tile :  8
 #define WS_R2 24     // attention GRU gates       K 384, 2 tiles: 24
-#define WS_R3 48     // attention GRU candidate   K 384, 1 tile : 12
-#define WS_R5 60     // attention layer           K 512, 1 tile : 16
-#define WS_R6 76     // GRU 1 gates               K 512, 2 tiles: 32
-#define WS_R7 108    // GRU 1 candidate           K 512, 1 tile : 16
-#define WS_R8 124    // GRU 2 gates                             : 32
-#define WS_R9 156    // GRU 2 candidate                         : 16
+#define WS_R3 48     // attention GRU candidate   K 384, 1 tile : 12  (CudnnCompatibleGRUCell: x W_ci over 128 / h W_ch over 256: 16)
+#define WS_R5 64     // attention layer           K 512, 1 tile : 16
+#define WS_R6 80     // GRU 1 gates               K 512, 2 tiles: 32
+#define WS_R7 112    // GRU 1 candidate           K 512, 1 tile : 16
+#define WS_R8 128    // GRU 2 gates                             : 32
+#define WS_R9 160    // GRU 2 candidate                         : 16
 static_assert(WS_R9 + 16 == DEC_WS_NREG, "register image size");
 
 // LDS map (floats)
@@ -63,7 +63,8 @@ static_assert(WS_R9 + 16 == DEC_WS_NREG, "register image size");
 #define WS_OFF_RED (WS_M * 512)                             // [8 waves][2 row blocks][16][WS_RED_LD]
 #define WS_OFF_H (WS_OFF_RED + WS_NW * 2 * 16 * WS_RED_LD)  // [3 layers][32 rows][16 units]: this workgroup's cell states
 #define WS_OFF_U (WS_OFF_H + 3 * WS_M * 16)                 // [32][16] update gate
-#define WS_OFF_BIAS (WS_OFF_U + WS_M * 16)                  // [DEC_WS_BIAS_SLOTS][32]
+#define WS_OFF_R (WS_OFF_U + WS_M * 16)                     // [32][16] reset gate (CudnnCompatibleGRUCell form)
+#define WS_OFF_BIAS (WS_OFF_R + WS_M * 16)                  // [DEC_WS_BIAS_SLOTS][32]
 #define WS_OFF_CTRL (WS_OFF_BIAS + DEC_WS_BIAS_SLOTS * 32)
 #define WS_OFF_SC (WS_OFF_CTRL + 16)                        // [2][Ts padded] scores
 
@@ -71,7 +72,10 @@ size_t ws_lds_bytes(int Ts) { return ((size_t)WS_OFF_SC + 2 * (size_t)((Ts + 3) 
 
 // per-cluster buffers (floats): the zeroed state block, then the plain hand-off buffers
 #define WS_BUF (WS_M * WS_D)                                // one 256-unit vector of a cluster
-#define WS_STATE_FLOATS (5 * WS_BUF)                        // att | h_att | h_dec1 | h_dec2 | y (top layer output)
+// att | h_att x 2 | h_dec1 x 2 | h_dec2 x 2 | y (top layer output).  The cell states are double-buffered by step parity: in
+// the CudnnCompatibleGRUCell form a workgroup stores its slice of h' in the phase that staged h, while a peer that left the
+// wait a little later may still be staging it (decoder_persistent.hip, tests/test_gpu_cudnn_variant.py: the late stager)
+#define WS_STATE_FLOATS (8 * WS_BUF)
 #define WS_REST_FLOATS (4 * WS_BUF + WS_M * WS_P2)          // p1 | rh | ctx | y0 | p2
 
 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned ws_u32x4;
@@ -87,7 +91,7 @@ __device__ __forceinline__ void ws_st4(const __amdgpu_buffer_rsrc_t& rs, unsigne
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, v), rs, (int)byte_off, 0, 16);
 }
 
-enum WsEpi { WS_ACT = 0, WS_GATES = 1, WS_CAND = 2 };
+enum WsEpi { WS_ACT = 0, WS_GATES = 1, WS_CAND = 2, WS_CUDNN_RU = 3 };
 
 #ifdef WS_TIMELINE   // tools only: s_memrealtime stamps (100 MHz) of workgroup 0, thread 0 in step 100: [phase 0..9][8]
 __device__ unsigned long long ws_dbg[10 * 8];
@@ -171,6 +175,7 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
     float* red = lds + WS_OFF_RED;
     float* h_loc = lds + WS_OFF_H + ph.layer * (WS_M * 16);
     float* u_loc = lds + WS_OFF_U;
+    float* r_loc = lds + WS_OFF_R;
     const float* bias = lds + WS_OFF_BIAS + ph.bias_slot * 32;
     int* ctrl = reinterpret_cast<int*>(lds + WS_OFF_CTRL);
 
@@ -252,7 +257,13 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
         const unsigned ooff = (unsigned)((j * WS_M + row) * UBO + c4) * 4u;   // byte offset inside a cluster's buffer
         float* hl = h_loc + row * 16 + c4;
         float* ul = u_loc + row * 16 + c4;
-        if (EPI == WS_ACT) {
+        if (EPI == WS_CUDNN_RU) {   // CudnnCompatibleGRUCell: r and u stay in this workgroup, ws_phase_hx continues on the tile
+            float4 rr4, uu4;
+            rr4.x = sigmoidf_(v[0].x); rr4.y = sigmoidf_(v[0].y); rr4.z = sigmoidf_(v[0].z); rr4.w = sigmoidf_(v[0].w);
+            uu4.x = sigmoidf_(v[TILES - 1].x); uu4.y = sigmoidf_(v[TILES - 1].y); uu4.z = sigmoidf_(v[TILES - 1].z); uu4.w = sigmoidf_(v[TILES - 1].w);
+            *reinterpret_cast<float4*>(ul) = uu4;
+            *reinterpret_cast<float4*>(r_loc + row * 16 + c4) = rr4;
+        } else if (EPI == WS_ACT) {
             float4 o = v[0];
             o.x = apply_act(o.x, ACT); o.y = apply_act(o.y, ACT); o.z = apply_act(o.z, ACT); o.w = apply_act(o.w, ACT);
             ws_st4(ws_rsrc(ph.out), ooff, o);
@@ -284,8 +295,90 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
         }
         // (a plain yhist store drains with the others: one wait covers both)
         WS_STAMP(5)
-        ws_publish_wave(cnt, WS_ARRIVALS / (unsigned)(NT / 64));
+        if (EPI != WS_CUDNN_RU) ws_publish_wave(cnt, WS_ARRIVALS / (unsigned)(NT / 64));
         WS_STAMP(6)
+    }
+    if (EPI == WS_CUDNN_RU) __syncthreads();   // r / u are in LDS, the partial tiles may be overwritten (no hand-off here)
+}
+
+// CudnnCompatibleGRUCell (reference layers.py:560-577, model.py:226-227,257-259), second half of a cell on the tile its gates
+// phase staged -- no wait, no staging, one hand-off per cell: c = tanh(x W_ci + b_ci + r * (h W_ch + b_ch)), h' = u h + (1 - u) c.
+// Waves 0..3 multiply segment 0 (x, K0 columns) with W_ci, waves 4..7 segment 1 (h, 256 columns) with W_ch, four K slices each.
+template <int K0, int UB0, int ROFF>
+__device__ __forceinline__ void ws_phase_hx(const float (&w)[DEC_WS_NREG], const WsPhase& ph, float* lds, int j, int b0, int B,
+                                            unsigned* cnt) {
+    constexpr int CH0 = K0 / 64, CH1 = WS_D / 64;   // 16-deep chunks per wave: x part, h part
+    static_assert(K0 % 64 == 0 && CH0 <= CH1, "phase shape");
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));   // (see ws_phase)
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    float* As = lds + WS_OFF_AS;
+    float* red = lds + WS_OFF_RED;
+    float* h_loc = lds + WS_OFF_H + ph.layer * (WS_M * 16);
+    const float* bias = lds + WS_OFF_BIAS + ph.bias_slot * 32;
+    const int tile = wave >> 2, slice = wave & 3;           // tile 0: x W_ci, tile 1: h W_ch
+    const int kb = tile ? K0 + slice * (WS_D / 4) : slice * (K0 / 4);
+    const int nch = tile ? CH1 : CH0;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < CH1; ++c) {
+        if (c < nch) {   // wave-uniform
+            int rbs;
+            const int off = ws_a_off<K0, UB0>(kb + 16 * c, r, q, &rbs);
+            const float4 a0v = *reinterpret_cast<const float4*>(As + off);
+            const float4 a1v = *reinterpret_cast<const float4*>(As + off + rbs);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.x, w[ROFF + 4 * c + 0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.x, w[ROFF + 4 * c + 0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.y, w[ROFF + 4 * c + 1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.y, w[ROFF + 4 * c + 1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.z, w[ROFF + 4 * c + 2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.z, w[ROFF + 4 * c + 2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.w, w[ROFF + 4 * c + 3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.w, w[ROFF + 4 * c + 3], acc1, 0, 0, 0);
+        }
+    }
+    const int rslot = slice * 2 + tile;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        red[((rslot * 2 + 0) * 16 + q * 4 + i) * WS_RED_LD + r] = acc0[i];
+        red[((rslot * 2 + 1) * 16 + q * 4 + i) * WS_RED_LD + r] = acc1[i];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int row = tid >> 2, c4 = (tid & 3) * 4;
+        const int rb = row >> 4, rr = row & 15;
+        float4 v[2];   // [0] = x W_ci + b_ci, [1] = h W_ch + b_ch
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            v[g] = *reinterpret_cast<const float4*>(bias + g * 16 + c4);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const float4 t4 = *reinterpret_cast<const float4*>(red + (((sl * 2 + g) * 2 + rb) * 16 + rr) * WS_RED_LD + c4);
+                v[g].x += t4.x; v[g].y += t4.y; v[g].z += t4.z; v[g].w += t4.w;
+            }
+        }
+        const unsigned ooff = (unsigned)((j * WS_M + row) * 16 + c4) * 4u;
+        float* hl = h_loc + row * 16 + c4;
+        const float4 h4 = *reinterpret_cast<const float4*>(hl);
+        const float4 u4 = *reinterpret_cast<const float4*>(lds + WS_OFF_U + row * 16 + c4);
+        const float4 r4 = *reinterpret_cast<const float4*>(lds + WS_OFF_R + row * 16 + c4);
+        float4 hn;
+        hn.x = u4.x * h4.x + (1.0f - u4.x) * tanhf_(v[0].x + r4.x * v[1].x);
+        hn.y = u4.y * h4.y + (1.0f - u4.y) * tanhf_(v[0].y + r4.y * v[1].y);
+        hn.z = u4.z * h4.z + (1.0f - u4.z) * tanhf_(v[0].z + r4.z * v[1].z);
+        hn.w = u4.w * h4.w + (1.0f - u4.w) * tanhf_(v[0].w + r4.w * v[1].w);
+        *reinterpret_cast<float4*>(hl) = hn;
+        ws_st4(ws_rsrc(ph.out), ooff, hn);
+        if (ph.yout) {   // ResidualWrapper: y = x + h'
+            const float4 x4 = *reinterpret_cast<const float4*>(As + (j * WS_M + row) * 16 + c4);
+            hn.x += x4.x; hn.y += x4.y; hn.z += x4.z; hn.w += x4.w;
+            ws_st4(ws_rsrc(ph.yout), ooff, hn);
+            if (ph.yhist && b0 + row < B)
+                *reinterpret_cast<float4*>(ph.yhist + (size_t)(b0 + row) * ph.yld + j * 16 + c4) = hn;
+        }
+        ws_publish_wave(cnt, WS_ARRIVALS / 2u);
     }
 }
 
@@ -432,6 +525,7 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
         for (int k = t256; k < Ts; k += 256) align_t[(size_t)row * Ts + k] = sc[k] * inv;
 }
 
+template <bool CUDNN>
 __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -441,7 +535,7 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
     unsigned* cnt = p.counters + 64 * cluster;
     int* ctrl = reinterpret_cast<int*>(lds + WS_OFF_CTRL);
 
-    // ---- this wave's weights: 172 registers per lane, once, from the register-order image (decoder_ws_pack)
+    // ---- this wave's weights: up to 176 registers per lane, once, from the register-order image (decoder_ws_pack)
     float w[DEC_WS_NREG];
     {
         const float4* img = reinterpret_cast<const float4*>(p.wimg) + (size_t)(j * WS_NW + wave) * (DEC_WS_NREG / 4) * 64 + lane;
@@ -465,14 +559,19 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
     __syncthreads();
 
     float* st = p.state + (size_t)cluster * WS_STATE_FLOATS;
-    float* att = st, *h_att = st + WS_BUF, *h_d1 = st + 2 * WS_BUF, *h_d2 = st + 3 * WS_BUF, *ycur = st + 4 * WS_BUF;
+    float* att = st, *ycur = st + 7 * WS_BUF;
     float* rs = p.rest + (size_t)cluster * WS_REST_FLOATS;
     float* p1 = rs, *rh = rs + WS_BUF, *ctx = rs + 2 * WS_BUF, *y0 = rs + 3 * WS_BUF, *p2 = rs + 4 * WS_BUF;
     const int yld = p.n_steps * WS_D;
-    unsigned g = 0;   // phases completed by the cluster
+    unsigned g = 0;   // hand-offs completed by the cluster
     const unsigned per = WS_ARRIVALS * WS_W;
 
     for (int t = 0; t < p.n_steps; ++t) {
+        // cell states by step parity: step t reads [t & 1] and writes [(t + 1) & 1]
+        const int po = t & 1, pn = po ^ 1;
+        float* h_att_o = st + (1 + po) * WS_BUF, *h_att = st + (1 + pn) * WS_BUF;
+        float* h_d1_o = st + (3 + po) * WS_BUF, *h_d1 = st + (3 + pn) * WS_BUF;
+        float* h_d2_o = st + (5 + po) * WS_BUF, *h_d2 = st + (5 + pn) * WS_BUF;
         WsPhase ph;
         ph.yout = nullptr; ph.yhist = nullptr; ph.yld = yld; ph.layer = 0; ph.delay = p.dbg_delay;
         // PrenetWrapper on concat([x_t, attention_{t-1}]) (wrappers.py:122-124).  x_t = (y_{t-1} W_o + b_o)[-n_mels:] is folded
@@ -484,13 +583,22 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
         ph.a0 = p1; ph.a1 = nullptr; ph.out = p2; ph.bias_slot = 2; ph.target = per * g++;
         WS_TL_PHASE(t, 1)
         ws_phase<WS_D, 16, 0, 1, 8, WS_ACT, ACT_RELU, WS_R1>(w, ph, lds, j, b0, p.B, cnt, p.status);
-        // attention GRU (model.py:226-229): gates on [p2 ; h_att], candidate on [p2 ; r*h_att]; the new state is the query
-        ph.a0 = p2; ph.a1 = h_att; ph.out = rh; ph.bias_slot = 3; ph.target = per * g++;
-        WS_TL_PHASE(t, 2)
-        ws_phase<WS_P2, 8, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R2>(w, ph, lds, j, b0, p.B, cnt, p.status);
-        ph.a0 = p2; ph.a1 = rh; ph.out = h_att; ph.bias_slot = 4; ph.target = per * g++;
-        WS_TL_PHASE(t, 3)
-        ws_phase<WS_P2, 8, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R3, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        // attention GRU (model.py:226-229) on [p2 ; h_att]; the new state is the attention query
+        if (CUDNN) {   // one hand-off: r, u, then x W_ci and h W_ch on the same staged tile
+            ph.a0 = p2; ph.a1 = h_att_o; ph.out = nullptr; ph.bias_slot = 3; ph.target = per * g;
+            WS_TL_PHASE(t, 2)
+            ws_phase<WS_P2, 8, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R2>(w, ph, lds, j, b0, p.B, cnt, p.status);
+            ph.out = h_att; ph.bias_slot = 4; ++g;
+            WS_TL_PHASE(t, 3)
+            ws_phase_hx<WS_P2, 8, WS_R3>(w, ph, lds, j, b0, p.B, cnt);
+        } else {       // TF GRUCell: gates on [p2 ; h_att], a hop, candidate on [p2 ; r*h_att]
+            ph.a0 = p2; ph.a1 = h_att_o; ph.out = rh; ph.bias_slot = 3; ph.target = per * g++;
+            WS_TL_PHASE(t, 2)
+            ws_phase<WS_P2, 8, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R2>(w, ph, lds, j, b0, p.B, cnt, p.status);
+            ph.a0 = p2; ph.a1 = rh; ph.out = h_att; ph.bias_slot = 4; ph.target = per * g++;
+            WS_TL_PHASE(t, 3)
+            ws_phase<WS_P2, 8, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R3, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        }
         WS_TL_PHASE(t, 4)
         ws_attention(h_att, p.keys, p.memory, ctx, p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr, p.Ts, lds, j, b0, p.B,
                      cnt, per * g++, p.status);
@@ -500,25 +608,42 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
         ws_phase<WS_D, 16, WS_D, 1, 16, WS_ACT, ACT_NONE, WS_R5>(w, ph, lds, j, b0, p.B, cnt, p.status);
         // two ResidualWrapper(GRU cell) layers (model.py:254-269); the top one writes the y history
         ph.layer = 1;
-        ph.a0 = att; ph.a1 = h_d1; ph.out = rh; ph.bias_slot = 6; ph.target = per * g++;
-        WS_TL_PHASE(t, 6)
-        ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R6>(w, ph, lds, j, b0, p.B, cnt, p.status);
-        ph.a0 = att; ph.a1 = rh; ph.out = h_d1; ph.yout = y0; ph.bias_slot = 7; ph.target = per * g++;
-        WS_TL_PHASE(t, 7)
-        ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R7, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
-        ph.layer = 2; ph.yout = nullptr;
-        ph.a0 = y0; ph.a1 = h_d2; ph.out = rh; ph.bias_slot = 8; ph.target = per * g++;
-        WS_TL_PHASE(t, 8)
-        ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R8>(w, ph, lds, j, b0, p.B, cnt, p.status);
-        ph.a0 = y0; ph.a1 = rh; ph.out = h_d2; ph.yout = ycur; ph.yhist = p.yhist + (size_t)t * WS_D; ph.bias_slot = 9;
-        ph.target = per * g++;
-        WS_TL_PHASE(t, 9)
-        ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R9, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        if (CUDNN) {
+            ph.a0 = att; ph.a1 = h_d1_o; ph.out = nullptr; ph.bias_slot = 6; ph.target = per * g;
+            WS_TL_PHASE(t, 6)
+            ws_phase<WS_D, 16, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R6>(w, ph, lds, j, b0, p.B, cnt, p.status);
+            ph.out = h_d1; ph.yout = y0; ph.bias_slot = 7; ++g;
+            WS_TL_PHASE(t, 7)
+            ws_phase_hx<WS_D, 16, WS_R7>(w, ph, lds, j, b0, p.B, cnt);
+            ph.layer = 2; ph.yout = nullptr;
+            ph.a0 = y0; ph.a1 = h_d2_o; ph.out = nullptr; ph.bias_slot = 8; ph.target = per * g;
+            WS_TL_PHASE(t, 8)
+            ws_phase<WS_D, 16, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R8>(w, ph, lds, j, b0, p.B, cnt, p.status);
+            ph.out = h_d2; ph.yout = ycur; ph.yhist = p.yhist + (size_t)t * WS_D; ph.bias_slot = 9; ++g;
+            WS_TL_PHASE(t, 9)
+            ws_phase_hx<WS_D, 16, WS_R9>(w, ph, lds, j, b0, p.B, cnt);
+        } else {
+            ph.a0 = att; ph.a1 = h_d1_o; ph.out = rh; ph.bias_slot = 6; ph.target = per * g++;
+            WS_TL_PHASE(t, 6)
+            ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R6>(w, ph, lds, j, b0, p.B, cnt, p.status);
+            ph.a0 = att; ph.a1 = rh; ph.out = h_d1; ph.yout = y0; ph.bias_slot = 7; ph.target = per * g++;
+            WS_TL_PHASE(t, 7)
+            ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R7, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
+            ph.layer = 2; ph.yout = nullptr;
+            ph.a0 = y0; ph.a1 = h_d2_o; ph.out = rh; ph.bias_slot = 8; ph.target = per * g++;
+            WS_TL_PHASE(t, 8)
+            ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R8>(w, ph, lds, j, b0, p.B, cnt, p.status);
+            ph.a0 = y0; ph.a1 = rh; ph.out = h_d2; ph.yout = ycur; ph.yhist = p.yhist + (size_t)t * WS_D; ph.bias_slot = 9;
+            ph.target = per * g++;
+            WS_TL_PHASE(t, 9)
+            ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R9, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        }
     }
 }
 
 bool decoder_ws_supports(const DecoderWeights& w, int cudnn, int B, int Ts) {
-    return !cudnn && w.local_d == 0 && w.n_layers == 2 && w.att_units == WS_D && w.dec_units == WS_D && w.mem_units == WS_D &&
+    (void)cudnn;   // both GRU formulations (the register image is packed for the handle's)
+    return w.local_d == 0 && w.n_layers == 2 && w.att_units == WS_D && w.dec_units == WS_D && w.mem_units == WS_D &&
            w.prenet1_units == WS_D && w.prenet2_units == WS_P2 && w.n_mels <= WS_D && w.ws_wimg && w.ws_bimg && B >= 1 && Ts >= 1 &&
            ws_lds_bytes(Ts) <= 160 * 1024 - 64 && (size_t)B * Ts * WS_D * 4 < 0xFFFFFFF0ull;
 }
@@ -527,7 +652,10 @@ int decoder_ws_workgroups(int B) { return WS_W * ((B + WS_M - 1) / WS_M); }
 size_t decoder_ws_scratch_floats(int B) { return (size_t)((B + WS_M - 1) / WS_M) * (WS_STATE_FLOATS + WS_REST_FLOATS); }
 
 hipError_t decoder_ws_configure() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024 - 64);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024 - 64);
 }
 
@@ -537,25 +665,45 @@ hipError_t decoder_ws_configure() {
 // of a phase with TILES column tiles, W[gate * 256 + j * UBO + n][slice * KW + 16 c + 4 q + e] with gate = w % TILES,
 // slice = (w / TILES + SROT) % (8 / TILES) -- exactly what ws_phase multiplies the staged element (row, that k) with.  bimg [16][slots][32].
 void decoder_ws_pack(const DecWsHostWeights& hw, float* wimg, float* bimg) {
-    struct Ph { const float* Wt; int K, tiles, ubo, roff, srot; };   // srot: ws_phase's SROT (the candidate phases)
-    const Ph phs[9] = {
-        {hw.w1f, 512, 1, 16, WS_R0, 0}, {hw.w2, 256, 1, 8, WS_R1, 0}, {hw.ag_w, 384, 2, 16, WS_R2, 0}, {hw.ac_w, 384, 1, 16, WS_R3, 4},
-        {hw.al_w, 512, 1, 16, WS_R5, 0}, {hw.g_gw[0], 512, 2, 16, WS_R6, 0}, {hw.g_cw[0], 512, 1, 16, WS_R7, 4},
-        {hw.g_gw[1], 512, 2, 16, WS_R8, 0}, {hw.g_cw[1], 512, 1, 16, WS_R9, 4}};
+    struct Ph { const float* Wt; int K, tiles, ubo, roff, srot, k0; };
+    // srot: ws_phase's SROT (the candidate phases); k0 > 0: a CudnnCompatibleGRUCell's second half (ws_phase_hx) on the
+    // [4U][K] block r | u | hh | xi: waves 0..3 hold W_ci (rows 3U..) over the k0 input columns, waves 4..7 W_ch (rows 2U..)
+    // over the 256 state columns, four K slices each
+    const Ph gru_cell[9] = {
+        {hw.w1f, 512, 1, 16, WS_R0, 0, 0}, {hw.w2, 256, 1, 8, WS_R1, 0, 0}, {hw.ag_w, 384, 2, 16, WS_R2, 0, 0}, {hw.ac_w, 384, 1, 16, WS_R3, 4, 0},
+        {hw.al_w, 512, 1, 16, WS_R5, 0, 0}, {hw.g_gw[0], 512, 2, 16, WS_R6, 0, 0}, {hw.g_cw[0], 512, 1, 16, WS_R7, 4, 0},
+        {hw.g_gw[1], 512, 2, 16, WS_R8, 0, 0}, {hw.g_cw[1], 512, 1, 16, WS_R9, 4, 0}};
+    const Ph cudnn_cell[9] = {
+        {hw.w1f, 512, 1, 16, WS_R0, 0, 0}, {hw.w2, 256, 1, 8, WS_R1, 0, 0}, {hw.ag_w, 384, 2, 16, WS_R2, 0, 0}, {hw.ag_w, 384, 2, 16, WS_R3, 0, 128},
+        {hw.al_w, 512, 1, 16, WS_R5, 0, 0}, {hw.g_gw[0], 512, 2, 16, WS_R6, 0, 0}, {hw.g_gw[0], 512, 2, 16, WS_R7, 0, 256},
+        {hw.g_gw[1], 512, 2, 16, WS_R8, 0, 0}, {hw.g_gw[1], 512, 2, 16, WS_R9, 0, 256}};
+    const Ph* phs = hw.cudnn ? cudnn_cell : gru_cell;
     std::memset(wimg, 0, sizeof(float) * decoder_ws_wimg_floats());
     for (int j = 0; j < WS_W; ++j)
         for (int wv = 0; wv < WS_NW; ++wv) {
             float* base = wimg + (size_t)(j * WS_NW + wv) * DEC_WS_NREG * 64;
-            for (const Ph& ph : phs) {
-                const int ksl = WS_NW / ph.tiles, kw = ph.K / ksl, ch = kw / 16;
-                const int gate = wv % ph.tiles, slice = (wv / ph.tiles + ph.srot) % ksl;
+            for (int pi = 0; pi < 9; ++pi) {
+                const Ph& ph = phs[pi];
+                int ch, kb, row0;
+                if (ph.k0 > 0) {
+                    const int tile = wv >> 2, slice = wv & 3;
+                    ch = tile ? WS_D / 64 : ph.k0 / 64;
+                    kb = tile ? ph.k0 + slice * (WS_D / 4) : slice * (ph.k0 / 4);
+                    row0 = (tile ? 2 : 3) * WS_D + j * 16;
+                } else {
+                    const int ksl = WS_NW / ph.tiles, kw = ph.K / ksl;
+                    const int gate = wv % ph.tiles, slice = (wv / ph.tiles + ph.srot) % ksl;
+                    ch = kw / 16;
+                    kb = slice * kw;
+                    row0 = gate * WS_D + j * ph.ubo;
+                }
                 for (int c = 0; c < ch; ++c)
                     for (int e = 0; e < 4; ++e) {
                         const int reg = ph.roff + 4 * c + e;
                         for (int lane = 0; lane < 64; ++lane) {
                             const int n = lane & 15, q = lane >> 4;
-                            const int k = slice * kw + 16 * c + 4 * q + e;
-                            const float v = n < ph.ubo ? ph.Wt[(size_t)(gate * WS_D + j * ph.ubo + n) * ph.K + k] : 0.f;
+                            const int k = kb + 16 * c + 4 * q + e;
+                            const float v = n < ph.ubo ? ph.Wt[(size_t)(row0 + n) * ph.K + k] : 0.f;
                             base[((size_t)(reg >> 2) * 64 + lane) * 4 + (reg & 3)] = v;   // float4 i = reg / 4 of the lane
                         }
                     }
@@ -568,11 +716,19 @@ void decoder_ws_pack(const DecWsHostWeights& hw, float* wimg, float* bimg) {
             b[0 * 32 + n] = hw.b1f[j * 16 + n];
             b[1 * 32 + n] = hw.b1[j * 16 + n];
             if (n < 8) b[2 * 32 + n] = hw.b2[j * 8 + n];
-            b[3 * 32 + n] = hw.ag_b[j * 16 + n]; b[3 * 32 + 16 + n] = hw.ag_b[WS_D + j * 16 + n];
-            b[4 * 32 + n] = hw.ac_b[j * 16 + n];
-            for (int l = 0; l < 2; ++l) {
-                b[(6 + 2 * l) * 32 + n] = hw.g_gb[l][j * 16 + n]; b[(6 + 2 * l) * 32 + 16 + n] = hw.g_gb[l][WS_D + j * 16 + n];
-                b[(7 + 2 * l) * 32 + n] = hw.g_cb[l][j * 16 + n];
+            // a cell's gates slot: [r | u]; its second slot: the candidate's bias (GRUCell) or [b_ci | b_ch] (cudnn: rows 3U.. | 2U..)
+            const float* gb[3] = {hw.ag_b, hw.g_gb[0], hw.g_gb[1]};
+            const float* cb[3] = {hw.ac_b, hw.g_cb[0], hw.g_cb[1]};
+            const int slot[3] = {3, 6, 8};
+            for (int l = 0; l < 3; ++l) {
+                b[slot[l] * 32 + n] = gb[l][j * 16 + n];
+                b[slot[l] * 32 + 16 + n] = gb[l][WS_D + j * 16 + n];
+                if (hw.cudnn) {
+                    b[(slot[l] + 1) * 32 + n] = gb[l][3 * WS_D + j * 16 + n];
+                    b[(slot[l] + 1) * 32 + 16 + n] = gb[l][2 * WS_D + j * 16 + n];
+                } else {
+                    b[(slot[l] + 1) * 32 + n] = cb[l][j * 16 + n];
+                }
             }
         }
     }
@@ -584,7 +740,7 @@ size_t decoder_ws_bimg_floats() { return (size_t)WS_W * DEC_WS_BIAS_SLOTS * 32; 
 // first: zeroed here); `sync` = 64 unsigned per cluster + 1 (resident count) + 1 (sticky status word, see decoder_persistent.hip).
 hipError_t decoder_ws_enqueue(hipStream_t s, const DecoderWeights& w, float* scratch, float* yhist, const float* memory,
                               const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync, int* hold_flag,
-                              int dbg_delay) {
+                              int cudnn, int dbg_delay) {
     const int clusters = (B + WS_M - 1) / WS_M;
     hipError_t e;
     if ((e = hipMemsetAsync(scratch, 0, (size_t)clusters * WS_STATE_FLOATS * sizeof(float), s)) != hipSuccess) return e;
@@ -596,8 +752,9 @@ hipError_t decoder_ws_enqueue(hipStream_t s, const DecoderWeights& w, float* scr
     p.yhist = yhist; p.align = align;
     p.counters = sync; p.resident = sync + 64 * clusters; p.status = reinterpret_cast<int*>(sync + 64 * clusters + 1);
     p.hold_flag = hold_flag;
-    p.B = B; p.Ts = Ts; p.n_steps = n_steps; p.dbg_delay = dbg_delay;
-    hipLaunchKernelGGL(dec_ws_kernel, dim3(WS_W * clusters), dim3(WS_THREADS), ws_lds_bytes(Ts), s, p);
+    p.B = B; p.Ts = Ts; p.n_steps = n_steps; p.dbg_delay = dbg_delay; p.cudnn = cudnn;
+    if (cudnn) hipLaunchKernelGGL(dec_ws_kernel<true>, dim3(WS_W * clusters), dim3(WS_THREADS), ws_lds_bytes(Ts), s, p);
+    else hipLaunchKernelGGL(dec_ws_kernel<false>, dim3(WS_W * clusters), dim3(WS_THREADS), ws_lds_bytes(Ts), s, p);
 #ifdef WS_TIMELINE
     {
         (void)hipStreamSynchronize(s);

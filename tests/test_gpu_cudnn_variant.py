@@ -69,13 +69,21 @@ def test_cudnn_persistent_decoder(cudnn_setup, B, Ts, S):
     dev = eng.to_device(memory)
     try:
         eng.set_option('persistent_decoder', 2)
+        assert eng.decoder_kernel_choice(B, Ts, pipelined=False) == 2   # the weight-stationary kernel (round 5: both GRU forms)
         mel, al = eng.decoder_forward(dev, S)
         eng.synchronize()
         mel, al = mel.to_host(), al.to_host()
+        eng.set_option('pd_ws', 0)                                       # ... and decoder_persistent.hip
+        assert eng.decoder_kernel_choice(B, Ts, pipelined=False) == 1
+        mel_s, al_s = eng.decoder_forward(dev, S)
+        eng.synchronize()
+        assert rel_l2(mel_s.to_host(), ref_mel) < 1e-3 and np.abs(al_s.to_host() - ref_al).max() < 1e-4
+        eng.set_option('pd_ws', 1)
         eng.set_option('persistent_decoder', 0)
         mel0, al0 = eng.decoder_forward(dev, S)
         mel0, al0 = mel0.to_host(), al0.to_host()
     finally:
+        eng.set_option('pd_ws', 1)
         eng.set_option('persistent_decoder', 1)
     e_mel, e_al = rel_l2(mel, ref_mel), float(np.abs(al - ref_al).max())
     print('cudnn persistent decoder B={} Ts={} S={}: mel rel-L2 {:.3e}, align max-abs {:.3e}; vs launch path {:.3e}'.format(
