@@ -1909,8 +1909,8 @@ static int pd_kernel_for(tts_handle_t h, int B, int Ts, int budget) {
 // launch-per-layer decoder at every batch size -- on an idle chip the two are within 0.5 ms of each other (7.9 against 8.3 ms
 // at B = 1, 8.8 against 8.4 at 16 and more), and a choice by batch size would make an utterance's bits depend on how many
 // others share its call (tests/test_gpu_full_size.py::test_shard_invariance); decoder_persistent.hip (streamed weights:
-// CudnnCompatibleGRUCell, LocalLuongAttention) only under the pipeline with more than 48 utterances, where the step is
-// bound by post-net + Griffin-Lim (rounds 2-4).
+// LocalLuongAttention, or "pd_ws" = 0) only under the pipeline with more than 48 utterances, where the step is bound by
+// post-net + Griffin-Lim (rounds 2-4).
 static int pd_choice(tts_handle_t h, int B, int Ts, int budget, bool pipelined) {
     if (h->persistent_decoder <= 0) return 0;
     const int k = pd_kernel_for(h, B, Ts, budget);
