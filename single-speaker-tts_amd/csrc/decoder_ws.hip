@@ -136,6 +136,7 @@ struct WsPhase {
     float* yout;                        // WS_CAND with residual: y = x + h' (block format), or null
     float* yhist; int yld;              // ... and the same rows in the y history [B][n_steps][256] (+ t * 256), or null
     int bias_slot, layer;
+    const float* next1;                 // NEXT1: segment 1 of the phase after this one (a cluster's buffer, 256 units)
     unsigned target;
     int delay;                          // tests only: workgroup 3 stages late
 };
@@ -159,9 +160,16 @@ __device__ __forceinline__ int ws_a_off(int kk, int r, int q, int* rbs) {
 // cell's input x) -- it is not loaded again, and the waves whose K slice lies inside it run their MFMAs BEFORE the wait for
 // the cluster: they only need x and the weights.  SROT rotates the wave -> K slice map so that those are waves 4..7: waves
 // 0 and 1 come out of the previous phase's epilogue last, and lane 0 of wave 0 polls.
-template <int K0, int UB0, int K1, int TILES, int UBO, int EPI, int ACT, int ROFF, bool KEEP0 = false, int SROT = 0>
+// EARLY1: segment 1 of the tile is a value the cluster finished long ago -- a cell's own previous state under its gates, the
+// previous step's attention under pre-net 1 -- and was requested by the phase BEFORE this one (NEXT1 there: four 16-byte loads
+// per thread behind that phase's MFMAs, in flight during its epilogue and its publish, handed over in `pre`): it is written to
+// LDS at once, and the waves whose K slices lie inside it (4..7) run their MFMAs while lane 0 of wave 0 already polls for the
+// cluster; behind the wait only segment 0 is staged and only waves 0..3 multiply -- one wave per SIMD instead of two.
+template <int K0, int UB0, int K1, int TILES, int UBO, int EPI, int ACT, int ROFF, bool KEEP0 = false, int SROT = 0, bool EARLY1 = false,
+          bool NEXT1 = false>
 __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const WsPhase& ph, float* lds, int j, int b0, int B,
-                                         unsigned* cnt, int* status) {
+                                         unsigned* cnt, int* status, float4 (&pre)[4]) {
+    static_assert(!EARLY1 || (K1 == WS_D && !KEEP0), "EARLY1: a 256-unit second segment");
     constexpr int K = K0 + K1, KSL = WS_NW / TILES, KW = K / KSL, CH = KW / 16, NLD = K / 64, NLD0 = K0 / 64;
     static_assert(KW % 16 == 0 && K % 64 == 0 && K0 % 64 == 0 && K0 % 16 == 0, "phase shape");
     // (the thread index is made opaque per phase: every address below is a function of it alone, and hoisted out of the
@@ -200,9 +208,15 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.w, w[ROFF + 4 * c + 3], acc1, 0, 0, 0);
         }
     };
-    // KEEP0: the slices inside segment 0 need nothing the cluster is still working on (wave-uniform)
-    const bool early = KEEP0 && kb + KW <= K0;
+    // KEEP0: the slices inside segment 0 need nothing the cluster is still working on (wave-uniform); EARLY1: those inside
+    // segment 1, once it is in LDS
+    const bool early = (KEEP0 && kb + KW <= K0) || (EARLY1 && kb >= K0);
     WS_STAMP(0)
+    if (EARLY1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(As + 4 * (tid + WS_THREADS * (u + NLD0))) = pre[u];
+        __syncthreads();
+    }
     if (early) mma_slice();
 
     ws_wait(cnt, ph.target, status, ctrl);
@@ -213,15 +227,15 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
     // ---- stage the cluster's A tile: a linear copy of the (at most two) block-format buffers, all loads in flight together
     // (KEEP0: segment 0 is in place)
     {
-        constexpr int U0 = KEEP0 ? NLD0 : 0;
-        const __amdgpu_buffer_rsrc_t r0 = ws_rsrc(ph.a0), r1 = ws_rsrc(K1 > 0 ? ph.a1 : ph.a0);
+        constexpr int U0 = KEEP0 ? NLD0 : 0, U1 = EARLY1 ? NLD0 : NLD;
+        const __amdgpu_buffer_rsrc_t r0 = ws_rsrc(ph.a0), r1 = ws_rsrc((K1 > 0 && !EARLY1) ? ph.a1 : ph.a0);
         float4 sv[NLD];
 #pragma unroll
-        for (int u = U0; u < NLD; ++u)
+        for (int u = U0; u < U1; ++u)
             sv[u] = u < NLD0 ? ws_ld4(r0, (unsigned)(tid + WS_THREADS * u) * 16u)
                              : ws_ld4(r1, (unsigned)(tid + WS_THREADS * (u - NLD0)) * 16u);
 #pragma unroll
-        for (int u = U0; u < NLD; ++u) *reinterpret_cast<float4*>(As + 4 * (tid + WS_THREADS * u)) = sv[u];
+        for (int u = U0; u < U1; ++u) *reinterpret_cast<float4*>(As + 4 * (tid + WS_THREADS * u)) = sv[u];
         __syncthreads();
     }
     WS_STAMP(2)
@@ -236,6 +250,11 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
     }
     __syncthreads();
     WS_STAMP(4)
+    if (NEXT1) {   // the next phase's early segment: requested now, in flight during this phase's epilogue and publish
+        const __amdgpu_buffer_rsrc_t rn = ws_rsrc(ph.next1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pre[u] = ws_ld4(rn, (unsigned)(tid + WS_THREADS * u) * 16u);
+    }
 
     // ---- epilogue: thread e owns (row, 4 consecutive units) of every gate; the K slices are added in a fixed order.
     // Eight consecutive threads cover one 128-byte line of the output block (two rows x 16 units, four rows x 8).
@@ -304,9 +323,9 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
 // CudnnCompatibleGRUCell (reference layers.py:560-577, model.py:226-227,257-259), second half of a cell on the tile its gates
 // phase staged -- no wait, no staging, one hand-off per cell: c = tanh(x W_ci + b_ci + r * (h W_ch + b_ch)), h' = u h + (1 - u) c.
 // Waves 0..3 multiply segment 0 (x, K0 columns) with W_ci, waves 4..7 segment 1 (h, 256 columns) with W_ch, four K slices each.
-template <int K0, int UB0, int ROFF>
+template <int K0, int UB0, int ROFF, bool NEXT1 = false>
 __device__ __forceinline__ void ws_phase_hx(const float (&w)[DEC_WS_NREG], const WsPhase& ph, float* lds, int j, int b0, int B,
-                                            unsigned* cnt) {
+                                            unsigned* cnt, float4 (&pre)[4]) {
     constexpr int CH0 = K0 / 64, CH1 = WS_D / 64;   // 16-deep chunks per wave: x part, h part
     static_assert(K0 % 64 == 0 && CH0 <= CH1, "phase shape");
     int tid = threadIdx.x;
@@ -346,6 +365,11 @@ __device__ __forceinline__ void ws_phase_hx(const float (&w)[DEC_WS_NREG], const
         red[((rslot * 2 + 1) * 16 + q * 4 + i) * WS_RED_LD + r] = acc1[i];
     }
     __syncthreads();
+    if (NEXT1) {   // (see ws_phase)
+        const __amdgpu_buffer_rsrc_t rn = ws_rsrc(ph.next1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pre[u] = ws_ld4(rn, (unsigned)(tid + WS_THREADS * u) * 16u);
+    }
     if (tid < 128) {
         const int row = tid >> 2, c4 = (tid & 3) * 4;
         const int rb = row >> 4, rr = row & 15;
@@ -566,6 +590,13 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
     unsigned g = 0;   // hand-offs completed by the cluster
     const unsigned per = WS_ARRIVALS * WS_W;
 
+    // segment 1 of the first phase (the attention of "step -1": zeros), as every later step gets it from the phase before
+    float4 pre[4];
+    {
+        const __amdgpu_buffer_rsrc_t rn = ws_rsrc(att);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pre[u] = ws_ld4(rn, (unsigned)(tid + WS_THREADS * u) * 16u);
+    }
     for (int t = 0; t < p.n_steps; ++t) {
         // cell states by step parity: step t reads [t & 1] and writes [(t + 1) & 1]
         const int po = t & 1, pn = po ^ 1;
@@ -573,70 +604,70 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
         float* h_d1_o = st + (3 + po) * WS_BUF, *h_d1 = st + (3 + pn) * WS_BUF;
         float* h_d2_o = st + (5 + po) * WS_BUF, *h_d2 = st + (5 + pn) * WS_BUF;
         WsPhase ph;
-        ph.yout = nullptr; ph.yhist = nullptr; ph.yld = yld; ph.layer = 0; ph.delay = p.dbg_delay;
+        ph.yout = nullptr; ph.yhist = nullptr; ph.yld = yld; ph.layer = 0; ph.delay = p.dbg_delay; ph.next1 = nullptr;
         // PrenetWrapper on concat([x_t, attention_{t-1}]) (wrappers.py:122-124).  x_t = (y_{t-1} W_o + b_o)[-n_mels:] is folded
         // into the pre-net matrix (decoder.hip); x_0 = GO frame = zeros (helpers.py:108): y and attention are zero at step 0,
         // so only the bias differs there (the un-folded one)
         ph.a0 = ycur; ph.a1 = att; ph.out = p1; ph.bias_slot = t == 0 ? 1 : 0; ph.target = per * g++;
         WS_TL_PHASE(t, 0)
-        ws_phase<WS_D, 16, WS_D, 1, 16, WS_ACT, ACT_RELU, WS_R0>(w, ph, lds, j, b0, p.B, cnt, p.status);
-        ph.a0 = p1; ph.a1 = nullptr; ph.out = p2; ph.bias_slot = 2; ph.target = per * g++;
+        ws_phase<WS_D, 16, WS_D, 1, 16, WS_ACT, ACT_RELU, WS_R0, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+        ph.a0 = p1; ph.a1 = nullptr; ph.out = p2; ph.bias_slot = 2; ph.target = per * g++; ph.next1 = h_att_o;
         WS_TL_PHASE(t, 1)
-        ws_phase<WS_D, 16, 0, 1, 8, WS_ACT, ACT_RELU, WS_R1>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        ws_phase<WS_D, 16, 0, 1, 8, WS_ACT, ACT_RELU, WS_R1, false, 0, false, true>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
         // attention GRU (model.py:226-229) on [p2 ; h_att]; the new state is the attention query
         if (CUDNN) {   // one hand-off: r, u, then x W_ci and h W_ch on the same staged tile
             ph.a0 = p2; ph.a1 = h_att_o; ph.out = nullptr; ph.bias_slot = 3; ph.target = per * g;
             WS_TL_PHASE(t, 2)
-            ws_phase<WS_P2, 8, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R2>(w, ph, lds, j, b0, p.B, cnt, p.status);
+            ws_phase<WS_P2, 8, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R2, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
             ph.out = h_att; ph.bias_slot = 4; ++g;
             WS_TL_PHASE(t, 3)
-            ws_phase_hx<WS_P2, 8, WS_R3>(w, ph, lds, j, b0, p.B, cnt);
+            ws_phase_hx<WS_P2, 8, WS_R3, false>(w, ph, lds, j, b0, p.B, cnt, pre);
         } else {       // TF GRUCell: gates on [p2 ; h_att], a hop, candidate on [p2 ; r*h_att]
             ph.a0 = p2; ph.a1 = h_att_o; ph.out = rh; ph.bias_slot = 3; ph.target = per * g++;
             WS_TL_PHASE(t, 2)
-            ws_phase<WS_P2, 8, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R2>(w, ph, lds, j, b0, p.B, cnt, p.status);
+            ws_phase<WS_P2, 8, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R2, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
             ph.a0 = p2; ph.a1 = rh; ph.out = h_att; ph.bias_slot = 4; ph.target = per * g++;
             WS_TL_PHASE(t, 3)
-            ws_phase<WS_P2, 8, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R3, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
+            ws_phase<WS_P2, 8, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R3, true, 4, false, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
         }
         WS_TL_PHASE(t, 4)
         ws_attention(h_att, p.keys, p.memory, ctx, p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr, p.Ts, lds, j, b0, p.B,
                      cnt, per * g++, p.status);
         // attention_layer(concat([cell_output, context])), no bias
-        ph.a0 = h_att; ph.a1 = ctx; ph.out = att; ph.bias_slot = 5; ph.target = per * g++;
+        ph.a0 = h_att; ph.a1 = ctx; ph.out = att; ph.bias_slot = 5; ph.target = per * g++; ph.next1 = h_d1_o;
         WS_TL_PHASE(t, 5)
-        ws_phase<WS_D, 16, WS_D, 1, 16, WS_ACT, ACT_NONE, WS_R5>(w, ph, lds, j, b0, p.B, cnt, p.status);
+        ws_phase<WS_D, 16, WS_D, 1, 16, WS_ACT, ACT_NONE, WS_R5, false, 0, false, true>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
         // two ResidualWrapper(GRU cell) layers (model.py:254-269); the top one writes the y history
         ph.layer = 1;
         if (CUDNN) {
             ph.a0 = att; ph.a1 = h_d1_o; ph.out = nullptr; ph.bias_slot = 6; ph.target = per * g;
             WS_TL_PHASE(t, 6)
-            ws_phase<WS_D, 16, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R6>(w, ph, lds, j, b0, p.B, cnt, p.status);
-            ph.out = h_d1; ph.yout = y0; ph.bias_slot = 7; ++g;
+            ws_phase<WS_D, 16, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R6, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+            ph.out = h_d1; ph.yout = y0; ph.bias_slot = 7; ++g; ph.next1 = h_d2_o;
             WS_TL_PHASE(t, 7)
-            ws_phase_hx<WS_D, 16, WS_R7>(w, ph, lds, j, b0, p.B, cnt);
+            ws_phase_hx<WS_D, 16, WS_R7, true>(w, ph, lds, j, b0, p.B, cnt, pre);
             ph.layer = 2; ph.yout = nullptr;
             ph.a0 = y0; ph.a1 = h_d2_o; ph.out = nullptr; ph.bias_slot = 8; ph.target = per * g;
             WS_TL_PHASE(t, 8)
-            ws_phase<WS_D, 16, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R8>(w, ph, lds, j, b0, p.B, cnt, p.status);
-            ph.out = h_d2; ph.yout = ycur; ph.yhist = p.yhist + (size_t)t * WS_D; ph.bias_slot = 9; ++g;
+            ws_phase<WS_D, 16, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R8, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+            ph.out = h_d2; ph.yout = ycur; ph.yhist = p.yhist + (size_t)t * WS_D; ph.bias_slot = 9; ++g; ph.next1 = att;
             WS_TL_PHASE(t, 9)
-            ws_phase_hx<WS_D, 16, WS_R9>(w, ph, lds, j, b0, p.B, cnt);
+            ws_phase_hx<WS_D, 16, WS_R9, true>(w, ph, lds, j, b0, p.B, cnt, pre);
         } else {
             ph.a0 = att; ph.a1 = h_d1_o; ph.out = rh; ph.bias_slot = 6; ph.target = per * g++;
             WS_TL_PHASE(t, 6)
-            ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R6>(w, ph, lds, j, b0, p.B, cnt, p.status);
-            ph.a0 = att; ph.a1 = rh; ph.out = h_d1; ph.yout = y0; ph.bias_slot = 7; ph.target = per * g++;
+            ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R6, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+            ph.a0 = att; ph.a1 = rh; ph.out = h_d1; ph.yout = y0; ph.bias_slot = 7; ph.target = per * g++; ph.next1 = h_d2_o;
             WS_TL_PHASE(t, 7)
-            ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R7, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
+            ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R7, true, 4, false, true>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
             ph.layer = 2; ph.yout = nullptr;
             ph.a0 = y0; ph.a1 = h_d2_o; ph.out = rh; ph.bias_slot = 8; ph.target = per * g++;
             WS_TL_PHASE(t, 8)
-            ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R8>(w, ph, lds, j, b0, p.B, cnt, p.status);
+            ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R8, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
             ph.a0 = y0; ph.a1 = rh; ph.out = h_d2; ph.yout = ycur; ph.yhist = p.yhist + (size_t)t * WS_D; ph.bias_slot = 9;
-            ph.target = per * g++;
+            ph.target = per * g++; ph.next1 = att;
             WS_TL_PHASE(t, 9)
-            ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R9, true, 4>(w, ph, lds, j, b0, p.B, cnt, p.status);
+            ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R9, true, 4, false, true>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
         }
     }
 }
