@@ -108,7 +108,10 @@ int tts_set_stream(tts_handle_t h, void* hip_stream);
  * workgroup clusters, two decoder GRU layers, at most 64 utterances under the pipeline: 1 = under the call pipeline
  * with more than 48 utterances per call, where it pays (default), 2 = whenever the configuration allows, 0 = never; tts_synchronize reports TTS_ERR_HIP if one of its bounded waits timed out),
  * "gl_pair" (Griffin-Lim iterations per launch, 1..3, default 3: the spectrum passes from one iteration to the next in
- * registers; identical arithmetic per iteration), "fused_tail" (default 1: lifter + highway stack + GRU input
+ * registers; identical arithmetic per iteration), "gl_wide_from" (pipelined calls: the first Griffin-Lim launch that is cut
+ * for all compute units instead of all but "reserve_cus" -- the next call's decoder has left them by then; -1 (default) =
+ * from a model of the two durations, -2 = never, n >= 0 = launch n; a second overlap-add order: rounding only),
+ * "fused_tail" (default 1: lifter + highway stack + GRU input
  * projections of a CBHG as one launch; 0 = layer by layer), "enc_stream" (default 1: under the call pipeline with the
  * persistent decoder the encoder of a call runs on a stream of its own, one inter-Griffin-Lim gap ahead of its decoder, so
  * that the decoders of consecutive calls follow each other without a pause; tts_synthesize then waits on the HOST until the

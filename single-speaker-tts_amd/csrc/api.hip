@@ -143,6 +143,9 @@ struct tts_handle_s {
     // per compute unit has nothing to cover its pipeline fill and its epilogue) -- profiles/r05_experiment_gemm_presplit.txt
     int gemm_ps = 0;
     int gl_pair = 3;                 // Griffin-Lim iterations per launch (1..3) where nothing per-iteration is asked for
+    // First Griffin-Lim launch of a pipelined call that is cut for all compute units (gl_run, `wide_from`): -1 = by the rule
+    // in gl_wide_from() below, -2 = never, >= 0 = that launch index.
+    int gl_wide = -1;
     int n_cus_dev = 0;
     bool pd_configured = false;
     // Test / diagnostic hooks, all per handle and all inert unless the option "debug_hooks" has been set to 1 on THIS handle
@@ -1202,7 +1205,8 @@ int gl_prepare(tts_handle_t h, int T, int win, int hop, int n_fft) {
 // holds the initial phasors (written on another stream, ordered by the caller's events).
 int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t seed, int B, int T, int n_iter,
            int win, int hop, int n_fft, float* wav, float* mse, bool peak_normalize = false,
-           bool under_reservation = false, float2* const* phase_pair = nullptr, bool phase_ready = false) {
+           bool under_reservation = false, float2* const* phase_pair = nullptr, bool phase_ready = false,
+           int wide_from = -1) {
     int rc = gl_prepare(h, T, win, hop, n_fft);
     if (rc) return rc;
     const int F = 1 + n_fft / 2, FP = TTS_GL_FP;
@@ -1238,7 +1242,13 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     while (per_launch > 1 && gl_stream_ring_frames(win, hop, per_launch) <= 0) --per_launch;
     gl_plan_stream(p, n_cus - held > 16 ? n_cus - held : n_cus, per_launch, h->debug_hooks ? h->gl_runs : 0,
                    h->debug_hooks ? h->gl_run_len : 0);
-    const int nchunks = p.slots_per_utt;
+    // wide_from >= 0 (the pipelined tts_synthesize, see gl_wide_from there): launches from that index on are cut for ALL
+    // compute units -- the second stream's decoder has left its share by then.  A second cut, fixed per launch index, so
+    // the waveform's bits stay a function of the call's arguments and options alone.
+    GlParams pw = p;
+    const bool two_cuts = held > 0 && wide_from >= 0 && n_cus - held > 16 && !(h->debug_hooks && (h->gl_runs || h->gl_run_len));
+    if (two_cuts) gl_plan_stream(pw, n_cus, per_launch, 0, 0);
+    const int nchunks = std::max(p.slots_per_utt, pw.slots_per_utt);
     WS(h, "gl.mse_partial", float, (size_t)B * nchunks, msep);
     // One zeroed work counter per launch (the persistent workgroups draw their item ids from it): slots of a ring that is
     // zeroed ONCE; a launch takes the next slot and zeroes the slot of the launch before it on the stream, which is drained
@@ -1260,8 +1270,9 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     // a seeded start with at least one iteration needs no codes: the first launch makes the initial phasors itself
     const bool seed_in_kernel = !init_ft && n_iter >= 1;
     if (!phase_ready && !seed_in_kernel) HIPCHK(h, launch_phase_init(h->stream, init_ft, seed, ph0, B, F, T, FP));
-    p.F = F;
-    p.seed = seed;
+    p.F = pw.F = F;
+    p.seed = pw.seed = seed;
+    int launch_idx = 0, mse_chunks = p.slots_per_utt, peak_chunks = p.slots_per_utt;
     float2* cur = ph0;
     float2* nxt = ph1;
     const int free_cus = n_cus - held > 16 ? n_cus - held : n_cus;
@@ -1273,24 +1284,28 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
             const bool want_mse = mse && it == n_iter - 1;
             const int left = n_iter - (mse ? 1 : 0) - it;   // iterations that may share a launch
             const int n_stage = left >= per_launch ? per_launch : (left >= 1 ? left : 1);
-            p.phase_in = cur;
-            p.phase_out = nxt;
-            p.seeded = seed_in_kernel && it == 0;
-            p.mse_partial = want_mse ? msep : nullptr;
-            next_counter(p);
+            const bool wide = two_cuts && launch_idx >= wide_from;
+            GlParams& q = wide ? pw : p;
+            q.phase_in = cur;
+            q.phase_out = nxt;
+            q.seeded = seed_in_kernel && it == 0;
+            q.mse_partial = want_mse ? msep : nullptr;
+            if (want_mse) mse_chunks = q.slots_per_utt;
+            next_counter(q);
 #ifdef GL_TIMELINE   // tools only: stamps of workgroup 0 during the last launch
             WS(h, "gl.timeline", unsigned long long, 1024 + 64 * 16, tl);
             if (it + n_stage >= n_iter) {
                 HIPCHK(h, hipMemsetAsync(tl, 0, (1024 + 64 * 16) * sizeof(unsigned long long), h->stream));
-                p.dbg = tl;
+                p.dbg = pw.dbg = tl;
             }
 #endif
             // no more workgroups than the plan counts on: one that finds its compute unit taken (the call pipeline's other
             // stream) would start when the first of the others leaves, load its tables, find no item and only
             // lengthen the launch
-            HIPCHK(h, launch_gl_stream(h->stream, p, free_cus, 0, n_stage));
+            HIPCHK(h, launch_gl_stream(h->stream, q, wide ? n_cus : free_cus, 0, n_stage));
             std::swap(cur, nxt);
             it += n_stage;
+            ++launch_idx;
         }
 #ifdef GL_TIMELINE
         if (n_iter > 0) {
@@ -1322,31 +1337,34 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
             double mean = 0; for (double e : ends) mean += e; mean /= n ? n : 1;
             fprintf(stderr, "workgroups %zu: start last %.1f us; end min %.1f p10 %.1f median %.1f mean %.1f p90 %.1f max %.1f us\n", n,
                     starts.back(), ends.front(), ends[n / 10], ends[n / 2], mean, ends[n * 9 / 10], ends.back());
-            p.dbg = nullptr;
+            p.dbg = pw.dbg = nullptr;
         }
 #endif
     }
     if (mse) {
         if (n_iter > 0) {
-            HIPCHK(h, launch_gl_mse_reduce(h->stream, msep, B, nchunks, (float)((double)F * T), mse));
+            HIPCHK(h, launch_gl_mse_reduce(h->stream, msep, B, mse_chunks, (float)((double)F * T), mse));
         } else {
             HIPCHK(h, hipMemsetAsync(mse, 0, B * sizeof(float), h->stream));
         }
     }
     {
         ProfScope ps(h, ST_GL_FINAL, 1);
-        p.seeded = 0;
-        p.phase_in = cur;
-        p.phase_out = nullptr;
-        p.mse_partial = nullptr;
-        p.wav = wav;
-        p.peak_partial = peak_normalize ? msep : nullptr;   // the mse partials are consumed by now
-        next_counter(p);
-        HIPCHK(h, launch_gl_stream(h->stream, p, free_cus, 1, 1));
+        const bool wide = two_cuts && launch_idx >= wide_from;
+        GlParams& q = wide ? pw : p;
+        q.seeded = 0;
+        q.phase_in = cur;
+        q.phase_out = nullptr;
+        q.mse_partial = nullptr;
+        q.wav = wav;
+        q.peak_partial = peak_normalize ? msep : nullptr;   // the mse partials are consumed by now
+        next_counter(q);
+        HIPCHK(h, launch_gl_stream(h->stream, q, wide ? n_cus : free_cus, 1, 1));
+        peak_chunks = q.slots_per_utt;
     }
     // (dividing by the peak inside the final launch -- by the workgroup that finishes an utterance's last run -- was built
     //  and measured: +0.09 ms on that launch against the 0.05 ms of this kernel)
-    if (peak_normalize) HIPCHK(h, launch_peak_scale(h->stream, wav, B, hop * (T - 1), msep, nchunks));
+    if (peak_normalize) HIPCHK(h, launch_peak_scale(h->stream, wav, B, hop * (T - 1), msep, peak_chunks));
     return TTS_OK;
 }
 
@@ -1540,6 +1558,7 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
         h->persistent_decoder = value;
     }
     else if (!std::strcmp(key, "gl_pair")) h->gl_pair = value;
+    else if (!std::strcmp(key, "gl_wide_from")) h->gl_wide = value < -2 ? -2 : value;
     else if (!std::strcmp(key, "gemm_presplit")) h->gemm_presplit = value;
     else if (!std::strcmp(key, "gemm_ps")) h->gemm_ps = value;
     else if (!std::strcmp(key, "defer_proj")) {
@@ -1918,6 +1937,28 @@ static int pd_choice(tts_handle_t h, int B, int Ts, int budget, bool pipelined) 
     if (k == 2) return pipelined ? 2 : 0;
     if (k == 1) return (pipelined && B > 48) ? 1 : 0;
     return 0;
+}
+
+// The launch index from which a pipelined call's Griffin-Lim launches are cut for ALL compute units (gl_run, wide_from), or -1.
+// Under the pipeline the next call's decoder starts with this call's first Griffin-Lim launch (its encoder ran in the gap
+// before it) on the `reserve_cus` units that Griffin-Lim leaves free, and with the weight-stationary kernel it is done long
+// before the last launch (8.9 ms of 12.0 at 64 utterances x 1000 frames): the launches after that would leave 32 units idle.
+// Nothing orders the two streams here -- a 256-workgroup launch that finds units still taken runs as 224 workers and its
+// last 32 items wait, which costs time (a launch of 0.5 ms becomes 1.0) and never bits -- so the index comes from a model of
+// the two durations with half a launch of margin (measured at 64 x 1000 x 60 iterations, profiles/r05_experiment_gl_wide.txt:
+// never 14.74 ms per step, from launch 14: 14.79, 15: 14.49, 16: 14.48, 17: 14.52, 18: 14.56): decoder 0.045 ms per step (both GRU forms; measured 8.9 ms / 200
+// steps beside Griffin-Lim), Griffin-Lim 3.1 ns per frame-iteration on the reduced unit count (0.60 ms per launch of
+// 3 x 64 x 1000).  A function of the call's shape and the handle's options alone: the waveform's bits do not depend on timing.
+static int gl_wide_from(tts_handle_t h, int B, int Ts, int n_steps, int T, int n_iter) {
+    if (h->gl_wide == -2 || h->reserve_cus <= 0) return -1;
+    if (h->gl_wide >= 0) return h->gl_wide;
+    if (pd_choice(h, B, Ts, h->reserve_cus, true) != 2) return -1;   // the streamed-weights decoder outlasts Griffin-Lim
+    const int per_launch = h->gl_pair < 1 ? 1 : (h->gl_pair > 3 ? 3 : h->gl_pair);
+    const double launch_ms = 3.125e-6 * (double)B * T * per_launch;
+    const double dec_ms = 0.045 * n_steps + 0.1;
+    const int n_launches = (n_iter + per_launch - 1) / per_launch;
+    const int from = (int)std::ceil((dec_ms + 0.5 * launch_ms + 0.1) / launch_ms);
+    return from <= n_launches ? from : -1;
 }
 
 // keys = memory_layer(memory), no bias (LuongAttention, reference tacotron/model.py:205-223; the values stay the raw memory)
@@ -2530,7 +2571,8 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     }
     if (gl_streaming)
         rc = gl_run(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav, nullptr,
-                    sp->peak_normalize != 0, pipelined, phase_pair, phase_on_front);
+                    sp->peak_normalize != 0, pipelined, phase_pair, phase_on_front,
+                    pipelined ? gl_wide_from(h, B, Ts, sp->n_steps, T, sp->n_iter) : -1);
     else
         rc = gl_run_generic(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav, nullptr,
                             sp->peak_normalize != 0);

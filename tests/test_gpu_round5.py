@@ -7,7 +7,8 @@
   * apply_post_processing = False (reference tacotron/model.py:388-391): final Dense straight on the mel frames;
   * tts_synthesize for another power-of-two n_fft (reference tacotron/params/model.py:13-24 makes it a parameter);
   * a pipelined tts_synthesize with a non-default window / hop (the general Griffin-Lim kernels) beside the persistent decoder;
-  * the runnable entry of tacotron/inference.py:130-200 (reads the sentences file, writes {i+1}.wav)."""
+  * the runnable entry of tacotron/inference.py:130-200 (reads the sentences file, writes {i+1}.wav);
+  * the second Griffin-Lim cut of a pipelined call (its last launches on all compute units, option "gl_wide_from")."""
 import copy
 import os
 import subprocess
@@ -266,6 +267,40 @@ def test_pipelined_synthesize_with_the_general_griffin_lim_kernels(engine):
     finally:
         engine.set_option('pipeline', 1)
         engine.set_option('persistent_decoder', 1)
+
+
+@pytest.mark.parametrize('peak', [True, False])
+def test_wide_last_griffin_lim_launches(engine, peak):
+    """Option "gl_wide_from" (api.hip, gl_wide_from()): the launches of a pipelined call from that index on are cut for all
+    compute units instead of all but `reserve_cus`.  Another overlap-add order, so: equal to the one-cut form to the
+    reconstruction's own rounding, bit-identical call after call, and the peak normalisation / the sample count intact."""
+    B, S, n_iter = 24, 60, 12   # 300 frames, four launches of three iterations and the final one
+    batches = [bench_ids(B, 120, 500 + i) for i in range(3)]
+
+    def run(wide):
+        engine.set_option('gl_wide_from', wide)
+        dev = [engine.to_device(b) for b in batches]
+        outs = [engine.synthesize(d, S, REF_DB, MAX_DB, POWER, n_iter, WIN, HOP, seed=7 + i, peak_normalize=peak)
+                for i, d in enumerate(dev)]
+        engine.synchronize()
+        return [o['wav'].to_host() for o in outs]
+
+    try:
+        engine.set_option('pipeline', 1)
+        run(-2)   # shapes known: the calls below are pipelined from the first one
+        one_cut = run(-2)
+        for wide in (0, 2, 4):   # every launch, the last two and the final one, the final one alone
+            a = run(wide)
+            b = run(wide)
+            for i in range(len(batches)):
+                assert np.array_equal(a[i], b[i]), (wide, i)
+                assert np.isfinite(a[i]).all()
+                for r in range(B):
+                    assert rel_l2(a[i][r], one_cut[i][r]) < 1e-4 * n_iter, (wide, i, r)
+                if peak:
+                    assert np.allclose(np.abs(a[i]).max(axis=1), 1.0, atol=1e-6)
+    finally:
+        engine.set_option('gl_wide_from', -1)
 
 
 def test_inference_main_reads_the_sentences_file(weights, tmp_path):
