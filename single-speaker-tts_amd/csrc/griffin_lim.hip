@@ -1186,15 +1186,15 @@ void gl_plan_stream(GlParams& p, int n_workers, int n_stage, int force_runs, int
             double best_t = 1e300;
             const double fill = 6.0;   // frames' worth of time to fill and drain the stream of a run
             // What a run costs beyond its own frames: every stage of a launch starts halo + lag indices before the next
-            // one's first frame (gl_stream_kernel: n_idx = run_len + NST (halo + lag)) -- 27 indices per run at three
+            // one's first frame (gl_stream_kernel: n_idx = run_len + NST (halo + lag)) -- 24 indices per run (halo 4, lag 4 for the 1102 / 275 window) at three
             // iterations per launch, which is why the cut is made for the launch form the call will mostly use.
             const int wpad = (TTS_GL_NFFT - p.win) >> 1;
             const int lag = (halo + 1) * p.hop > 2 * (TTS_GL_NFFT / 2 - wpad) ? halo : halo + 1;
             const double over = (double)n_stage * (halo + lag) + fill;
             // Every run length that is a multiple of the eight waves is a candidate: n_full runs of L frames and one of the
             // rest per utterance.  (Only the equal cuts ceil(T / n) used to be: at T = 1000, 64 utterances, 224 workgroups
-            // they give two runs of 144 / 136 frames per workgroup = 2 x (144 + 27) indices; three runs of 296 frames and
-            // one of 112 per utterance give 192 workgroups one long run and 32 workgroups two short ones: 296 + 27.)
+            // they give two runs of 144 / 136 frames per workgroup = 2 x (144 + 24) indices; three runs of 296 frames and
+            // one of 112 per utterance give 192 workgroups one long run and 32 workgroups two short ones: 296 + 24 = 40 rounds of the eight waves.)
             for (int L = GL_NW; L < p.T + GL_NW; L += GL_NW) {
                 const int n_full = p.T / L, rem = p.T - n_full * L;
                 // list schedule, longest runs first: n_full * B items of cost cL, then B items of cost cR

@@ -220,8 +220,8 @@ def test_griffin_lim_item_plan_covers_every_frame_once(T, B, win, hop, workers):
     # same inputs -> same cut (the waveform's summation order depends on it)
     assert _gl_plan(T, B, win, hop, workers)[0] == classes
     if (T, B, win, hop, workers) == (1000, 64, 1102, 275, 224):
-        # three iterations per launch cost a run 27 indices beyond its frames: 192 workgroups take one run of 296 frames,
-        # 32 take two of 112 (the equal cut, two runs of 144 / 136 per workgroup, is 2 x 171 indices against 323)
+        # three iterations per launch cost a run 24 indices beyond its frames: 192 workgroups take one run of 296 frames,
+        # 32 take two of 112 (the equal cut, two runs of 144 / 136 per workgroup, is 2 x 168 indices against 320)
         assert classes == [(296, 3), (112, 1)]
 
 
