@@ -105,6 +105,7 @@ struct tts_handle_s {
     hipEvent_t ev_front_done = nullptr;
     hipEvent_t ev_post_done[2] = {nullptr, nullptr};   // post-net of the calls of even / odd parity
     bool post_pending[2] = {false, false};
+    bool gl_wide_used[2] = {false, false};   // the Griffin-Lim phase of that parity's last call ends in launches on ALL compute units
     hipEvent_t ev_gl_done[2] = {nullptr, nullptr};     // Griffin-Lim of the calls of even / odd parity (its phase buffers are free)
     bool gl_pending[2] = {false, false};
     bool front_pending = false;     // ev_front_done has been recorded at least once
@@ -1526,6 +1527,7 @@ int tts_set_stream(tts_handle_t h, void* s) {
     }
     h->post_pending[0] = h->post_pending[1] = false;
     h->gl_pending[0] = h->gl_pending[1] = false;
+    h->gl_wide_used[0] = h->gl_wide_used[1] = false;
     {
         int rc = graph_drop(h);
         if (rc) return rc;
@@ -1603,6 +1605,7 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
         if (rc) return rc;
         h->post_pending[0] = h->post_pending[1] = false;
         h->gl_pending[0] = h->gl_pending[1] = false;
+        h->gl_wide_used[0] = h->gl_wide_used[1] = false;
         h->pipeline = value;
     }
     else return fail(h, TTS_ERR_INVALID, std::string("unknown option ") + key);
@@ -2456,6 +2459,15 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         }
         if (mel_out && h->post_pending[parity ^ 1])
             HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_post_done[parity ^ 1], 0));
+        // The call two back ends its Griffin-Lim phase in launches cut for ALL compute units (gl_wide_from): this call's
+        // decoder must not take 32 of them away in the middle of those, so it starts behind the post-net of the call before
+        // it, i.e. behind that whole phase.  In the steady state this is where it starts anyway (its encoder runs beside that
+        // post-net); it matters while a burst of calls fills the pipeline, when the decoders -- 8.9 ms against 14.5 per call
+        // on the main stream -- would run ahead back to back (profiles/r05_step_timeline.txt before the gate: the wide
+        // launches of calls 2 and 3 took 0.77 instead of 0.55 ms).  Only then: where the decoder is the longer stage (small
+        // batches) there are no wide launches, and this wait would put the post-net into the decoders' chain.
+        if (h->gl_wide_used[parity] && h->post_pending[parity ^ 1])
+            HIPCHK(h, hipStreamWaitEvent(h->front, h->ev_post_done[parity ^ 1], 0));
         if (h->reserve_cus > 0 && !pd_path) {
             // reserve CUs for the front stream while the previous call's Griffin-Lim fills the rest
             hold_flag = h->hold_flags + (h->call_count++ & 1);
@@ -2569,10 +2581,11 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         HIPCHK(h, hipEventRecord(h->ev_post_done[parity], h->stream));
         h->post_pending[parity] = true;
     }
+    const int wide_from = (pipelined && gl_streaming) ? gl_wide_from(h, B, Ts, sp->n_steps, T, sp->n_iter) : -1;
+    h->gl_wide_used[parity] = wide_from >= 0;
     if (gl_streaming)
         rc = gl_run(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav, nullptr,
-                    sp->peak_normalize != 0, pipelined, phase_pair, phase_on_front,
-                    pipelined ? gl_wide_from(h, B, Ts, sp->n_steps, T, sp->n_iter) : -1);
+                    sp->peak_normalize != 0, pipelined, phase_pair, phase_on_front, wide_from);
     else
         rc = gl_run_generic(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav, nullptr,
                             sp->peak_normalize != 0);
