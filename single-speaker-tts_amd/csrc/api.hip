@@ -1948,7 +1948,7 @@ static int pd_choice(tts_handle_t h, int B, int Ts, int budget, bool pipelined) 
 // before the last launch (8.9 ms of 12.0 at 64 utterances x 1000 frames): the launches after that would leave 32 units idle.
 // Nothing orders the two streams here -- a 256-workgroup launch that finds units still taken runs as 224 workers and its
 // last 32 items wait, which costs time (a launch of 0.5 ms becomes 1.0) and never bits -- so the index comes from a model of
-// the two durations with half a launch of margin (measured at 64 x 1000 x 60 iterations, profiles/r05_experiment_gl_wide.txt:
+// the two durations with half a launch of margin (measured at 64 x 1000 x 60 iterations, GRUCell form, profiles/r05_experiment_gl_wide.txt:
 // never 14.74 ms per step, from launch 14: 14.79, 15: 14.49, 16: 14.48, 17: 14.52, 18: 14.56): decoder 0.045 ms per step (both GRU forms; measured 8.9 ms / 200
 // steps beside Griffin-Lim), Griffin-Lim 3.1 ns per frame-iteration on the reduced unit count (0.60 ms per launch of
 // 3 x 64 x 1000).  A function of the call's shape and the handle's options alone: the waveform's bits do not depend on timing.
@@ -1958,7 +1958,7 @@ static int gl_wide_from(tts_handle_t h, int B, int Ts, int n_steps, int T, int n
     if (pd_choice(h, B, Ts, h->reserve_cus, true) != 2) return -1;   // the streamed-weights decoder outlasts Griffin-Lim
     const int per_launch = h->gl_pair < 1 ? 1 : (h->gl_pair > 3 ? 3 : h->gl_pair);
     const double launch_ms = 3.125e-6 * (double)B * T * per_launch;
-    const double dec_ms = 0.045 * n_steps + 0.1;
+    const double dec_ms = (h->cfg.force_cudnn ? 0.038 : 0.045) * n_steps + 0.1;   // (seven hand-offs per step instead of ten: 6.9 ms alone)
     const int n_launches = (n_iter + per_launch - 1) / per_launch;
     const int from = (int)std::ceil((dec_ms + 0.5 * launch_ms + 0.1) / launch_ms);
     return from <= n_launches ? from : -1;
