@@ -1954,8 +1954,10 @@ static int pd_choice(tts_handle_t h, int B, int Ts, int budget, bool pipelined) 
 // 3 x 64 x 1000).  A function of the call's shape and the handle's options alone: the waveform's bits do not depend on timing.
 static int gl_wide_from(tts_handle_t h, int B, int Ts, int n_steps, int T, int n_iter) {
     if (h->gl_wide == -2 || h->reserve_cus <= 0) return -1;
-    if (h->gl_wide >= 0) return h->gl_wide;
-    if (pd_choice(h, B, Ts, h->reserve_cus, true) != 2) return -1;   // the streamed-weights decoder outlasts Griffin-Lim
+    const int pd = pd_choice(h, B, Ts, h->reserve_cus, true);
+    if (pd == 0) return -1;                    // launch-per-layer decoder: sleeper workgroups hold the units through the whole phase
+    if (h->gl_wide >= 0) return h->gl_wide;    // (tools: an explicit launch index)
+    if (pd != 2) return -1;                    // the streamed-weights decoder outlasts Griffin-Lim
     const int per_launch = h->gl_pair < 1 ? 1 : (h->gl_pair > 3 ? 3 : h->gl_pair);
     const double launch_ms = 3.125e-6 * (double)B * T * per_launch;
     const double dec_ms = (h->cfg.force_cudnn ? 0.038 : 0.045) * n_steps + 0.1;   // (seven hand-offs per step instead of ten: 6.9 ms alone)
