@@ -303,6 +303,36 @@ def test_wide_last_griffin_lim_launches(engine, peak):
         engine.set_option('gl_wide_from', -1)
 
 
+def test_wide_launches_between_calls_of_other_shapes(engine):
+    """The decoder of a call waits for the post-net of the call before it when the call two back ended its Griffin-Lim phase
+    in wide launches (api.hip, gl_wide_used): calls of two shapes alternate here, so the gate, the two cuts and the
+    workspaces of both shapes meet in one sequence.  Bit-identical run to run, equal to the one-cut form to rounding."""
+    shapes = [(24, 60), (6, 30), (24, 60), (6, 30), (24, 60), (24, 60)]
+    batches = [bench_ids(B, 100, 700 + i) for i, (B, _) in enumerate(shapes)]
+
+    def run(wide):
+        engine.set_option('gl_wide_from', wide)
+        dev = [engine.to_device(b) for b in batches]
+        outs = [engine.synthesize(d, S, REF_DB, MAX_DB, POWER, 9, WIN, HOP, seed=3 + i, want_mel=True)
+                for i, (d, (_, S)) in enumerate(zip(dev, shapes))]
+        engine.synchronize()
+        return [(o['wav'].to_host(), o['mel'].to_host()) for o in outs]
+
+    try:
+        engine.set_option('pipeline', 1)
+        run(-2)
+        one_cut = run(-2)
+        a = run(1)
+        b = run(1)
+        for i in range(len(shapes)):
+            assert np.array_equal(a[i][0], b[i][0]) and np.array_equal(a[i][1], b[i][1]), i
+            assert np.array_equal(a[i][1], one_cut[i][1]), i   # the network's output does not depend on the cut
+            for r in range(shapes[i][0]):
+                assert rel_l2(a[i][0][r], one_cut[i][0][r]) < 1e-4 * 9, (i, r)
+    finally:
+        engine.set_option('gl_wide_from', -1)
+
+
 def test_inference_main_reads_the_sentences_file(weights, tmp_path):
     """reference tacotron/inference.py:130-200 as a runnable entry: sentences file in, {i+1}.wav out (one per line, in order)."""
     I = pkg('tacotron.inference')
