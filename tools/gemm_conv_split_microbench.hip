@@ -185,15 +185,146 @@ __global__ __launch_bounds__(512) void conv_kernel(const unsigned char* __restri
             }
 }
 
+
+// the same for k steps of 16: [n tile][k step][plane][128 rows][2 slots of 8 bf16], slot = k half ^ ((row >> 3) & 1)
+__global__ void pack_w16_kernel(const float* __restrict__ W, int N, int K, unsigned short* __restrict__ img, int Npad) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int kch = K / 8;
+    if (idx >= (size_t)Npad * kch) return;
+    const int kc = (int)(idx % kch), n = (int)(idx / kch);
+    const int tile = n / TNR, rr = n % TNR, ks = kc >> 1, half = kc & 1;
+    const int slot = half ^ ((rr >> 3) & 1);
+    unsigned short out[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float v = n < N ? W[(size_t)n * K + kc * 8 + i] : 0.f;
+        unsigned h, m, l;
+        split3(v, h, m, l);
+        out[0][i] = (unsigned short)(h >> 16); out[1][i] = (unsigned short)(m >> 16); out[2][i] = (unsigned short)(l >> 16);
+    }
+    const size_t base = ((size_t)tile * (K / 16) + ks) * 3 * (TNR * 16);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<uint4*>(img + base + (size_t)p * TNR * 16 + rr * 16 + slot * 8) = *reinterpret_cast<const uint4*>(out[p]);
+}
+
+// k steps of 16: a stage is 3 planes x (256 + 128) rows x 32 B = 36 KB, FOUR stages in the ring, three in flight; the A planes by
+// all 512 threads (one 16-byte piece each per plane), the B planes by waves 0..3; counted vmcnt per wave, one raw barrier per step
 template <int MODE>
+__global__ __launch_bounds__(512) void conv16_kernel(const unsigned char* __restrict__ Apl, const unsigned char* __restrict__ Bimg,
+                                                     float* __restrict__ Cout, int Bn, int T, int C, int N, int taps) {
+    constexpr int AP = TMR * 32, BP = TNR * 32, AB = 3 * AP, ST = AB + 3 * BP, NB = 4;   // bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int M = Bn * T;
+    const int csteps = C / 16, ksteps = taps * csteps;
+    const size_t plane_stride = (size_t)Bn * (T + 2) * C * 2;
+    const int m_tile = blockIdx.x >> 1, n_tile = blockIdx.x & 1;
+    const int m0 = m_tile * TMR;
+    const unsigned char* a_src;
+    {
+        const int row = tid >> 1;
+        int m = m0 + row;
+        if (m >= M) m = M - 1;
+        const int b = m / T, t = m - b * T;
+        a_src = Apl + ((size_t)b * (T + 2) + t) * C * 2 + (((tid & 1) ^ ((row >> 3) & 1)) << 4);
+    }
+    const unsigned char* b_src = Bimg + (size_t)n_tile * ksteps * (3 * BP) + (tid & 255) * 16;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto glds16 = [&](const unsigned char* src, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    };
+    auto issue = [&](int s, int buf) {
+        const int tap = s / csteps, cs = s - tap * csteps;
+        const size_t aoff = (size_t)tap * C * 2 + (size_t)cs * 32;
+        const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + buf * ST + wave * 1024);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) glds16(a_src + p * plane_stride + aoff, d + p * AP);
+        if (wave < 4) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) glds16(b_src + (size_t)s * (3 * BP) + p * BP, d + AB + p * BP);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int ra = wm * 64 + blk * 32 + li, rb = wn * 64 + blk * 32 + li;
+        a_off[blk] = ra * 32 + ((lh ^ ((ra >> 3) & 1)) << 4);
+        b_off[blk] = AB + rb * 32 + ((lh ^ ((rb >> 3) & 1)) << 4);
+    }
+#pragma unroll
+    for (int s = 0; s < NB - 1; ++s)
+        if (s < ksteps) issue(s, s);
+    int buf = 0;
+    for (int s = 0; s < ksteps; ++s) {
+        const int later = (ksteps - 1 - s) < (NB - 2) ? (ksteps - 1 - s) : (NB - 2);
+        if (wave < 4) {
+            if (later >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (later >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (MODE != 1 && s + NB - 1 < ksteps) issue(s + NB - 1, (buf + NB - 1) & (NB - 1));
+        if (MODE != 2) {
+            const unsigned char* st = smem + buf * ST;
+            uint4 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    fa[blk][p] = *reinterpret_cast<const uint4*>(st + p * AP + a_off[blk]);
+                    fb[blk][p] = *reinterpret_cast<const uint4*>(st + p * BP + b_off[blk]);
+                }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+#define MMA(SA, SB)                                                                                              \
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[mb][SA]), \
+                                                                          __builtin_bit_cast(bf16x8_t, fb[nb][SB]), acc[mb][nb], 0, 0, 0);
+                    MMA(0, 2) MMA(2, 0) MMA(1, 1) MMA(0, 1) MMA(1, 0) MMA(0, 0)
+#undef MMA
+                }
+        }
+        buf = (buf + 1) & (NB - 1);
+    }
+    const int mw = m0 + wm * 64, nw = n_tile * TNR + wn * 64;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mw + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n = nw + nb * 32 + li;
+                if (m < M && n < N) Cout[(size_t)m * N + n] = acc[mb][nb][r];
+            }
+}
+
+template <int MODE, bool K16 = false>
 static void run(const unsigned char* Apl, const unsigned char* Bimg, float* dC, int B, int T, int C, int N, int taps,
                 const std::vector<float>& hX, const std::vector<float>& hW) {
     const int M = B * T, K = taps * C;
-    const size_t lds = 2 * STAGE_BYTES;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = K16 ? 4 * 36864 : 2 * STAGE_BYTES;
+    auto kern = K16 ? &conv16_kernel<MODE> : &conv_kernel<MODE>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = ((M + TMR - 1) / TMR) * 2;
     CK(hipMemset(dC, 0, (size_t)M * N * 4));
-    conv_kernel<MODE><<<grid, 512, lds>>>(Apl, Bimg, dC, B, T, C, N, taps);
+    kern<<<grid, 512, lds>>>(Apl, Bimg, dC, B, T, C, N, taps);
     CK(hipDeviceSynchronize());
     double num = 0, den = 0;
     if (MODE == 0) {
@@ -218,13 +349,13 @@ static void run(const unsigned char* Apl, const unsigned char* Bimg, float* dC, 
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 10;
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) conv_kernel<MODE><<<grid, 512, lds>>>(Apl, Bimg, dC, B, T, C, N, taps);
+    for (int i = 0; i < reps; ++i) kern<<<grid, 512, lds>>>(Apl, Bimg, dC, B, T, C, N, taps);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
     ms /= reps;
-    printf("B %d T %d C %d N %d taps %d  MODE %d: %8.1f us  %6.1f TFLOP/s f32-equivalent (%6.1f bf16 MFMA)  rel-L2 %.2e\n", B, T, C, N, taps, MODE,
+    printf("B %d T %d C %d N %d taps %d  %s MODE %d: %8.1f us  %6.1f TFLOP/s f32-equivalent (%6.1f bf16 MFMA)  rel-L2 %.2e\n", B, T, C, N, taps, K16 ? "k16 x 4 stages" : "k32 x 2 stages", MODE,
            ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, 12.0 * M * N * K / (ms * 1e-3) / 1e12, MODE == 0 ? std::sqrt(num / den) : 0.0);
 }
 
@@ -264,5 +395,13 @@ int main(int argc, char** argv) {
     run<0>(Apl, (const unsigned char*)iw, dC, B, T, C, N, taps, hX, hW);
     run<1>(Apl, (const unsigned char*)iw, dC, B, T, C, N, taps, hX, hW);
     run<2>(Apl, (const unsigned char*)iw, dC, B, T, C, N, taps, hX, hW);
+    {
+        const size_t nw = (size_t)Np * (K / 8);
+        pack_w16_kernel<<<(unsigned)((nw + 255) / 256), 256>>>(dW, N, K, iw, Np);
+        CK(hipDeviceSynchronize());
+    }
+    run<0, true>(Apl, (const unsigned char*)iw, dC, B, T, C, N, taps, hX, hW);
+    run<1, true>(Apl, (const unsigned char*)iw, dC, B, T, C, N, taps, hX, hW);
+    run<2, true>(Apl, (const unsigned char*)iw, dC, B, T, C, N, taps, hX, hW);
     return 0;
 }
