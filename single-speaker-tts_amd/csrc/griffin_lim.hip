@@ -568,6 +568,11 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
 #pragma unroll
         for (int c = 0; c < 16; ++c)
             if (WIN_CT && (c < c_lo || c > c_hi)) { wana[c][0] = wana[c][1] = wsyn[c][0] = wsyn[c][1] = 0.f; }
+        // the inverse transform's output is conj(z): the sign of the odd sample is in the window, so that the synthesis window
+        // is one packed multiply per pair (as `v * cmk(w0, -w1)` it was two scalar ones: the negation is not a source modifier
+        // the compiler forms on a packed operand)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) wsyn[c][1] = -wsyn[c][1];
     }
     __syncthreads();
     int item = __builtin_amdgcn_readfirstlane(ctrl[CT_SNEXT]);
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
     auto synth_window = [&](int t, cf (&v)[16]) __attribute__((always_inline)) {
         if (t >= halo && t + halo < p.T) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) v[c] = v[c] * cmk(wsyn[c][0], -wsyn[c][1]);
+            for (int c = 0; c < 16; ++c) v[c] = v[c] * cmk(wsyn[c][0], wsyn[c][1]);   // (wsyn[c][1] carries the conjugation's sign)
         } else {
             // frame near an utterance end: fewer overlapping neighbours, 1 / wss per sample (rare)
             const float* rwp = p.rwss + (size_t)t * hop + wpad;
@@ -939,8 +944,9 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
             }
             GLS_STAMP()   // 1: decoded, split
             GLS_URGENCY(i)
-            // the row is consumed.  NST == 1: request this wave's next one now (of this run, or the first of the next
-            // item).  NST == 2: the magnitude registers first take |S| of the frame that goes from stage A to stage B
+            // the row is consumed.  NST == 1: request this wave's next one now (of this run, or the first of the next item).
+            // NST > 1: the LAST stage requests it; the magnitude registers first take |S| of the frames that go from stage to
+            // stage, each requested where its stage starts (below)
 #define GLS_NEXT_ROW()                                                                                                   \
             if (i + GL_NW < n_idx) {                                                                                     \
                 GLS_LOAD_ROW(phb, magb, t + GL_NW)                                                                       \
@@ -950,14 +956,6 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
             }
             if (NST == 1) {
                 GLS_NEXT_ROW()
-            } else {
-                // (|S| of the frame that goes from this stage to the next: the magnitude registers are free until the next row is requested)
-                const int tq = t - lag < 0 ? 0 : (t - lag >= p.T ? p.T - 1 : t - lag);
-                const float* mrow_ = magb + (size_t)tq * p.FP;
-                const float* mlo_ = mrow_ + lane; const float* mhi_ = mrow_ + (MH - lane);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) gs[j] = GL_ROW(mlo_, mhi_, j);
-                nyq_s = mrow_[MH / 2];
             }
             if (valid) {
                 fft1024(v, ex, tw, lane);
@@ -992,6 +990,22 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
                 ring_k += ring_floats;
                 yb_k += halo * hop;
                 const bool valid_k = ik >= 0 && tk >= 0 && tk < p.T;
+                {
+                    // |S| of this stage's frame, requested where the stage starts (the forward transform covers the loads;
+                    // unconditional: a row that is not needed is one that exists).  ONE load site for every further stage --
+                    // round 6: requested at the end of the stage before, beside the last stage's request for the next row,
+                    // the two sites' registers met in a phi, the allocator gave this site temporaries and copied them into
+                    // place behind an `s_waitcnt vmcnt(1)` right after the loads (a whole memory round trip exposed per
+                    // iteration), and because those temporaries were transform registers as well, the compiler's waits for
+                    // "loads that may still write them" stood in the middle of the transforms and inside the overlap-add's
+                    // critical section: 190.5 -> 185.9 us per iteration alone (profiles/r06_experiment_gl_issue.txt)
+                    const int tq = tk < 0 ? 0 : (tk >= p.T ? p.T - 1 : tk);
+                    const float* mrow_ = magb + (size_t)tq * p.FP;
+                    const float* mlo_ = mrow_ + lane; const float* mhi_ = mrow_ + (MH - lane);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) gs[j] = GL_ROW(mlo_, mhi_, j);
+                    nyq_s = mrow_[MH / 2];
+                }
                 if (valid_k) {
                     int sm = s_prev - lag;
                     sm += sm < 0 ? R : 0;
@@ -1008,14 +1022,7 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) asm volatile("v_mov_b64 %0, 0" : "=v"(v[j]));   // (as in stage 0)
                 }
-                if (k + 1 < NST) {
-                    const int tq = tk - lag < 0 ? 0 : (tk - lag >= p.T ? p.T - 1 : tk - lag);
-                    const float* mrow_ = magb + (size_t)tq * p.FP;
-                    const float* mlo_ = mrow_ + lane; const float* mhi_ = mrow_ + (MH - lane);
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) gs[j] = GL_ROW(mlo_, mhi_, j);
-                    nyq_s = mrow_[MH / 2];
-                } else {
+                if (k + 1 == NST) {
                     GLS_NEXT_ROW()
                 }
                 if (ik >= 0) {
