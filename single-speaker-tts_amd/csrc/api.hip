@@ -55,6 +55,9 @@ struct ProfSpan {
 
 }  // namespace
 
+#ifndef TTS_USE_GRAPH_DEFAULT
+#define TTS_USE_GRAPH_DEFAULT 0   // (tools: -DTTS_USE_GRAPH_DEFAULT=1 builds a library whose handles replay the decoder graph)
+#endif
 struct tts_handle_s {
     tts_config_t cfg;
     int device = 0;
@@ -62,14 +65,16 @@ struct tts_handle_s {
     bool own_stream = false;
     std::string err;
     // Launch-per-layer decoder: replay the whole loop from one executable hipGraph instead of enqueueing its ~10 launches per
-    // step.  OFF by default since round 5: in a long-lived process (the whole GPU test suite in one interpreter: dozens of
-    // graphs instantiated and destroyed, buffers allocated and freed between replays) replays of a freshly instantiated
-    // graph returned wrong mel spectrograms -- garbage of 1e20...1e34 from step 0 on, or plausible values that differ in nearly
-    // every element -- in 2-5 of every 5 runs of the suite on MI355X / ROCm 7.2, serial or pipelined, also with the captured
-    // hipGraph_t kept alive beside the executable one and never two launches of it in flight; the same kernels enqueued
-    // directly were right every time, and the same sequence in a fresh process replays correctly.  The dependent launches
-    // cost ~5 us each either way; the host enqueues them in ~3.5 us each.
-    int use_graph = 0;
+    // step (9.30 against 9.42 ms for 200 steps at B = 64: the dependent launches are GPU-bound at ~4.7 us each).  OFF by default,
+    // and REFUSED on a HIP runtime older than the one the library was built and validated with (graph_runtime_ok below).
+    // Round 5 saw replays return wrong mel spectrograms "in a long-lived process"; round 6 found what that process had in
+    // common: it had imported torch before the library, so the library ran on PyTorch's BUNDLED libamdhip64 (HIP 7.0.51831, same
+    // soname) instead of /opt/rocm's 7.2.26015.  On that runtime a cached decoder graph replays wrongly after other work on the
+    // handle (tools/graph_probe.py --torch: 5 of 5, garbage of 1e10...1e33 or last-bit differences; whole suite green there with
+    // DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, i.e. without the runtime's pre-built AQL packets -- the graph's dec_gemm_kernel nodes use
+    // 16 bytes of scratch); the same binary and sequence are right on the 7.2 runtime, graph on, every time
+    // (profiles/r06_experiment_hipgraph.txt).
+    int use_graph = TTS_USE_GRAPH_DEFAULT;   // (a tools build with the default ON still checks the runtime: tts_create)
     int fused_tail = 1;          // CBHG: lifter + highway stack + GRU input projections as one launch (cbhg_tail.hip)
     bool tail_configured = false;
     int profile = 0;
@@ -237,11 +242,13 @@ struct tts_handle_s {
     hipEvent_t ev_graph_done = nullptr;
     bool graph_in_flight = false;
     hipGraph_t dec_graph_src = nullptr;   // the captured graph the executable one was instantiated from: kept alive with it
-    struct {
+    struct {   // everything the captured launches have baked in: shapes and EVERY pointer (decoder_impl)
         const void* memory = nullptr;
-        void* mel = nullptr;
+        const void* keys = nullptr;
         void* align = nullptr;
         int B = 0, Ts = 0, n_steps = 0;
+        DecoderScratch sc;
+        DecoderWeights w;
     } dec_key;
 
     // Griffin-Lim tables
@@ -1374,6 +1381,15 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
 // ======================================================================================== C ABI
 extern "C" {
 
+// Is the HIP runtime this PROCESS runs on at least the one the library was built with (major.minor)?  A host that loaded another
+// ROCm's libamdhip64 first (import torch: PyTorch bundles its own) serves the library with that one -- same soname.
+static bool graph_runtime_ok(int* have) {
+    int v = 0;
+    if (hipRuntimeGetVersion(&v) != hipSuccess) v = 0;
+    if (have) *have = v;
+    return v / 100000 >= HIP_VERSION / 100000;   // HIP_VERSION = major * 10^7 + minor * 10^5 + patch
+}
+
 const char* tts_version(void) { return "sstts_hip 0.1.0 (gfx950)"; }
 
 int tts_default_config(tts_config_t* c) {
@@ -1438,6 +1454,7 @@ int tts_create(const tts_config_t* cfg, int device_id, tts_handle_t* out) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus < 1) cus = 256;
         h->n_cus_dev = cus;
     }
+    if (h->use_graph && !graph_runtime_ok(nullptr)) h->use_graph = 0;
     build_manifest(h);
     *out = h;
     return TTS_OK;
@@ -1546,7 +1563,17 @@ int tts_set_stream(tts_handle_t h, void* s) {
 int tts_set_option(tts_handle_t h, const char* key, int value) {
     DeviceScope dev_scope(h);
     if (!h || !key) return TTS_ERR_INVALID;
-    if (!std::strcmp(key, "use_graph")) h->use_graph = value;
+    if (!std::strcmp(key, "use_graph")) {
+        int have = 0;
+        // (value 2 behind "debug_hooks": tools/graph_probe.py reproduces the problem on the other runtime with it)
+        if (value && !(value == 2 && h->debug_hooks) && !graph_runtime_ok(&have))
+            return fail(h, TTS_ERR_UNSUPPORTED,
+                        "use_graph: this process runs the library on HIP runtime " + std::to_string(have) + ", older than the " +
+                        std::to_string(HIP_VERSION) + " it was built with (a libamdhip64 loaded before the library, e.g. the one "
+                        "PyTorch bundles); hipGraph replays of the decoder are wrong there (csrc/api.hip, `use_graph`) -- the "
+                        "launches are enqueued directly instead");
+        h->use_graph = value;
+    }
     else if (!std::strcmp(key, "profile")) h->profile = value;
     else if (!std::strcmp(key, "fused_tail")) h->fused_tail = value;
     else if (!std::strcmp(key, "persistent_decoder")) {
@@ -1808,7 +1835,7 @@ int tts_finalize_weights(tts_handle_t h) {
     h->dense_wt = base + o_dw;
     h->dense_b = base + o_db;
     h->zeros = base + o_zero;
-    h->dec_key = {};
+    std::memset(&h->dec_key, 0, sizeof(h->dec_key));
     h->host_w.clear();   // the packed copy on device is the only one kept
     h->finalized = true;
     return TTS_OK;
@@ -2083,8 +2110,9 @@ static int decoder_impl(tts_handle_t h, const float* memory, int B, int Ts, int 
         HIPCHK(h, decoder_enqueue(h->stream, h->dec, sc, memory, keys, B, Ts, n_steps, alignments, c.force_cudnn));
     } else {
         auto& k = h->dec_key;
-        if (!h->dec_graph || k.memory != memory || k.align != alignments || k.B != B || k.Ts != Ts ||
-            k.n_steps != n_steps) {
+        // (the scratch and weight structs are plain pointers and ints, zeroed before they are filled: compared bytewise)
+        if (!h->dec_graph || k.memory != memory || k.keys != keys || k.align != alignments || k.B != B || k.Ts != Ts ||
+            k.n_steps != n_steps || std::memcmp(&k.sc, &sc, sizeof(sc)) != 0 || std::memcmp(&k.w, &h->dec, sizeof(h->dec)) != 0) {
             if ((rc = graph_drop(h))) return rc;
             hipGraph_t graph = nullptr;
             HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
@@ -2105,7 +2133,8 @@ static int decoder_impl(tts_handle_t h, const float* memory, int B, int Ts, int 
                 h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
                 return TTS_ERR_HIP;
             }
-            k.memory = memory; k.mel = nullptr; k.align = alignments; k.B = B; k.Ts = Ts; k.n_steps = n_steps;
+            k.memory = memory; k.keys = keys; k.align = alignments; k.B = B; k.Ts = Ts; k.n_steps = n_steps;
+            k.sc = sc; k.w = h->dec;
         }
         if ((rc = graph_quiesce(h))) return rc;   // (never two launches of one executable graph in flight)
         HIPCHK(h, hipGraphLaunch(h->dec_graph, h->stream));

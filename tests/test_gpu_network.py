@@ -3,6 +3,8 @@
 Tolerance: BASELINE.json's north star asks for spectrograms within 1e-3 rel-L2 of the CPU
 reference; stage intermediates are held to 1e-4 (fp32 MFMA vs fp64), final outputs to 1e-3.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -63,13 +65,20 @@ def test_decoder(engine, hparams, weights64, B, Ts, S):
 
 
 def test_decoder_graph_matches_eager(engine):
+    """Option "use_graph": the launch-per-layer decoder loop replayed from a cached hipGraph gives the bits of the directly
+    enqueued launches -- on the HIP runtime the library was built with.  A process that loaded an older libamdhip64 first (this
+    suite's collection imports torch, which bundles HIP 7.0) is refused the option: replays were wrong there (csrc/api.hip)."""
     rng = np.random.default_rng(7)
     memory = engine.to_device((rng.standard_normal((4, 21, 256))).astype(np.float32))
     engine.set_option('use_graph', 0)
     mel0, al0 = engine.decoder_forward(memory, 5)
     m0, a0 = mel0.to_host(), al0.to_host()
     try:
-        engine.set_option('use_graph', 1)   # (off by default since round 5: csrc/api.hip, `use_graph`)
+        try:
+            engine.set_option('use_graph', 1)
+        except pkg('_hip').TtsError as e:
+            assert e.code == pkg('_hip').TTS_ERR_UNSUPPORTED and 'HIP runtime' in str(e)
+            return
         mel1, al1 = engine.decoder_forward(memory, 5)
         # replay the cached graph into the same buffers
         engine.decoder_forward(memory, 5, mel=mel1, alignments=al1)
@@ -77,6 +86,20 @@ def test_decoder_graph_matches_eager(engine):
         assert np.array_equal(a0, al1.to_host())
     finally:
         engine.set_option('use_graph', 0)
+
+
+def test_decoder_graph_in_a_process_of_its_own():
+    """The sequence that showed the graph problem (a cached decoder graph replayed between calls of the persistent decoder,
+    serial and pipelined, after calls of another shape: tools/graph_probe.py), in a fresh interpreter that has NOT imported
+    torch -- i.e. on /opt/rocm's runtime, where the option is allowed: every graph call equals the directly enqueued one."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for prelude in (2, 3):
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'graph_probe.py'), '--reps', '3', '--prelude', str(prelude)],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:]
+        assert 'serial with use_graph=1: 0 of 3' in r.stdout and 'pipelined with use_graph=1: 0 of 3' in r.stdout, r.stdout[-2000:]
 
 
 @pytest.mark.parametrize('B,T', [(2, 15), (2, 20), (3, 100)])   # T % 3 = 0, 2, 1
