@@ -173,6 +173,9 @@ struct tts_handle_s {
     int pd_clusters = 0;
     int* cur_hold_flag = nullptr;    // set by tts_synthesize around its decoder call: the sleepers' flag
     int cur_cu_budget = 0;           // ... and the compute units the front stream may count on (0 = the whole chip)
+    bool dec_chip_idle = false;      // tts_synthesize: the main stream had nothing in flight when this call's decoder was enqueued
+    int pd_rows = 0;                 // tests ("pd_rows" behind "debug_hooks"): utterances per cluster of the weight-stationary decoder, 16 / 32
+    int pd_rows_used = 0;            // ... of the last launch
 
     // host-memory calls (tts_synthesize_host): pinned staging of the ids, device copies, pinned waveform buffers and the
     // device buffers they are copied from, one set per call in flight (ticket mod 3: the device pipeline holds three calls
@@ -1609,13 +1612,14 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     }
     else if (!std::strcmp(key, "debug_hooks")) h->debug_hooks = value;
     else if (!std::strcmp(key, "pd_debug_delay") || !std::strcmp(key, "gl_runs") || !std::strcmp(key, "gl_run_len") ||
-             !std::strcmp(key, "timeline") || !std::strcmp(key, "gl_workers")) {
+             !std::strcmp(key, "timeline") || !std::strcmp(key, "gl_workers") || !std::strcmp(key, "pd_rows")) {
         if (!h->debug_hooks && value != 0)
             return fail(h, TTS_ERR_INVALID, std::string(key) + ": a test hook; set the option \"debug_hooks\" to 1 on this handle first");
         if (!std::strcmp(key, "pd_debug_delay")) h->pd_debug_delay = value;
         else if (!std::strcmp(key, "gl_runs")) h->gl_runs = value;
         else if (!std::strcmp(key, "gl_run_len")) h->gl_run_len = value;
         else if (!std::strcmp(key, "gl_workers")) h->gl_workers = value;
+        else if (!std::strcmp(key, "pd_rows")) h->pd_rows = value;
         else h->timeline = value;
     }
     else if (!std::strcmp(key, "reserve_cus")) {
@@ -1952,19 +1956,20 @@ static int pd_kernel_for(tts_handle_t h, int B, int Ts, int budget) {
 }
 
 // ... and which one the option "persistent_decoder" picks for a call: 0 never; 2 whenever a kernel covers the configuration;
-// 1 (default) by what was measured (tools/pipeline_sweep.py, tools/latency_bench.py, round 5): the weight-stationary kernel
-// under the call pipeline at EVERY batch size (8.5 against 10.1 ms per call at B = 1, 9.6 against 13.7 at 32, 12.4 against
-// 16.4 at 48: the launch-per-layer decoder's ~2000 launches queue behind Griffin-Lim); unpipelined calls keep the
-// launch-per-layer decoder at every batch size -- on an idle chip the two are within 0.5 ms of each other (7.9 against 8.3 ms
-// at B = 1, 8.8 against 8.4 at 16 and more), and a choice by batch size would make an utterance's bits depend on how many
-// others share its call (tests/test_gpu_full_size.py::test_shard_invariance); decoder_persistent.hip (streamed weights:
-// LocalLuongAttention, or "pd_ws" = 0) only under the pipeline with more than 48 utterances, where the step is bound by
-// post-net + Griffin-Lim (rounds 2-4).
+// 1 (default) by what was measured (tools/pipeline_sweep.py, tools/latency_bench.py): the weight-stationary kernel wherever it
+// covers the configuration and its workgroups fit -- under the call pipeline at every batch size (round 5: 8.5 against 10.1 ms
+// per call at B = 1, 9.6 against 13.7 at 32, 12.4 against 16.4 at 48: the launch-per-layer decoder's ~2000 launches queue behind
+// Griffin-Lim) and, since round 6, for unpipelined calls as well: with 16 utterances per cluster (decoder_impl picks the rows)
+// the loop takes 6.15-6.2 ms at B = 1 ... 64 on an idle chip against 7.5 ... 9.4 ms launch per layer and 8.25 with 32 rows
+// (profiles/r06_stage_benchmarks.txt).  Its bits do not depend on the rows per cluster, on the batch size or on whether the
+// call was pipelined (tests/test_gpu_persistent.py, test_gpu_full_size.py::test_shard_invariance), so a call's spectrograms no
+// longer depend on the call history of the handle.  decoder_persistent.hip (streamed weights: LocalLuongAttention, or "pd_ws"
+// = 0) only under the pipeline with more than 48 utterances, where the step is bound by post-net + Griffin-Lim (rounds 2-4).
 static int pd_choice(tts_handle_t h, int B, int Ts, int budget, bool pipelined) {
     if (h->persistent_decoder <= 0) return 0;
     const int k = pd_kernel_for(h, B, Ts, budget);
     if (h->persistent_decoder >= 2) return k;
-    if (k == 2) return pipelined ? 2 : 0;
+    if (k == 2) return 2;
     if (k == 1) return (pipelined && B > 48) ? 1 : 0;
     return 0;
 }
@@ -2082,13 +2087,23 @@ static int decoder_impl(tts_handle_t h, const float* memory, int B, int Ts, int 
             HIPCHK(h, decoder_ws_configure());
             h->ws_configured = true;
         }
-        const int clusters = (B + 31) / 32;
-        WS(h, "dec.ws_scratch", float, decoder_ws_scratch_floats(B), ws_scratch);
+        // Utterances per cluster of 16 workgroups: 16 wherever the 16 * ceil(B / 16) compute units are there for the launch --
+        // every unpipelined call (the whole chip), pipelined calls of up to 2 x 16 utterances (the reserved units), and a
+        // pipelined call that finds the main stream idle (the first of a burst: nothing runs beside its decoder) -- else 32.
+        // The same bits either way (decoder_ws.hip), so the choice may look at the clock.
+        int rows = 32;
+        if (decoder_ws_workgroups(B, 16) <= pd_budget) rows = 16;
+        else if (h->cur_cu_budget > 0 && h->dec_chip_idle && decoder_ws_workgroups(B, 16) <= h->n_cus_dev) rows = 16;
+        if (h->debug_hooks && (h->pd_rows == 16 || h->pd_rows == 32) && decoder_ws_workgroups(B, h->pd_rows) <= h->n_cus_dev)
+            rows = h->pd_rows;   // (tests: "pd_rows")
+        const int clusters = decoder_ws_clusters(B, 16);   // layout of the sync words: that of the form with more clusters
+        WS(h, "dec.ws_scratch", float, std::max(decoder_ws_scratch_floats(B, 16), decoder_ws_scratch_floats(B, 32)), ws_scratch);
         WS(h, "dec.ws_sync", unsigned, (size_t)64 * clusters + 2, ws_sync);
         if (ws_sync != h->pd_sync || clusters != h->pd_clusters)   // new buffer / new layout: the sticky status word starts clean
             HIPCHK(h, hipMemsetAsync(ws_sync + 64 * clusters + 1, 0, sizeof(unsigned), h->stream));
         HIPCHK(h, decoder_ws_enqueue(h->stream, h->dec, ws_scratch, yhist, memory, keys, B, Ts, n_steps, alignments, ws_sync,
-                                     h->cur_hold_flag, c.force_cudnn, h->debug_hooks ? h->pd_debug_delay : 0));
+                                     h->cur_hold_flag, c.force_cudnn, h->debug_hooks ? h->pd_debug_delay : 0, rows, clusters));
+        h->pd_rows_used = rows;
         h->pd_sync = ws_sync;
         h->pd_clusters = clusters;
         h->pd_used = true;
@@ -2560,6 +2575,9 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     }
     h->cur_hold_flag = hold_flag;
     h->cur_cu_budget = (pipelined && h->reserve_cus > 0) ? h->reserve_cus : 0;
+    // nothing in flight on the main stream: no post-net, no Griffin-Lim runs beside this call's decoder (the first call of a
+    // burst) -- the weight-stationary decoder may then spread over twice the compute units (decoder_impl; the same bits)
+    h->dec_chip_idle = pipelined && hipStreamQuery(main_stream) == hipSuccess;
     h->defer_projection = pipelined && h->defer_proj;
     h->defer_parity = parity;
     h->has_pending_proj = false;
@@ -2573,6 +2591,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     h->defer_projection = false;
     h->cur_hold_flag = nullptr;
     h->cur_cu_budget = 0;
+    h->dec_chip_idle = false;
     h->stream = main_stream;
     if (!rc && !pipelined && h->front) {
         if (!h->ev_serial_done) HIPCHK(h, hipEventCreateWithFlags(&h->ev_serial_done, hipEventDisableTiming));

@@ -132,12 +132,15 @@ size_t decoder_ws_wimg_floats();
 size_t decoder_ws_bimg_floats();
 void decoder_ws_pack(const DecWsHostWeights& hw, float* wimg, float* bimg);
 bool decoder_ws_supports(const DecoderWeights& w, int cudnn, int B, int Ts);
-int decoder_ws_workgroups(int B);                 // compute units the launch needs all to itself
-size_t decoder_ws_scratch_floats(int B);
+// rows = utterances per cluster of 16 workgroups: 32 (round 5) or 16 (round 6: twice the compute units, ~0.8 of the time; the
+// same bits per utterance)
+int decoder_ws_workgroups(int B, int rows = 32);  // compute units the launch needs all to itself
+int decoder_ws_clusters(int B, int rows = 32);
+size_t decoder_ws_scratch_floats(int B, int rows = 32);
 hipError_t decoder_ws_configure();                // per device
-// `sync`: 64 * ceil(B / 32) + 2 unsigned words (counters, resident count, sticky status word)
+// `sync`: 64 * max(clusters, sync_clusters) + 2 unsigned words (counters, resident count, sticky status word)
 hipError_t decoder_ws_enqueue(hipStream_t s, const DecoderWeights& w, float* scratch, float* yhist, const float* memory,
                               const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync, int* hold_flag,
-                              int cudnn, int dbg_delay);
+                              int cudnn, int dbg_delay, int rows = 32, int sync_clusters = 0);
 
 }  // namespace tts

@@ -32,7 +32,6 @@
 namespace tts {
 
 #define WS_W 16
-#define WS_M 32
 #define WS_NW 8
 #define WS_THREADS (WS_NW * 64)
 #define WS_D 256
@@ -58,25 +57,30 @@ namespace tts {
 #define WS_R9 160    // GRU 2 candidate                         : 16
 static_assert(WS_R9 + 16 == DEC_WS_NREG, "register image size");
 
-// LDS map (floats)
-#define WS_OFF_AS 0                                         // staged A tile, block format: 32 rows x <= 512 k
-#define WS_OFF_RED (WS_M * 512)                             // [8 waves][2 row blocks][16][WS_RED_LD]
-#define WS_OFF_H (WS_OFF_RED + WS_NW * 2 * 16 * WS_RED_LD)  // [3 layers][32 rows][16 units]: this workgroup's cell states
-#define WS_OFF_U (WS_OFF_H + 3 * WS_M * 16)                 // [32][16] update gate
-#define WS_OFF_R (WS_OFF_U + WS_M * 16)                     // [32][16] reset gate (CudnnCompatibleGRUCell form)
-#define WS_OFF_BIAS (WS_OFF_R + WS_M * 16)                  // [DEC_WS_BIAS_SLOTS][32]
-#define WS_OFF_CTRL (WS_OFF_BIAS + DEC_WS_BIAS_SLOTS * 32)
-#define WS_OFF_SC (WS_OFF_CTRL + 16)                        // [2][Ts padded] scores
+// Rows (utterances) per cluster, M: 32 (two 16-row blocks per wave: the form of round 5, 16 compute units per 32 utterances --
+// what fits the call pipeline's 32 reserved units at B = 64) or 16 (round 6: one 16-row block per wave, twice the compute units
+// per utterance and about 0.8 of the time per phase -- staging, MFMA and reduction halve, the waits and the drain do not -- for
+// calls that have the chip to themselves).  A row's arithmetic does not see M: the same K slices in the same order, the same
+// four waves per attention row, MFMA rows are independent -- the two forms give the same bits (tests/test_gpu_persistent.py).
+// LDS map (floats) for M rows
+#define WS_OFF_AS 0                                               // staged A tile, block format: M rows x <= 512 k
+#define WS_OFF_RED(M) ((M) * 512)                                 // [8 waves][M / 16 row blocks][16][WS_RED_LD]
+#define WS_OFF_H(M) (WS_OFF_RED(M) + WS_NW * ((M) / 16) * 16 * WS_RED_LD)   // [3 layers][M rows][16 units]: this workgroup's cell states
+#define WS_OFF_U(M) (WS_OFF_H(M) + 3 * (M) * 16)                  // [M][16] update gate
+#define WS_OFF_R(M) (WS_OFF_U(M) + (M) * 16)                      // [M][16] reset gate (CudnnCompatibleGRUCell form)
+#define WS_OFF_BIAS(M) (WS_OFF_R(M) + (M) * 16)                   // [DEC_WS_BIAS_SLOTS][32]
+#define WS_OFF_CTRL(M) (WS_OFF_BIAS(M) + DEC_WS_BIAS_SLOTS * 32)
+#define WS_OFF_SC(M) (WS_OFF_CTRL(M) + 16)                        // [2][Ts padded] scores
 
-size_t ws_lds_bytes(int Ts) { return ((size_t)WS_OFF_SC + 2 * (size_t)((Ts + 3) & ~3)) * sizeof(float); }
+size_t ws_lds_bytes(int Ts, int M) { return ((size_t)WS_OFF_SC(M) + 2 * (size_t)((Ts + 3) & ~3)) * sizeof(float); }
 
 // per-cluster buffers (floats): the zeroed state block, then the plain hand-off buffers
-#define WS_BUF (WS_M * WS_D)                                // one 256-unit vector of a cluster
+#define WS_BUF(M) ((M) * WS_D)                                    // one 256-unit vector of a cluster
 // att | h_att x 2 | h_dec1 x 2 | h_dec2 x 2 | y (top layer output).  The cell states are double-buffered by step parity: in
 // the CudnnCompatibleGRUCell form a workgroup stores its slice of h' in the phase that staged h, while a peer that left the
 // wait a little later may still be staging it (decoder_persistent.hip, tests/test_gpu_cudnn_variant.py: the late stager)
-#define WS_STATE_FLOATS (8 * WS_BUF)
-#define WS_REST_FLOATS (4 * WS_BUF + WS_M * WS_P2)          // p1 | rh | ctx | y0 | p2
+#define WS_STATE_FLOATS(M) (8 * WS_BUF(M))
+#define WS_REST_FLOATS(M) (4 * WS_BUF(M) + (M) * WS_P2)          // p1 | rh | ctx | y0 | p2
 
 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned ws_u32x4;
 
@@ -143,15 +147,15 @@ struct WsPhase {
 
 // LDS offset (floats) of element (row r of row block 0, k = kk + 4 q) of the staged tile, kk a multiple of 16; the
 // distance to row block 1 in *rbs.  Segment 0 holds K0 columns in blocks of UB0 units per producer, segment 1 blocks of 16.
-template <int K0, int UB0>
+template <int M, int K0, int UB0>
 __device__ __forceinline__ int ws_a_off(int kk, int r, int q, int* rbs) {
     if (kk < K0) {
-        if (UB0 == 16) { *rbs = 256; return (kk >> 4) * (WS_M * 16) + r * 16 + 4 * q; }
+        if (UB0 == 16) { *rbs = 256; return (kk >> 4) * (M * 16) + r * 16 + 4 * q; }
         *rbs = 128;
-        return ((kk >> 3) + (q >> 1)) * (WS_M * 8) + r * 8 + 4 * (q & 1);
+        return ((kk >> 3) + (q >> 1)) * (M * 8) + r * 8 + 4 * (q & 1);
     }
     *rbs = 256;
-    return WS_M * K0 + ((kk - K0) >> 4) * (WS_M * 16) + r * 16 + 4 * q;
+    return M * K0 + ((kk - K0) >> 4) * (M * 16) + r * 16 + 4 * q;
 }
 
 // One GEMM-shaped phase: out[32 rows][this workgroup's UBO units (x TILES gates)] = epi([a0 | a1] . W^T + bias), the
@@ -165,13 +169,17 @@ __device__ __forceinline__ int ws_a_off(int kk, int r, int q, int* rbs) {
 // per thread behind that phase's MFMAs, in flight during its epilogue and its publish, handed over in `pre`): it is written to
 // LDS at once, and the waves whose K slices lie inside it (4..7) run their MFMAs while lane 0 of wave 0 already polls for the
 // cluster; behind the wait only segment 0 is staged and only waves 0..3 multiply -- one wave per SIMD instead of two.
-template <int K0, int UB0, int K1, int TILES, int UBO, int EPI, int ACT, int ROFF, bool KEEP0 = false, int SROT = 0, bool EARLY1 = false,
+template <int M, int K0, int UB0, int K1, int TILES, int UBO, int EPI, int ACT, int ROFF, bool KEEP0 = false, int SROT = 0, bool EARLY1 = false,
           bool NEXT1 = false>
 __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const WsPhase& ph, float* lds, int j, int b0, int B,
                                          unsigned* cnt, int* status, float4 (&pre)[4]) {
     static_assert(!EARLY1 || (K1 == WS_D && !KEEP0), "EARLY1: a 256-unit second segment");
-    constexpr int K = K0 + K1, KSL = WS_NW / TILES, KW = K / KSL, CH = KW / 16, NLD = K / 64, NLD0 = K0 / 64;
-    static_assert(KW % 16 == 0 && K % 64 == 0 && K0 % 64 == 0 && K0 % 16 == 0, "phase shape");
+    static_assert(M == 32 || M == 16, "rows per cluster");
+    constexpr int RB = M / 16;                       // 16-row blocks per wave
+    constexpr int PRE = WS_D * M / 4 / WS_THREADS;   // 16-byte pieces per thread of a 256-unit buffer (the early segment)
+    // 16-byte pieces per thread of the whole staged tile / of its segment 0
+    constexpr int K = K0 + K1, KSL = WS_NW / TILES, KW = K / KSL, CH = KW / 16, NLD = K * M / 4 / WS_THREADS, NLD0 = K0 * M / 4 / WS_THREADS;
+    static_assert(KW % 16 == 0 && (K * M) % (4 * WS_THREADS) == 0 && (K0 * M) % (4 * WS_THREADS) == 0 && K0 % 16 == 0, "phase shape");
     // (the thread index is made opaque per phase: every address below is a function of it alone, and hoisted out of the
     //  step loop for all nine phases at once those addresses -- not the weights -- were what the register allocator spilled)
     int tid = threadIdx.x;
@@ -180,14 +188,14 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     float* As = lds + WS_OFF_AS;
-    float* red = lds + WS_OFF_RED;
-    float* h_loc = lds + WS_OFF_H + ph.layer * (WS_M * 16);
-    float* u_loc = lds + WS_OFF_U;
-    float* r_loc = lds + WS_OFF_R;
-    const float* bias = lds + WS_OFF_BIAS + ph.bias_slot * 32;
-    int* ctrl = reinterpret_cast<int*>(lds + WS_OFF_CTRL);
+    float* red = lds + WS_OFF_RED(M);
+    float* h_loc = lds + WS_OFF_H(M) + ph.layer * (M * 16);
+    float* u_loc = lds + WS_OFF_U(M);
+    float* r_loc = lds + WS_OFF_R(M);
+    const float* bias = lds + WS_OFF_BIAS(M) + ph.bias_slot * 32;
+    int* ctrl = reinterpret_cast<int*>(lds + WS_OFF_CTRL(M));
 
-    // ---- this wave's K slice of one 16-column tile, both 16-row blocks
+    // ---- this wave's K slice of one 16-column tile, every 16-row block of the cluster (two for M = 32, one for 16)
     const int tile = wave % TILES, slice = (wave / TILES + SROT) % KSL;
     const int kb = slice * KW;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -195,17 +203,24 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             int rbs;
-            const int off = ws_a_off<K0, UB0>(kb + 16 * c, r, q, &rbs);
+            const int off = ws_a_off<M, K0, UB0>(kb + 16 * c, r, q, &rbs);
             const float4 a0v = *reinterpret_cast<const float4*>(As + off);
-            const float4 a1v = *reinterpret_cast<const float4*>(As + off + rbs);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.x, w[ROFF + 4 * c + 0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.x, w[ROFF + 4 * c + 0], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.y, w[ROFF + 4 * c + 1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.y, w[ROFF + 4 * c + 1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.z, w[ROFF + 4 * c + 2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.z, w[ROFF + 4 * c + 2], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.w, w[ROFF + 4 * c + 3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.w, w[ROFF + 4 * c + 3], acc1, 0, 0, 0);
+            if (RB == 2) {
+                const float4 a1v = *reinterpret_cast<const float4*>(As + off + rbs);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.x, w[ROFF + 4 * c + 0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.x, w[ROFF + 4 * c + 0], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.y, w[ROFF + 4 * c + 1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.y, w[ROFF + 4 * c + 1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.z, w[ROFF + 4 * c + 2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.z, w[ROFF + 4 * c + 2], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.w, w[ROFF + 4 * c + 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.w, w[ROFF + 4 * c + 3], acc1, 0, 0, 0);
+            } else {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.x, w[ROFF + 4 * c + 0], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.y, w[ROFF + 4 * c + 1], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.z, w[ROFF + 4 * c + 2], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.w, w[ROFF + 4 * c + 3], acc0, 0, 0, 0);
+            }
         }
     };
     // KEEP0: the slices inside segment 0 need nothing the cluster is still working on (wave-uniform); EARLY1: those inside
@@ -214,7 +229,7 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
     WS_STAMP(0)
     if (EARLY1) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(As + 4 * (tid + WS_THREADS * (u + NLD0))) = pre[u];
+        for (int u = 0; u < PRE; ++u) *reinterpret_cast<float4*>(As + 4 * (tid + WS_THREADS * (u + NLD0))) = pre[u];
         __syncthreads();
     }
     if (early) mma_slice();
@@ -245,20 +260,20 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
     const int rslot = slice * TILES + tile;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        red[((rslot * 2 + 0) * 16 + q * 4 + i) * WS_RED_LD + r] = acc0[i];
-        red[((rslot * 2 + 1) * 16 + q * 4 + i) * WS_RED_LD + r] = acc1[i];
+        red[((rslot * RB + 0) * 16 + q * 4 + i) * WS_RED_LD + r] = acc0[i];
+        if (RB == 2) red[((rslot * RB + 1) * 16 + q * 4 + i) * WS_RED_LD + r] = acc1[i];
     }
     __syncthreads();
     WS_STAMP(4)
     if (NEXT1) {   // the next phase's early segment: requested now, in flight during this phase's epilogue and publish
         const __amdgpu_buffer_rsrc_t rn = ws_rsrc(ph.next1);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pre[u] = ws_ld4(rn, (unsigned)(tid + WS_THREADS * u) * 16u);
+        for (int u = 0; u < PRE; ++u) pre[u] = ws_ld4(rn, (unsigned)(tid + WS_THREADS * u) * 16u);
     }
 
     // ---- epilogue: thread e owns (row, 4 consecutive units) of every gate; the K slices are added in a fixed order.
     // Eight consecutive threads cover one 128-byte line of the output block (two rows x 16 units, four rows x 8).
-    constexpr int NT = WS_M * UBO / 4;             // 128 threads (two waves) or 64
+    constexpr int NT = M * UBO / 4;                // 128 threads (two waves), 64 or (M = 16, pre-net 2) 32
     if (tid < NT) {
         const int row = UBO == 16 ? tid >> 2 : tid >> 1;
         const int c4 = UBO == 16 ? (tid & 3) * 4 : (tid & 1) * 4;
@@ -269,11 +284,11 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
             v[g] = *reinterpret_cast<const float4*>(bias + g * 16 + c4);
 #pragma unroll
             for (int s = 0; s < KSL; ++s) {
-                const float4 t4 = *reinterpret_cast<const float4*>(red + (((s * TILES + g) * 2 + rb) * 16 + rr) * WS_RED_LD + c4);
+                const float4 t4 = *reinterpret_cast<const float4*>(red + (((s * TILES + g) * RB + rb) * 16 + rr) * WS_RED_LD + c4);
                 v[g].x += t4.x; v[g].y += t4.y; v[g].z += t4.z; v[g].w += t4.w;
             }
         }
-        const unsigned ooff = (unsigned)((j * WS_M + row) * UBO + c4) * 4u;   // byte offset inside a cluster's buffer
+        const unsigned ooff = (unsigned)((j * M + row) * UBO + c4) * 4u;   // byte offset inside a cluster's buffer
         float* hl = h_loc + row * 16 + c4;
         float* ul = u_loc + row * 16 + c4;
         if (EPI == WS_CUDNN_RU) {   // CudnnCompatibleGRUCell: r and u stay in this workgroup, ws_phase_hx continues on the tile
@@ -305,7 +320,7 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
             *reinterpret_cast<float4*>(hl) = hn;
             ws_st4(ws_rsrc(ph.out), ooff, hn);
             if (ph.yout) {   // ResidualWrapper: y = x + h'; x = this workgroup's units of segment 0 of the staged tile
-                const float4 x4 = *reinterpret_cast<const float4*>(As + (j * WS_M + row) * 16 + c4);
+                const float4 x4 = *reinterpret_cast<const float4*>(As + (j * M + row) * 16 + c4);
                 hn.x += x4.x; hn.y += x4.y; hn.z += x4.z; hn.w += x4.w;
                 ws_st4(ws_rsrc(ph.yout), ooff, hn);
                 if (ph.yhist && b0 + row < B)   // (read by the deferred output projection after the launch: a plain store)
@@ -314,7 +329,7 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
         }
         // (a plain yhist store drains with the others: one wait covers both)
         WS_STAMP(5)
-        if (EPI != WS_CUDNN_RU) ws_publish_wave(cnt, WS_ARRIVALS / (unsigned)(NT / 64));
+        if (EPI != WS_CUDNN_RU) ws_publish_wave(cnt, WS_ARRIVALS / (unsigned)(NT >= 64 ? NT / 64 : 1));
         WS_STAMP(6)
     }
     if (EPI == WS_CUDNN_RU) __syncthreads();   // r / u are in LDS, the partial tiles may be overwritten (no hand-off here)
@@ -323,9 +338,10 @@ __device__ __forceinline__ void ws_phase(const float (&w)[DEC_WS_NREG], const Ws
 // CudnnCompatibleGRUCell (reference layers.py:560-577, model.py:226-227,257-259), second half of a cell on the tile its gates
 // phase staged -- no wait, no staging, one hand-off per cell: c = tanh(x W_ci + b_ci + r * (h W_ch + b_ch)), h' = u h + (1 - u) c.
 // Waves 0..3 multiply segment 0 (x, K0 columns) with W_ci, waves 4..7 segment 1 (h, 256 columns) with W_ch, four K slices each.
-template <int K0, int UB0, int ROFF, bool NEXT1 = false>
+template <int M, int K0, int UB0, int ROFF, bool NEXT1 = false>
 __device__ __forceinline__ void ws_phase_hx(const float (&w)[DEC_WS_NREG], const WsPhase& ph, float* lds, int j, int b0, int B,
                                             unsigned* cnt, float4 (&pre)[4]) {
+    constexpr int RB = M / 16, PRE = WS_D * M / 4 / WS_THREADS;
     constexpr int CH0 = K0 / 64, CH1 = WS_D / 64;   // 16-deep chunks per wave: x part, h part
     static_assert(K0 % 64 == 0 && CH0 <= CH1, "phase shape");
     int tid = threadIdx.x;
@@ -334,9 +350,9 @@ __device__ __forceinline__ void ws_phase_hx(const float (&w)[DEC_WS_NREG], const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     float* As = lds + WS_OFF_AS;
-    float* red = lds + WS_OFF_RED;
-    float* h_loc = lds + WS_OFF_H + ph.layer * (WS_M * 16);
-    const float* bias = lds + WS_OFF_BIAS + ph.bias_slot * 32;
+    float* red = lds + WS_OFF_RED(M);
+    float* h_loc = lds + WS_OFF_H(M) + ph.layer * (M * 16);
+    const float* bias = lds + WS_OFF_BIAS(M) + ph.bias_slot * 32;
     const int tile = wave >> 2, slice = wave & 3;           // tile 0: x W_ci, tile 1: h W_ch
     const int kb = tile ? K0 + slice * (WS_D / 4) : slice * (K0 / 4);
     const int nch = tile ? CH1 : CH0;
@@ -345,32 +361,39 @@ __device__ __forceinline__ void ws_phase_hx(const float (&w)[DEC_WS_NREG], const
     for (int c = 0; c < CH1; ++c) {
         if (c < nch) {   // wave-uniform
             int rbs;
-            const int off = ws_a_off<K0, UB0>(kb + 16 * c, r, q, &rbs);
+            const int off = ws_a_off<M, K0, UB0>(kb + 16 * c, r, q, &rbs);
             const float4 a0v = *reinterpret_cast<const float4*>(As + off);
-            const float4 a1v = *reinterpret_cast<const float4*>(As + off + rbs);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.x, w[ROFF + 4 * c + 0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.x, w[ROFF + 4 * c + 0], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.y, w[ROFF + 4 * c + 1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.y, w[ROFF + 4 * c + 1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.z, w[ROFF + 4 * c + 2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.z, w[ROFF + 4 * c + 2], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.w, w[ROFF + 4 * c + 3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.w, w[ROFF + 4 * c + 3], acc1, 0, 0, 0);
+            if (RB == 2) {
+                const float4 a1v = *reinterpret_cast<const float4*>(As + off + rbs);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.x, w[ROFF + 4 * c + 0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.x, w[ROFF + 4 * c + 0], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.y, w[ROFF + 4 * c + 1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.y, w[ROFF + 4 * c + 1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.z, w[ROFF + 4 * c + 2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.z, w[ROFF + 4 * c + 2], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.w, w[ROFF + 4 * c + 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.w, w[ROFF + 4 * c + 3], acc1, 0, 0, 0);
+            } else {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.x, w[ROFF + 4 * c + 0], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.y, w[ROFF + 4 * c + 1], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.z, w[ROFF + 4 * c + 2], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v.w, w[ROFF + 4 * c + 3], acc0, 0, 0, 0);
+            }
         }
     }
     const int rslot = slice * 2 + tile;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        red[((rslot * 2 + 0) * 16 + q * 4 + i) * WS_RED_LD + r] = acc0[i];
-        red[((rslot * 2 + 1) * 16 + q * 4 + i) * WS_RED_LD + r] = acc1[i];
+        red[((rslot * RB + 0) * 16 + q * 4 + i) * WS_RED_LD + r] = acc0[i];
+        if (RB == 2) red[((rslot * RB + 1) * 16 + q * 4 + i) * WS_RED_LD + r] = acc1[i];
     }
     __syncthreads();
     if (NEXT1) {   // (see ws_phase)
         const __amdgpu_buffer_rsrc_t rn = ws_rsrc(ph.next1);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pre[u] = ws_ld4(rn, (unsigned)(tid + WS_THREADS * u) * 16u);
+        for (int u = 0; u < PRE; ++u) pre[u] = ws_ld4(rn, (unsigned)(tid + WS_THREADS * u) * 16u);
     }
-    if (tid < 128) {
+    if (tid < M * 4) {
         const int row = tid >> 2, c4 = (tid & 3) * 4;
         const int rb = row >> 4, rr = row & 15;
         float4 v[2];   // [0] = x W_ci + b_ci, [1] = h W_ch + b_ch
@@ -379,15 +402,15 @@ __device__ __forceinline__ void ws_phase_hx(const float (&w)[DEC_WS_NREG], const
             v[g] = *reinterpret_cast<const float4*>(bias + g * 16 + c4);
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl) {
-                const float4 t4 = *reinterpret_cast<const float4*>(red + (((sl * 2 + g) * 2 + rb) * 16 + rr) * WS_RED_LD + c4);
+                const float4 t4 = *reinterpret_cast<const float4*>(red + (((sl * 2 + g) * RB + rb) * 16 + rr) * WS_RED_LD + c4);
                 v[g].x += t4.x; v[g].y += t4.y; v[g].z += t4.z; v[g].w += t4.w;
             }
         }
-        const unsigned ooff = (unsigned)((j * WS_M + row) * 16 + c4) * 4u;
+        const unsigned ooff = (unsigned)((j * M + row) * 16 + c4) * 4u;
         float* hl = h_loc + row * 16 + c4;
         const float4 h4 = *reinterpret_cast<const float4*>(hl);
-        const float4 u4 = *reinterpret_cast<const float4*>(lds + WS_OFF_U + row * 16 + c4);
-        const float4 r4 = *reinterpret_cast<const float4*>(lds + WS_OFF_R + row * 16 + c4);
+        const float4 u4 = *reinterpret_cast<const float4*>(lds + WS_OFF_U(M) + row * 16 + c4);
+        const float4 r4 = *reinterpret_cast<const float4*>(lds + WS_OFF_R(M) + row * 16 + c4);
         float4 hn;
         hn.x = u4.x * h4.x + (1.0f - u4.x) * tanhf_(v[0].x + r4.x * v[1].x);
         hn.y = u4.y * h4.y + (1.0f - u4.y) * tanhf_(v[0].y + r4.y * v[1].y);
@@ -396,35 +419,40 @@ __device__ __forceinline__ void ws_phase_hx(const float (&w)[DEC_WS_NREG], const
         *reinterpret_cast<float4*>(hl) = hn;
         ws_st4(ws_rsrc(ph.out), ooff, hn);
         if (ph.yout) {   // ResidualWrapper: y = x + h'
-            const float4 x4 = *reinterpret_cast<const float4*>(As + (j * WS_M + row) * 16 + c4);
+            const float4 x4 = *reinterpret_cast<const float4*>(As + (j * M + row) * 16 + c4);
             hn.x += x4.x; hn.y += x4.y; hn.z += x4.z; hn.w += x4.w;
             ws_st4(ws_rsrc(ph.yout), ooff, hn);
             if (ph.yhist && b0 + row < B)
                 *reinterpret_cast<float4*>(ph.yhist + (size_t)(b0 + row) * ph.yld + j * 16 + c4) = hn;
         }
-        ws_publish_wave(cnt, WS_ARRIVALS / 2u);
+        ws_publish_wave(cnt, WS_ARRIVALS / (unsigned)(M * 4 / 64));
     }
 }
 
-// Luong dot attention for rows 2j and 2j+1 of the cluster (TF-1.8 _luong_score / _compute_attention; dot form at
-// reference attention.py:396-400): softmax over ALL Ts positions, context = alignments . memory.  Four waves per row.
+// Luong dot attention for this workgroup's rows of the cluster -- rows 2 j and 2 j + 1 for M = 32, row j for M = 16 (TF-1.8
+// _luong_score / _compute_attention; dot form at reference attention.py:396-400): softmax over ALL Ts positions, context =
+// alignments . memory.  FOUR waves per row in both forms (the same partial sums in the same order: a row's bits do not depend
+// on M); with one row the other four waves only keep the barriers.
+template <int M>
 __device__ __forceinline__ void ws_attention(const float* __restrict__ query, const float* __restrict__ keys,
                                              const float* __restrict__ values, float* ctx, float* align_t, int Ts, float* lds,
                                              int j, int b0, int B, unsigned* cnt, unsigned target, int* status) {
+    constexpr int RPW = M / 16;            // rows per workgroup
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));   // (see ws_phase)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave >> 2, hw = wave & 3, t256 = tid & 255;
+    const bool active = half < RPW;        // wave-uniform
     float* qs = lds + WS_OFF_AS + half * WS_D;                        // [2][256]
     float* part = lds + WS_OFF_AS + 2 * WS_D + half * (4 * WS_D);     // [2][4][256]
-    float* redm = lds + WS_OFF_RED + half * 16;                       // [2][4] maxima, then sums
-    float* invs = lds + WS_OFF_RED + 32;                              // [2] 1 / sum
+    float* redm = lds + WS_OFF_RED(M) + half * 16;                    // [2][4] maxima, then sums
+    float* invs = lds + WS_OFF_RED(M) + 32;                           // [2] 1 / sum
     const int Tsp = (Ts + 3) & ~3;
-    float* sc = lds + WS_OFF_SC + half * Tsp;
-    int* ctrl = reinterpret_cast<int*>(lds + WS_OFF_CTRL);
+    float* sc = lds + WS_OFF_SC(M) + half * Tsp;
+    int* ctrl = reinterpret_cast<int*>(lds + WS_OFF_CTRL(M));
 
-    const int rl = 2 * j + half;           // row inside the cluster
+    const int rl = RPW * j + (active ? half : 0);   // row inside the cluster
     const int row = b0 + rl;
     const bool row_ok = row < B;
     const int mr = row_ok ? row : B - 1;   // (a padding row of the last cluster attends over the last utterance's memory)
@@ -443,93 +471,104 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
         }
     };
     const float* kb = keys + (size_t)mr * Ts * WS_D;
-    load_keys(kb, 0);
+    if (active) load_keys(kb, 0);
     WS_STAMP(0)
 
     ws_wait(cnt, target, status, ctrl);
     WS_STAMP(1)
 
-    // the query: row rl of the attention GRU's new state (block format: unit u at ((u / 16) * 32 + row) * 16 + u % 16)
-    if (t256 < 64)
+    // the query: row rl of the attention GRU's new state (block format: unit u at ((u / 16) * M + row) * 16 + u % 16)
+    if (active && t256 < 64)
         *reinterpret_cast<float4*>(qs + 4 * t256) =
-            ws_ld4(ws_rsrc(query), (unsigned)(((t256 >> 2) * WS_M + rl) * 16 + 4 * (t256 & 3)) * 4u);
+            ws_ld4(ws_rsrc(query), (unsigned)(((t256 >> 2) * M + rl) * 16 + 4 * (t256 & 3)) * 4u);
     __syncthreads();
 
-    for (int j0 = 0; j0 < Ts; j0 += 16 * WS_KB) {
-        if (j0 > 0) load_keys(kb, j0);
+    if (active) {
+        for (int j0 = 0; j0 < Ts; j0 += 16 * WS_KB) {
+            if (j0 > 0) load_keys(kb, j0);
 #pragma unroll
-        for (int p = 0; p < WS_KB; ++p) {
-            const int jj = j0 + 16 * p + hw * 4 + sub;
-            float s = 0.f;
+            for (int p = 0; p < WS_KB; ++p) {
+                const int jj = j0 + 16 * p + hw * 4 + sub;
+                float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 kv = kpre[p][i];
-                const float4 qv = *reinterpret_cast<const float4*>(qs + (l16 + 16 * i) * 4);
-                s = fmaf(kv.x, qv.x, s);
-                s = fmaf(kv.y, qv.y, s);
-                s = fmaf(kv.z, qv.z, s);
-                s = fmaf(kv.w, qv.w, s);
+                for (int i = 0; i < 4; ++i) {
+                    const float4 kv = kpre[p][i];
+                    const float4 qv = *reinterpret_cast<const float4*>(qs + (l16 + 16 * i) * 4);
+                    s = fmaf(kv.x, qv.x, s);
+                    s = fmaf(kv.y, qv.y, s);
+                    s = fmaf(kv.z, qv.z, s);
+                    s = fmaf(kv.w, qv.w, s);
+                }
+                s += __shfl_xor(s, 8);
+                s += __shfl_xor(s, 4);
+                s += __shfl_xor(s, 2);
+                s += __shfl_xor(s, 1);
+                if (jj < Ts && l16 == 0) sc[jj] = s;
             }
-            s += __shfl_xor(s, 8);
-            s += __shfl_xor(s, 4);
-            s += __shfl_xor(s, 2);
-            s += __shfl_xor(s, 1);
-            if (jj < Ts && l16 == 0) sc[jj] = s;
         }
     }
     __syncthreads();
     WS_STAMP(2)
 
     float m = -INFINITY;
-    for (int jj = t256; jj < Ts; jj += 256) m = fmaxf(m, sc[jj]);
+    if (active) {
+        for (int jj = t256; jj < Ts; jj += 256) m = fmaxf(m, sc[jj]);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0) redm[hw] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
-    float sum = 0.f;
-    for (int jj = t256; jj < Ts; jj += 256) {
-        const float e = __expf(sc[jj] - m);
-        sc[jj] = e;
-        sum += e;
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) redm[hw] = m;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    __syncthreads();   // everyone has read the maxima
-    if (lane == 0) redm[hw] = sum;
     __syncthreads();
-    sum = (redm[0] + redm[1]) + (redm[2] + redm[3]);
-    const float inv = 1.0f / sum;
-    if (hw == 0 && lane == 0) invs[half] = inv;
+    float sum = 0.f;
+    if (active) {
+        m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+        for (int jj = t256; jj < Ts; jj += 256) {
+            const float e = __expf(sc[jj] - m);
+            sc[jj] = e;
+            sum += e;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    }
+    __syncthreads();   // everyone has read the maxima
+    if (active && lane == 0) redm[hw] = sum;
+    __syncthreads();
+    float inv = 0.f;
+    if (active) {
+        sum = (redm[0] + redm[1]) + (redm[2] + redm[3]);
+        inv = 1.0f / sum;
+        if (hw == 0 && lane == 0) invs[half] = inv;
+    }
 
     // context: wave hw takes positions hw, hw + 4, ...; a lane owns 4 consecutive depth elements (1 KB rows, coalesced);
     // WS_VB rows requested together
     WS_STAMP(3)
-    const float* vb = values + (size_t)mr * Ts * WS_D + 4 * lane;
-    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j0 = hw; j0 < Ts; j0 += 4 * WS_VB) {
-        float4 vv[WS_VB];
+    if (active) {
+        const float* vb = values + (size_t)mr * Ts * WS_D + 4 * lane;
+        float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j0 = hw; j0 < Ts; j0 += 4 * WS_VB) {
+            float4 vv[WS_VB];
 #pragma unroll
-        for (int p = 0; p < WS_VB; ++p) {
-            const int jj = j0 + 4 * p;
-            vv[p] = *reinterpret_cast<const float4*>(vb + (size_t)(jj < Ts ? jj : Ts - 1) * WS_D);
-        }
+            for (int p = 0; p < WS_VB; ++p) {
+                const int jj = j0 + 4 * p;
+                vv[p] = *reinterpret_cast<const float4*>(vb + (size_t)(jj < Ts ? jj : Ts - 1) * WS_D);
+            }
 #pragma unroll
-        for (int p = 0; p < WS_VB; ++p) {
-            const int jj = j0 + 4 * p;
-            const float e = jj < Ts ? sc[jj] : 0.f;
-            c0.x = fmaf(e, vv[p].x, c0.x); c0.y = fmaf(e, vv[p].y, c0.y); c0.z = fmaf(e, vv[p].z, c0.z); c0.w = fmaf(e, vv[p].w, c0.w);
+            for (int p = 0; p < WS_VB; ++p) {
+                const int jj = j0 + 4 * p;
+                const float e = jj < Ts ? sc[jj] : 0.f;
+                c0.x = fmaf(e, vv[p].x, c0.x); c0.y = fmaf(e, vv[p].y, c0.y); c0.z = fmaf(e, vv[p].z, c0.z); c0.w = fmaf(e, vv[p].w, c0.w);
+            }
         }
+        *reinterpret_cast<float4*>(part + hw * WS_D + 4 * lane) = c0;
     }
-    *reinterpret_cast<float4*>(part + hw * WS_D + 4 * lane) = c0;
     __syncthreads();
     WS_STAMP(4)
-    // wave 0 hands over both rows: a lane's 16 bytes are (block j', row 2j + hf, units 4c..4c+3), eight lanes one
-    // 128-byte line of the context buffer (block format), two store instructions
+    // wave 0 hands the rows over: a lane's 16 bytes are (block j', row RPW j + hf, units 4c..4c+3) -- M = 32: eight lanes one
+    // 128-byte line of the context buffer (block format: two rows x 16 units), two store instructions; M = 16: one
     if (wave == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int jb = 8 * i + (lane >> 3), hf = (lane >> 2) & 1, c = lane & 3;
+        for (int i = 0; i < RPW; ++i) {
+            const int jb = RPW == 2 ? 8 * i + (lane >> 3) : lane >> 2, hf = RPW == 2 ? (lane >> 2) & 1 : 0, c = lane & 3;
             const float* pp = lds + WS_OFF_AS + 2 * WS_D + hf * (4 * WS_D) + 16 * jb + 4 * c;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -539,25 +578,26 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
             }
             const float iv = invs[hf];
             a.x *= iv; a.y *= iv; a.z *= iv; a.w *= iv;
-            ws_st4(ws_rsrc(ctx), (unsigned)((jb * WS_M + 2 * j + hf) * 16 + 4 * c) * 4u, a);
+            ws_st4(ws_rsrc(ctx), (unsigned)((jb * M + RPW * j + hf) * 16 + 4 * c) * 4u, a);
         }
         WS_STAMP(5)
         ws_publish_wave(cnt, WS_ARRIVALS);
         WS_STAMP(6)
     }
-    if (align_t && row_ok)
+    if (active && align_t && row_ok)
         for (int k = t256; k < Ts; k += 256) align_t[(size_t)row * Ts + k] = sc[k] * inv;
 }
 
-template <bool CUDNN>
+template <bool CUDNN, int M>
 __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
+    constexpr int PRE = WS_D * M / 4 / WS_THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cluster = blockIdx.x / WS_W, j = blockIdx.x - cluster * WS_W;
-    const int b0 = cluster * WS_M;
+    const int b0 = cluster * M;
     unsigned* cnt = p.counters + 64 * cluster;
-    int* ctrl = reinterpret_cast<int*>(lds + WS_OFF_CTRL);
+    int* ctrl = reinterpret_cast<int*>(lds + WS_OFF_CTRL(M));
 
     // ---- this wave's weights: up to 176 registers per lane, once, from the register-order image (decoder_ws_pack)
     float w[DEC_WS_NREG];
@@ -572,8 +612,8 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
 #pragma unroll
         for (int i = 0; i < DEC_WS_NREG; ++i) asm volatile("" : "+v"(w[i]));
     }
-    for (int i = tid; i < 4 * WS_M * 16; i += WS_THREADS) lds[WS_OFF_H + i] = 0.f;   // zero_state (h of three cells, u)
-    for (int i = tid; i < DEC_WS_BIAS_SLOTS * 32; i += WS_THREADS) lds[WS_OFF_BIAS + i] = p.bimg[j * (DEC_WS_BIAS_SLOTS * 32) + i];
+    for (int i = tid; i < 4 * M * 16; i += WS_THREADS) lds[WS_OFF_H(M) + i] = 0.f;   // zero_state (h of three cells, u)
+    for (int i = tid; i < DEC_WS_BIAS_SLOTS * 32; i += WS_THREADS) lds[WS_OFF_BIAS(M) + i] = p.bimg[j * (DEC_WS_BIAS_SLOTS * 32) + i];
     if (tid == 0) {
         ctrl[0] = 0;
         // all workgroups resident: the CUs the call pipeline held for this stream are no longer needed
@@ -582,10 +622,10 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
     }
     __syncthreads();
 
-    float* st = p.state + (size_t)cluster * WS_STATE_FLOATS;
-    float* att = st, *ycur = st + 7 * WS_BUF;
-    float* rs = p.rest + (size_t)cluster * WS_REST_FLOATS;
-    float* p1 = rs, *rh = rs + WS_BUF, *ctx = rs + 2 * WS_BUF, *y0 = rs + 3 * WS_BUF, *p2 = rs + 4 * WS_BUF;
+    float* st = p.state + (size_t)cluster * WS_STATE_FLOATS(M);
+    float* att = st, *ycur = st + 7 * WS_BUF(M);
+    float* rs = p.rest + (size_t)cluster * WS_REST_FLOATS(M);
+    float* p1 = rs, *rh = rs + WS_BUF(M), *ctx = rs + 2 * WS_BUF(M), *y0 = rs + 3 * WS_BUF(M), *p2 = rs + 4 * WS_BUF(M);
     const int yld = p.n_steps * WS_D;
     unsigned g = 0;   // hand-offs completed by the cluster
     const unsigned per = WS_ARRIVALS * WS_W;
@@ -595,14 +635,14 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
     {
         const __amdgpu_buffer_rsrc_t rn = ws_rsrc(att);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pre[u] = ws_ld4(rn, (unsigned)(tid + WS_THREADS * u) * 16u);
+        for (int u = 0; u < PRE; ++u) pre[u] = ws_ld4(rn, (unsigned)(tid + WS_THREADS * u) * 16u);
     }
     for (int t = 0; t < p.n_steps; ++t) {
         // cell states by step parity: step t reads [t & 1] and writes [(t + 1) & 1]
         const int po = t & 1, pn = po ^ 1;
-        float* h_att_o = st + (1 + po) * WS_BUF, *h_att = st + (1 + pn) * WS_BUF;
-        float* h_d1_o = st + (3 + po) * WS_BUF, *h_d1 = st + (3 + pn) * WS_BUF;
-        float* h_d2_o = st + (5 + po) * WS_BUF, *h_d2 = st + (5 + pn) * WS_BUF;
+        float* h_att_o = st + (1 + po) * WS_BUF(M), *h_att = st + (1 + pn) * WS_BUF(M);
+        float* h_d1_o = st + (3 + po) * WS_BUF(M), *h_d1 = st + (3 + pn) * WS_BUF(M);
+        float* h_d2_o = st + (5 + po) * WS_BUF(M), *h_d2 = st + (5 + pn) * WS_BUF(M);
         WsPhase ph;
         ph.yout = nullptr; ph.yhist = nullptr; ph.yld = yld; ph.layer = 0; ph.delay = p.dbg_delay; ph.next1 = nullptr;
         // PrenetWrapper on concat([x_t, attention_{t-1}]) (wrappers.py:122-124).  x_t = (y_{t-1} W_o + b_o)[-n_mels:] is folded
@@ -610,64 +650,64 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
         // so only the bias differs there (the un-folded one)
         ph.a0 = ycur; ph.a1 = att; ph.out = p1; ph.bias_slot = t == 0 ? 1 : 0; ph.target = per * g++;
         WS_TL_PHASE(t, 0)
-        ws_phase<WS_D, 16, WS_D, 1, 16, WS_ACT, ACT_RELU, WS_R0, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+        ws_phase<M, WS_D, 16, WS_D, 1, 16, WS_ACT, ACT_RELU, WS_R0, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
         ph.a0 = p1; ph.a1 = nullptr; ph.out = p2; ph.bias_slot = 2; ph.target = per * g++; ph.next1 = h_att_o;
         WS_TL_PHASE(t, 1)
-        ws_phase<WS_D, 16, 0, 1, 8, WS_ACT, ACT_RELU, WS_R1, false, 0, false, true>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+        ws_phase<M, WS_D, 16, 0, 1, 8, WS_ACT, ACT_RELU, WS_R1, false, 0, false, true>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
         // attention GRU (model.py:226-229) on [p2 ; h_att]; the new state is the attention query
         if (CUDNN) {   // one hand-off: r, u, then x W_ci and h W_ch on the same staged tile
             ph.a0 = p2; ph.a1 = h_att_o; ph.out = nullptr; ph.bias_slot = 3; ph.target = per * g;
             WS_TL_PHASE(t, 2)
-            ws_phase<WS_P2, 8, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R2, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+            ws_phase<M, WS_P2, 8, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R2, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
             ph.out = h_att; ph.bias_slot = 4; ++g;
             WS_TL_PHASE(t, 3)
-            ws_phase_hx<WS_P2, 8, WS_R3, false>(w, ph, lds, j, b0, p.B, cnt, pre);
+            ws_phase_hx<M, WS_P2, 8, WS_R3, false>(w, ph, lds, j, b0, p.B, cnt, pre);
         } else {       // TF GRUCell: gates on [p2 ; h_att], a hop, candidate on [p2 ; r*h_att]
             ph.a0 = p2; ph.a1 = h_att_o; ph.out = rh; ph.bias_slot = 3; ph.target = per * g++;
             WS_TL_PHASE(t, 2)
-            ws_phase<WS_P2, 8, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R2, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+            ws_phase<M, WS_P2, 8, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R2, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
             ph.a0 = p2; ph.a1 = rh; ph.out = h_att; ph.bias_slot = 4; ph.target = per * g++;
             WS_TL_PHASE(t, 3)
-            ws_phase<WS_P2, 8, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R3, true, 4, false, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+            ws_phase<M, WS_P2, 8, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R3, true, 4, false, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
         }
         WS_TL_PHASE(t, 4)
-        ws_attention(h_att, p.keys, p.memory, ctx, p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr, p.Ts, lds, j, b0, p.B,
+        ws_attention<M>(h_att, p.keys, p.memory, ctx, p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr, p.Ts, lds, j, b0, p.B,
                      cnt, per * g++, p.status);
         // attention_layer(concat([cell_output, context])), no bias
         ph.a0 = h_att; ph.a1 = ctx; ph.out = att; ph.bias_slot = 5; ph.target = per * g++; ph.next1 = h_d1_o;
         WS_TL_PHASE(t, 5)
-        ws_phase<WS_D, 16, WS_D, 1, 16, WS_ACT, ACT_NONE, WS_R5, false, 0, false, true>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+        ws_phase<M, WS_D, 16, WS_D, 1, 16, WS_ACT, ACT_NONE, WS_R5, false, 0, false, true>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
         // two ResidualWrapper(GRU cell) layers (model.py:254-269); the top one writes the y history
         ph.layer = 1;
         if (CUDNN) {
             ph.a0 = att; ph.a1 = h_d1_o; ph.out = nullptr; ph.bias_slot = 6; ph.target = per * g;
             WS_TL_PHASE(t, 6)
-            ws_phase<WS_D, 16, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R6, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+            ws_phase<M, WS_D, 16, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R6, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
             ph.out = h_d1; ph.yout = y0; ph.bias_slot = 7; ++g; ph.next1 = h_d2_o;
             WS_TL_PHASE(t, 7)
-            ws_phase_hx<WS_D, 16, WS_R7, true>(w, ph, lds, j, b0, p.B, cnt, pre);
+            ws_phase_hx<M, WS_D, 16, WS_R7, true>(w, ph, lds, j, b0, p.B, cnt, pre);
             ph.layer = 2; ph.yout = nullptr;
             ph.a0 = y0; ph.a1 = h_d2_o; ph.out = nullptr; ph.bias_slot = 8; ph.target = per * g;
             WS_TL_PHASE(t, 8)
-            ws_phase<WS_D, 16, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R8, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+            ws_phase<M, WS_D, 16, WS_D, 2, 16, WS_CUDNN_RU, ACT_NONE, WS_R8, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
             ph.out = h_d2; ph.yout = ycur; ph.yhist = p.yhist + (size_t)t * WS_D; ph.bias_slot = 9; ++g; ph.next1 = att;
             WS_TL_PHASE(t, 9)
-            ws_phase_hx<WS_D, 16, WS_R9, true>(w, ph, lds, j, b0, p.B, cnt, pre);
+            ws_phase_hx<M, WS_D, 16, WS_R9, true>(w, ph, lds, j, b0, p.B, cnt, pre);
         } else {
             ph.a0 = att; ph.a1 = h_d1_o; ph.out = rh; ph.bias_slot = 6; ph.target = per * g++;
             WS_TL_PHASE(t, 6)
-            ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R6, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+            ws_phase<M, WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R6, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
             ph.a0 = att; ph.a1 = rh; ph.out = h_d1; ph.yout = y0; ph.bias_slot = 7; ph.target = per * g++; ph.next1 = h_d2_o;
             WS_TL_PHASE(t, 7)
-            ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R7, true, 4, false, true>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+            ws_phase<M, WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R7, true, 4, false, true>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
             ph.layer = 2; ph.yout = nullptr;
             ph.a0 = y0; ph.a1 = h_d2_o; ph.out = rh; ph.bias_slot = 8; ph.target = per * g++;
             WS_TL_PHASE(t, 8)
-            ws_phase<WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R8, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+            ws_phase<M, WS_D, 16, WS_D, 2, 16, WS_GATES, ACT_NONE, WS_R8, false, 0, true, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
             ph.a0 = y0; ph.a1 = rh; ph.out = h_d2; ph.yout = ycur; ph.yhist = p.yhist + (size_t)t * WS_D; ph.bias_slot = 9;
             ph.target = per * g++; ph.next1 = att;
             WS_TL_PHASE(t, 9)
-            ws_phase<WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R9, true, 4, false, true>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
+            ws_phase<M, WS_D, 16, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R9, true, 4, false, true>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
         }
     }
 }
@@ -676,18 +716,26 @@ bool decoder_ws_supports(const DecoderWeights& w, int cudnn, int B, int Ts) {
     (void)cudnn;   // both GRU formulations (the register image is packed for the handle's)
     return w.local_d == 0 && w.n_layers == 2 && w.att_units == WS_D && w.dec_units == WS_D && w.mem_units == WS_D &&
            w.prenet1_units == WS_D && w.prenet2_units == WS_P2 && w.n_mels <= WS_D && w.ws_wimg && w.ws_bimg && B >= 1 && Ts >= 1 &&
-           ws_lds_bytes(Ts) <= 160 * 1024 - 64 && (size_t)B * Ts * WS_D * 4 < 0xFFFFFFF0ull;
+           ws_lds_bytes(Ts, 32) <= 160 * 1024 - 64 && (size_t)B * Ts * WS_D * 4 < 0xFFFFFFF0ull;
 }
 
-int decoder_ws_workgroups(int B) { return WS_W * ((B + WS_M - 1) / WS_M); }
-size_t decoder_ws_scratch_floats(int B) { return (size_t)((B + WS_M - 1) / WS_M) * (WS_STATE_FLOATS + WS_REST_FLOATS); }
+// rows: utterances per cluster, 32 or 16 (see the LDS map)
+static int ws_rows(int rows) { return rows == 16 ? 16 : 32; }
+int decoder_ws_workgroups(int B, int rows) { const int M = ws_rows(rows); return WS_W * ((B + M - 1) / M); }
+size_t decoder_ws_scratch_floats(int B, int rows) {
+    const int M = ws_rows(rows);
+    return (size_t)((B + M - 1) / M) * (WS_STATE_FLOATS(M) + WS_REST_FLOATS(M));
+}
+int decoder_ws_clusters(int B, int rows) { const int M = ws_rows(rows); return (B + M - 1) / M; }
 
 hipError_t decoder_ws_configure() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024 - 64);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               160 * 1024 - 64);
+    const void* fns[4] = {reinterpret_cast<const void*>(&dec_ws_kernel<false, 32>), reinterpret_cast<const void*>(&dec_ws_kernel<true, 32>),
+                          reinterpret_cast<const void*>(&dec_ws_kernel<false, 16>), reinterpret_cast<const void*>(&dec_ws_kernel<true, 16>)};
+    for (const void* f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // The register-order image of the decoder's weights (host; called by tts_finalize_weights).  Wt arrays are the packed
@@ -767,25 +815,39 @@ void decoder_ws_pack(const DecWsHostWeights& hw, float* wimg, float* bimg) {
 size_t decoder_ws_wimg_floats() { return (size_t)WS_W * WS_NW * DEC_WS_NREG * 64; }
 size_t decoder_ws_bimg_floats() { return (size_t)WS_W * DEC_WS_BIAS_SLOTS * 32; }
 
-// Capturable: two memsets and one launch.  `scratch`: decoder_ws_scratch_floats(B) floats (the state blocks of all clusters
-// first: zeroed here); `sync` = 64 unsigned per cluster + 1 (resident count) + 1 (sticky status word, see decoder_persistent.hip).
+// Capturable: two memsets and one launch.  `scratch`: decoder_ws_scratch_floats(B, rows) floats (the state blocks of all clusters
+// first: zeroed here); `sync` = 64 unsigned per cluster (of sync_clusters >= the launch's) + 1 (resident count) + 1 (sticky status
+// word, see decoder_persistent.hip).
+// rows: utterances per cluster (32: 16 compute units per 32 utterances; 16: per 16 -- same bits, see the LDS map)
 hipError_t decoder_ws_enqueue(hipStream_t s, const DecoderWeights& w, float* scratch, float* yhist, const float* memory,
                               const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync, int* hold_flag,
-                              int cudnn, int dbg_delay) {
-    const int clusters = (B + WS_M - 1) / WS_M;
+                              int cudnn, int dbg_delay, int rows, int sync_clusters) {
+    const int M = ws_rows(rows);
+    const int clusters = (B + M - 1) / M;
+    // (the resident count and the sticky status word sit behind the counters of `sync_clusters` clusters: one place for
+    //  both forms of one batch size, so that a status raised by a launch of one form is found after a launch of the other)
+    if (sync_clusters < clusters) sync_clusters = clusters;
+    const size_t state_floats = M == 16 ? WS_STATE_FLOATS(16) : WS_STATE_FLOATS(32);
     hipError_t e;
-    if ((e = hipMemsetAsync(scratch, 0, (size_t)clusters * WS_STATE_FLOATS * sizeof(float), s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(sync, 0, ((size_t)64 * clusters + 1) * sizeof(unsigned), s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(scratch, 0, (size_t)clusters * state_floats * sizeof(float), s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(sync, 0, ((size_t)64 * sync_clusters + 1) * sizeof(unsigned), s)) != hipSuccess) return e;
     WsParams p;
     p.wimg = w.ws_wimg; p.bimg = w.ws_bimg;
     p.memory = memory; p.keys = keys;
-    p.state = scratch; p.rest = scratch + (size_t)clusters * WS_STATE_FLOATS;
+    p.state = scratch; p.rest = scratch + (size_t)clusters * state_floats;
     p.yhist = yhist; p.align = align;
-    p.counters = sync; p.resident = sync + 64 * clusters; p.status = reinterpret_cast<int*>(sync + 64 * clusters + 1);
+    p.counters = sync; p.resident = sync + 64 * sync_clusters; p.status = reinterpret_cast<int*>(sync + 64 * sync_clusters + 1);
     p.hold_flag = hold_flag;
     p.B = B; p.Ts = Ts; p.n_steps = n_steps; p.dbg_delay = dbg_delay; p.cudnn = cudnn;
-    if (cudnn) hipLaunchKernelGGL(dec_ws_kernel<true>, dim3(WS_W * clusters), dim3(WS_THREADS), ws_lds_bytes(Ts), s, p);
-    else hipLaunchKernelGGL(dec_ws_kernel<false>, dim3(WS_W * clusters), dim3(WS_THREADS), ws_lds_bytes(Ts), s, p);
+    const dim3 grid(WS_W * clusters), block(WS_THREADS);
+    const size_t lds = ws_lds_bytes(Ts, M);
+    if (M == 16) {
+        if (cudnn) hipLaunchKernelGGL((dec_ws_kernel<true, 16>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((dec_ws_kernel<false, 16>), grid, block, lds, s, p);
+    } else {
+        if (cudnn) hipLaunchKernelGGL((dec_ws_kernel<true, 32>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((dec_ws_kernel<false, 32>), grid, block, lds, s, p);
+    }
 #ifdef WS_TIMELINE
     {
         (void)hipStreamSynchronize(s);

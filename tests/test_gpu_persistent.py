@@ -14,13 +14,19 @@ pytestmark = pytest.mark.gpu
 WIN, HOP, NFFT = 1102, 275, 2048
 
 
-@pytest.fixture(params=[1, 0], ids=['weight-stationary', 'streamed-weights'])
+@pytest.fixture(params=[(1, 32), (1, 16), (0, 0)], ids=['weight-stationary-32', 'weight-stationary-16', 'streamed-weights'])
 def persistent(engine, request):
-    """both persistent kernels: decoder_ws.hip (round 5: clusters of 16 workgroups x 32 utterances, the weights resident
-    in registers; the default) and decoder_persistent.hip (8 x 16, the weights streamed from L2 in every step)"""
+    """the persistent kernels: decoder_ws.hip (clusters of 16 workgroups, the weights resident in registers; the default) in
+    both of its forms -- 32 utterances per cluster (round 5) and 16 (round 6: twice the compute units, a shorter phase) -- and
+    decoder_persistent.hip (8 workgroups x 16 utterances, the weights streamed from L2 in every step)"""
+    pd_ws, rows = request.param
     engine.set_option('persistent_decoder', 2)   # also outside the call pipeline
-    engine.set_option('pd_ws', request.param)
+    engine.set_option('pd_ws', pd_ws)
+    engine.set_option('debug_hooks', 1)
+    engine.set_option('pd_rows', rows)
     yield engine
+    engine.set_option('pd_rows', 0)
+    engine.set_option('debug_hooks', 0)
     engine.set_option('pd_ws', 1)
     engine.set_option('persistent_decoder', 1)
 
@@ -100,3 +106,28 @@ def test_pipelined_full_size_calls_repeat_bit_identically(engine):
     for o in outs[1:]:
         for k, v in ref.items():
             assert np.array_equal(v, o[k].to_host()), k
+
+
+@pytest.mark.parametrize('B,Ts,S', [(1, 9, 4), (5, 37, 6), (16, 64, 5), (33, 150, 6), (64, 150, 12)])
+def test_weight_stationary_decoder_same_bits_at_16_and_32_rows_per_cluster(engine, B, Ts, S):
+    """decoder_ws.hip with 16 and with 32 utterances per cluster: the same K slices in the same order, four waves per
+    attention row in both, independent MFMA rows -- mel spectrograms and alignments equal BIT FOR BIT, which is what lets the
+    library choose the form by what else is running (csrc/api.hip, decoder_impl)."""
+    rng = np.random.default_rng(900 + B)
+    memory = engine.to_device((rng.standard_normal((B, Ts, 256)) * 1.2).astype(np.float32))
+    out = {}
+    try:
+        engine.set_option('persistent_decoder', 2)
+        engine.set_option('debug_hooks', 1)
+        for rows in (32, 16):
+            engine.set_option('pd_rows', rows)
+            mel, al = engine.decoder_forward(memory, S)
+            engine.synchronize()
+            out[rows] = (mel.to_host(), al.to_host())
+    finally:
+        engine.set_option('pd_rows', 0)
+        engine.set_option('debug_hooks', 0)
+        engine.set_option('persistent_decoder', 1)
+    assert np.isfinite(out[32][0]).all() and np.abs(out[32][0]).max() > 0
+    assert np.array_equal(out[16][0], out[32][0])
+    assert np.array_equal(out[16][1], out[32][1])
