@@ -45,8 +45,11 @@ enum tts_status {
 };
 
 /* Architecture hyper-parameters; field names and defaults follow the reference's
- * model_params (tacotron/params/model.py:8-153).  tts_default_config fills the defaults. */
+ * model_params (tacotron/params/model.py:8-153).  ALWAYS start from tts_default_config: it fills the defaults and
+ * `struct_size`, and tts_create refuses a struct whose size is not the library's (a caller built against another version of
+ * this header, or a zero-initialised struct) instead of reading past its end or taking zeros for settings. */
 typedef struct tts_config {
+    int32_t struct_size;         /* sizeof(tts_config_t) of the header the caller was built with (set by tts_default_config) */
     int32_t vocabulary_size;     /* 39  */
     int32_t embedding_size;      /* 256 */
     int32_t enc_prenet_units[2]; /* 256, 128 */

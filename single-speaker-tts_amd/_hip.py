@@ -34,6 +34,7 @@ class TtsError(RuntimeError):
 class TtsConfig(ctypes.Structure):
     """struct tts_config (include/sstts_hip.h)."""
     _fields_ = [
+        ('struct_size', c_int32),
         ('vocabulary_size', c_int32), ('embedding_size', c_int32), ('enc_prenet_units', c_int32 * 2),
         ('enc_n_banks', c_int32), ('enc_n_filters', c_int32), ('enc_proj_filters', c_int32 * 2),
         ('post_n_banks', c_int32), ('post_n_filters', c_int32), ('post_proj_filters', c_int32 * 2),

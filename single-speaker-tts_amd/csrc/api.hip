@@ -127,31 +127,26 @@ struct tts_handle_s {
     // utterances, weights in registers) wherever it covers the configuration and its 16 * ceil(B / 32) workgroups fit the
     // budget, else decoder_persistent.hip (8 x 16, weights streamed from L2 every step); 0 = always the latter
     int pd_ws = 1;
-    // the decoder's output projection (one GEMM over all steps) on the MAIN stream in front of the post-net (1: rounds 2-4,
-    // when the front stream bounded the step) or on the front stream behind its decoder (0).  Round 5, with the front stream
-    // 5 ms short of the main one: 14.45 ms per step either way (two same-box pairs): stays as it was
-    int defer_proj = 1;
+    // (the decoder's output projection -- one GEMM over all steps -- runs on the MAIN stream in front of the post-net under the
+    //  call pipeline: `defer_projection`.  On the front stream behind its decoder it gave the same 14.45 ms per step in round 5;
+    //  the option that switched it is gone)
     bool ws_configured = false;
-    // GEMM weights pre-split into the kernel's bf16 LDS images (gemm_f32.hip, PRE): made on first use per weight matrix
-    // (keyed by its address in the arena; tts_finalize_weights drops them).  Option "gemm_presplit", OFF by default: built
-    // and measured in round 5 (tools/gemm_bench.py 1 / 0, profiles/r05_experiment_gemm_presplit.txt) -- no launch got
-    // faster.  With the register budget of two waves per SIMD the pre-split kernels ran within 1 % of the in-kernel split
-    // on the long-K layers and 10-15 % slower on the short-K ones (1.5 x the weight bytes per tile); at the three-waves
-    // budget the six 16-byte image pieces a thread holds in flight spill (77 against 158 TFLOP/s).  Halving the split
-    // arithmetic changes nothing: the kernel is bound by neither the vector pipe nor LDS latency (fragment reads requested
-    // a step ahead, -DGEMM_FRAG_PIPE: -2 %).
+    // Round 5's two GEMM variants, measured and not faster (profiles/r05_experiment_gemm_presplit.txt): weights
+    // pre-split into the kernel's bf16 LDS images ("gemm_presplit": images made on first use per weight matrix, keyed by its
+    // address in the arena; tts_finalize_weights drops them) and the producer / consumer form of the kernel ("gemm_ps").  Their
+    // kernels are only compiled into a tools build of gemm_f32.hip (-DGEMM_EXPERIMENTS); the shipped library refuses both options.
     struct WeightImage { unsigned char* p = nullptr; size_t bytes = 0; int N = 0, K = 0, Cin = 0; };
     std::map<const float*, WeightImage> wimg;
     int gemm_presplit = 0;
-    // option "gemm_ps": the producer / consumer form of the GEMM kernel (gemm_f32.hip, PS: 512 threads, four multiplying and
-    // four staging waves, two LDS image pairs).  OFF: measured slower than the 256-thread form on every layer shape (145
-    // against 165 TFLOP/s on the long-K layers, 157 with pre-split weights; 65 against 105 on the final Dense: one workgroup
-    // per compute unit has nothing to cover its pipeline fill and its epilogue) -- profiles/r05_experiment_gemm_presplit.txt
     int gemm_ps = 0;
     int gl_pair = 3;                 // Griffin-Lim iterations per launch (1..3) where nothing per-iteration is asked for
     // First Griffin-Lim launch of a pipelined call that is cut for all compute units (gl_run, `wide_from`): -1 = by the rule
     // in gl_wide_from() below, -2 = never, >= 0 = that launch index.
     int gl_wide = -1;
+    // option "deterministic" (default 0): 1 = a call's outputs are bit-identical whatever the handle ran before -- the decoder
+    // already is (one kernel form's bits everywhere), this pins the Griffin-Lim run cut: the pipelined calls' cut for every
+    // call, no wide launches (costs the pipelined step ~0.25 ms and an unpipelined call ~5 % of its Griffin-Lim phase)
+    int deterministic = 0;
     int n_cus_dev = 0;
     bool pd_configured = false;
     // Test / diagnostic hooks, all per handle and all inert unless the option "debug_hooks" has been set to 1 on THIS handle
@@ -1251,13 +1246,18 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     int per_launch = h->gl_pair;
     per_launch = per_launch < 1 ? 1 : (per_launch > 3 ? 3 : per_launch);
     while (per_launch > 1 && gl_stream_ring_frames(win, hop, per_launch) <= 0) --per_launch;
-    gl_plan_stream(p, n_cus - held > 16 ? n_cus - held : n_cus, per_launch, h->debug_hooks ? h->gl_runs : 0,
+    // option "deterministic": ONE cut for every call of a shape, pipelined or not -- the cut of the pipelined calls (all but
+    // `reserve_cus` workgroups), never the second, wide one; an unpipelined call then runs that cut on all compute units
+    // (the cut decides the overlap-add order, the number of workgroups that draw its items does not)
+    const int plan_held = (h->deterministic && h->reserve_cus > 0) ? h->reserve_cus : held;
+    gl_plan_stream(p, n_cus - plan_held > 16 ? n_cus - plan_held : n_cus, per_launch, h->debug_hooks ? h->gl_runs : 0,
                    h->debug_hooks ? h->gl_run_len : 0);
     // wide_from >= 0 (the pipelined tts_synthesize, see gl_wide_from there): launches from that index on are cut for ALL
     // compute units -- the second stream's decoder has left its share by then.  A second cut, fixed per launch index, so
     // the waveform's bits stay a function of the call's arguments and options alone.
     GlParams pw = p;
-    const bool two_cuts = held > 0 && wide_from >= 0 && n_cus - held > 16 && !(h->debug_hooks && (h->gl_runs || h->gl_run_len));
+    const bool two_cuts = held > 0 && wide_from >= 0 && n_cus - held > 16 && !h->deterministic &&
+                          !(h->debug_hooks && (h->gl_runs || h->gl_run_len));
     if (two_cuts) gl_plan_stream(pw, n_cus, per_launch, 0, 0);
     const int nchunks = std::max(p.slots_per_utt, pw.slots_per_utt);
     WS(h, "gl.mse_partial", float, (size_t)B * nchunks, msep);
@@ -1398,6 +1398,7 @@ const char* tts_version(void) { return "sstts_hip 0.1.0 (gfx950)"; }
 int tts_default_config(tts_config_t* c) {
     if (!c) return TTS_ERR_INVALID;
     std::memset(c, 0, sizeof(*c));
+    c->struct_size = (int32_t)sizeof(tts_config_t);
     c->vocabulary_size = 39;
     c->embedding_size = 256;
     c->enc_prenet_units[0] = 256; c->enc_prenet_units[1] = 128;
@@ -1419,6 +1420,11 @@ int tts_default_config(tts_config_t* c) {
 
 int tts_create(const tts_config_t* cfg, int device_id, tts_handle_t* out) {
     if (!cfg || !out) return fail(nullptr, TTS_ERR_INVALID, "tts_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(tts_config_t))   // (the first field: read before anything behind it is trusted)
+        return fail(nullptr, TTS_ERR_INVALID,
+                    "tts_create: tts_config_t.struct_size is " + std::to_string(cfg->struct_size) + ", this library's struct has " +
+                    std::to_string(sizeof(tts_config_t)) + " bytes: fill the struct with tts_default_config of the header the "
+                    "library was built from");
     const tts_config_t& c = *cfg;
     // constraints of the kernels
     auto mult = [](int v, int m) { return v > 0 && v % m == 0; };
@@ -1591,12 +1597,12 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     }
     else if (!std::strcmp(key, "gl_pair")) h->gl_pair = value;
     else if (!std::strcmp(key, "gl_wide_from")) h->gl_wide = value < -2 ? -2 : value;
-    else if (!std::strcmp(key, "gemm_presplit")) h->gemm_presplit = value;
-    else if (!std::strcmp(key, "gemm_ps")) h->gemm_ps = value;
-    else if (!std::strcmp(key, "defer_proj")) {
-        int rc = sync_all(h);
-        if (rc) return rc;
-        h->defer_proj = value;
+    else if (!std::strcmp(key, "deterministic")) h->deterministic = value ? 1 : 0;
+    else if (!std::strcmp(key, "gemm_presplit") || !std::strcmp(key, "gemm_ps")) {
+        if (value && !gemm_experiments_built())
+            return fail(h, TTS_ERR_UNSUPPORTED, std::string(key) + ": a measured-and-not-faster GEMM variant of round 5; its kernels are only "
+                        "in a tools build of gemm_f32.hip (-DGEMM_EXPERIMENTS, tools/build_variant.sh)");
+        (key[5] == 'p' && key[6] == 'r' ? h->gemm_presplit : h->gemm_ps) = value;
     }
     else if (!std::strcmp(key, "pd_ws")) {
         if (value != h->pd_ws) {   // (may change whether a pipelined call's decoder is a persistent kernel at all)
@@ -2578,7 +2584,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
     // nothing in flight on the main stream: no post-net, no Griffin-Lim runs beside this call's decoder (the first call of a
     // burst) -- the weight-stationary decoder may then spread over twice the compute units (decoder_impl; the same bits)
     h->dec_chip_idle = pipelined && hipStreamQuery(main_stream) == hipSuccess;
-    h->defer_projection = pipelined && h->defer_proj;
+    h->defer_projection = pipelined;
     h->defer_parity = parity;
     h->has_pending_proj = false;
     h->pre_keys = (pipelined && keys_ahead) ? keys_ahead : nullptr;
@@ -2631,7 +2637,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         HIPCHK(h, hipEventRecord(h->ev_post_done[parity], h->stream));
         h->post_pending[parity] = true;
     }
-    const int wide_from = (pipelined && gl_streaming) ? gl_wide_from(h, B, Ts, sp->n_steps, T, sp->n_iter) : -1;
+    const int wide_from = (pipelined && gl_streaming && !h->deterministic) ? gl_wide_from(h, B, Ts, sp->n_steps, T, sp->n_iter) : -1;
     h->gl_wide_used[parity] = wide_from >= 0;
     if (gl_streaming)
         rc = gl_run(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav, nullptr,

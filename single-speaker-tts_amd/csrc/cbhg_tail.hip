@@ -13,8 +13,7 @@
 // exactly into three bf16 terms when it is staged, [split][row][4 chunks of 8 bf16] swizzled, and a 16-deep step of a 32 x 32
 // block is six v_mfma_f32_32x32x16_bf16 (the kernel was bound by the f32 MFMA rate: 62.9 MFLOP per workgroup = 117 us at
 // 256 flop per cycle).  One image per operand, two workgroup barriers per chunk; the next chunk's weights are in flight in
-// registers meanwhile.  -DCBHG_TAIL_F32_MFMA builds the round-3 form (v_mfma_f32_32x32x2_f32, [row][32 + 4] floats,
-// double-buffered weights) for A/B runs.
+// registers meanwhile.  (The round-3 form on v_mfma_f32_32x32x2_f32 is in git history up to round 5.)
 // 512 threads = 8 waves (2 x 4), a wave owns 64 rows x 64 columns; the highway packing puts the 32 H columns and the 32 T
 // columns of the same units in one 64-column span, so the gate mix is lane-local.
 #include "tts_common.h"
@@ -29,9 +28,6 @@ namespace tts {
 #define CT_BN 256
 #define CT_THREADS 512
 
-#ifdef CBHG_TAIL_F32_MFMA
-size_t cbhg_tail_lds_bytes() { return ((size_t)CT_BM * CT_XLD + 2 * (size_t)CT_BN * CT_BLD) * sizeof(float); }
-#else
 // the tile's f32 rows, then the bf16 images of one k-chunk: A [3][128][64 B], B [3][256][64 B]
 #define CT_AIMG (3 * CT_BM * 64)
 #define CT_BIMG (3 * CT_BN * 64)
@@ -58,7 +54,6 @@ __device__ __forceinline__ void ct_store_split4(unsigned char* img, int rows, in
     *reinterpret_cast<uint2*>(img + rows * 64 + off) = make_uint2(ct_pack_hi(m[0], m[1]), ct_pack_hi(m[2], m[3]));
     *reinterpret_cast<uint2*>(img + 2 * rows * 64 + off) = make_uint2(ct_pack_hi(l[0], l[1]), ct_pack_hi(l[2], l[3]));
 }
-#endif
 
 bool cbhg_tail_supports(int c_in, int units, int gru_units, int n_hw, long long M) {
     // (32-bit byte offsets into the projection buffer)
@@ -69,12 +64,8 @@ bool cbhg_tail_supports(int c_in, int units, int gru_units, int n_hw, long long 
 __global__ __launch_bounds__(CT_THREADS) void cbhg_tail_kernel(CbhgTailParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Xs = lds;                          // [128][CT_XLD]
-#ifdef CBHG_TAIL_F32_MFMA
-    float* Bs = lds + CT_BM * CT_XLD;         // [2][256][CT_BLD]
-#else
     unsigned char* Ai = reinterpret_cast<unsigned char*>(lds + CT_BM * CT_XLD);   // [3][128][64 B]
     unsigned char* Bi = Ai + CT_AIMG;                                              // [3][256][64 B]
-#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -116,16 +107,6 @@ __global__ __launch_bounds__(CT_THREADS) void cbhg_tail_kernel(CbhgTailParams p)
             rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (int)((unsigned)(row * K + kk) * 4u) : -1, 0, 0));
         }
     };
-#ifdef CBHG_TAIL_F32_MFMA
-    auto store_chunk = [&](int buf) {
-        float* B = Bs + buf * (CT_BN * CT_BLD);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (tid >> 3) + 64 * i;
-            *reinterpret_cast<float4*>(&B[row * CT_BLD + 4 * kq]) = rb[i];
-        }
-    };
-#else
     // chunk kc of the weights (registers) and of the tile (its f32 rows in LDS) -> the two bf16 images
     auto stage_chunk = [&](int kc) {
 #pragma unroll
@@ -136,7 +117,6 @@ __global__ __launch_bounds__(CT_THREADS) void cbhg_tail_kernel(CbhgTailParams p)
             ct_store_split4(Ai, CT_BM, row, kq, *reinterpret_cast<const float4*>(&Xs[row * CT_XLD + kc * CT_BK + 4 * kq]));
         }
     };
-#endif
 
     // Outputs leave through raw buffer stores whose resource ends with row M - 1: one 32-bit offset register per lane plus a
     // compile-time constant per element (as 64-bit addresses the 64 stores of an epilogue held 128 registers), and rows
@@ -148,9 +128,6 @@ __global__ __launch_bounds__(CT_THREADS) void cbhg_tail_kernel(CbhgTailParams p)
     const int row_l = wm * 64 + 4 * lh;   // + tm * 32 + (r & 3) + 8 * (r >> 2)
 
     f32x16 acc[2][2];
-#ifdef CBHG_TAIL_F32_MFMA
-    int buf = 0;
-#endif
     load_chunk(0, 0);
     for (int j = 0; j < n_jobs; ++j) {
         const int nch = (job_k(j) + CT_BK - 1) / CT_BK;
@@ -161,7 +138,6 @@ __global__ __launch_bounds__(CT_THREADS) void cbhg_tail_kernel(CbhgTailParams p)
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-#ifndef CBHG_TAIL_F32_MFMA
         for (int kc = 0; kc < nch; ++kc) {
             __syncthreads();   // the images are free (the previous chunk's MFMAs have read them); the tile's rows are written
             stage_chunk(kc);
@@ -200,45 +176,6 @@ __global__ __launch_bounds__(CT_THREADS) void cbhg_tail_kernel(CbhgTailParams p)
                 }
             }
         }
-#else
-        for (int kc = 0; kc < nch; ++kc) {
-            store_chunk(buf);
-            __syncthreads();   // (the first one also covers the tile's rows, a job's first one its updated rows)
-            if (kc + 1 < nch) load_chunk(j, kc + 1);
-            else if (j + 1 < n_jobs) load_chunk(j + 1, 0);
-            if (live) {
-                const float* B = Bs + buf * (CT_BN * CT_BLD);
-                auto frag = [&](int q, float4 (&a)[2], float4 (&b)[2]) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        a[t] = *reinterpret_cast<const float4*>(&Xs[(wm * 64 + t * 32 + li) * CT_XLD + kc * CT_BK + 8 * q + 4 * lh]);
-                        b[t] = *reinterpret_cast<const float4*>(&B[(wn * 64 + t * 32 + li) * CT_BLD + 8 * q + 4 * lh]);
-                    }
-                };
-                auto mma = [&](const float4 (&a)[2], const float4 (&b)[2]) {
-#pragma unroll
-                    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                        for (int tn = 0; tn < 2; ++tn) {
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
-                        }
-                };
-                float4 a0[2], b0[2], a1[2], b1[2];
-                frag(0, a0, b0);
-                frag(1, a1, b1);
-                mma(a0, b0);
-                frag(2, a0, b0);
-                mma(a1, b1);
-                frag(3, a1, b1);
-                mma(a0, b0);
-                mma(a1, b1);
-            }
-            buf ^= 1;
-        }
-#endif
 
         // ---- epilogue.  C/D map of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
         if (j == 0) {                       // lifter: relu(acc + b) -> the tile

@@ -13,9 +13,11 @@
 // Round 4: the products run on the bf16 matrix pipe at f32 accuracy.  Every f32 operand is split EXACTLY into three
 // bf16 terms where it is staged (x = hi + mid + lo: truncate to the top 16 bits, subtract, twice; 8 + 8 + 8 significand
 // bits, the subtractions are exact), and a 16-deep step of a block is six v_mfma_f32_32x32x16_bf16 into the same f32
-// accumulator: hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi.  The three products left out (mid*lo, lo*mid, lo*lo) are
-// below 2^-23 of |a||b|: the size of one f32 rounding, measured against the float64 oracle in tests/test_gpu_gemm.py
-// (same error as the v_mfma_f32_32x32x2_f32 form, which -DGEMM_F32_MFMA still builds for A/B runs).  Six bf16 MFMAs of
+// accumulator: hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi.  The three products left out: the splits TRUNCATE, so
+// |mid| < 2^-7 |x| and |lo| < 2^-15 |x|, and the two dropped mid*lo terms are bounded by 2^-21 |a||b| in the worst case
+// (lo*lo by 2^-30) -- four f32 roundings of one product, not one; the MEASURED error of a whole GEMM against the float64
+// oracle is that of the f32-input v_mfma_f32_32x32x2_f32 form the kernel used until round 3 (2.5e-7 rel-L2,
+// tests/test_gpu_gemm.py: the truncation errors are one-sided but far below the accumulation's own rounding).  Six bf16 MFMAs of
 // 8 passes replace eight f32 MFMAs of 16 passes per 16 k: 2.67x less matrix-pipe time; the splits are ~5.5 VALU
 // instructions per element on the otherwise idle vector pipe.  LDS image per operand: [split][row][4 chunks of 8 bf16]
 // with the chunk index XOR-swizzled by (row >> 2) & 3 (ds_read_b128 of 16 rows at one chunk hit 16 different bank
@@ -26,8 +28,6 @@
 // the lower terms are bf16 denormals (and below 2^-126 all three are): whatever the matrix pipe does with them, the result
 // differs from the exact one by less than K 2^-126 max|w| in absolute terms -- measured 2.5e-39 on 1e-39 ... 1e-36 operands.
 // From 1e-30 to 1e30 the error against float64 is the same 2.5e-7 rel-L2 as at unit scale.
-// (f32 MFMA form: [row][32+4] floats, b128 conflict-free; the k index inside a tile permuted -- lane half h of MFMA
-// step (q,j) uses k = 8q+4h+j -- so that each lane fetches its 4 consecutive k values with one ds_read_b128.)
 #include "tts_common.h"
 #include <cstring>
 #include <type_traits>
@@ -47,7 +47,6 @@ namespace tts {
 #define BN 128
 #define BK 32
 #define LDS_LD (BK + 4)
-#ifndef GEMM_F32_MFMA
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 // x = hi + mid + lo exactly, each a bf16 (the top 16 bits of an f32): bits of x, of x - hi, of x - hi - mid
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
@@ -71,7 +70,6 @@ __device__ __forceinline__ void store_split4(unsigned char* img, int row, int kq
     *reinterpret_cast<uint2*>(img + BM * 64 + off) = make_uint2(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]));
     *reinterpret_cast<uint2*>(img + 2 * BM * 64 + off) = make_uint2(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]));
 }
-#endif
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 max4(float4 a, float4 b) {
@@ -82,6 +80,9 @@ __device__ __forceinline__ float4 max4(float4 a, float4 b) {
 // powf out of the register allocation of every other GEMM)
 // POOL: instantiation whose A loader takes max(x[t], x[t+1]) (the two k = 3 projections that follow a max-pool): kept
 // apart so that every other GEMM carries neither its second load nor its registers.
+// PRE and PS are round 5's two measured-and-not-faster variants (profiles/r05_experiment_gemm_presplit.txt).
+// They stay in the body's source as template parameters, but the shipped library instantiates neither: only a tools build
+// with -DGEMM_EXPERIMENTS (tools/build_variant.sh) compiles their kernels and accepts the options "gemm_presplit" / "gemm_ps".
 // PRE: the weights come PRE-SPLIT (round 5): `g.Wimg` holds, per 128-row block of N and per k tile in the order the k loop
 // visits them, the 24 KB LDS image of the B tile itself -- [split][row][4 chunks, swizzled][8 bf16], made once per weight by
 // gemm_pack_weights_kernel with the same split3 -- so staging the B tile is six 16-byte loads and six linear ds_write_b128
@@ -110,10 +111,6 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
     const int n0 = (seq % nyb) * BN;
     if (n0 >= N || m0 >= M) return;
 
-#ifdef GEMM_F32_MFMA
-    __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
-#else
     // [split][row][32 bf16], chunks swizzled; PS: two such pairs in dynamic LDS (96 KB), As / Bs = the pair being read,
     // As_w / Bs_w = the pair being written
     __shared__ __attribute__((aligned(16))) unsigned char As_static[PS ? 16 : 3 * BM * 64];
@@ -123,7 +120,6 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
     unsigned char* Bs = PS ? ps_smem + 3 * BM * 64 : Bs_static;
     unsigned char* As_w = As;
     unsigned char* Bs_w = Bs;
-#endif
 
     // PS: both roles index their work with 0..255 (a consumer's wave tile, a producer's staging rows)
     const bool producer = PS && threadIdx.x >= 256;
@@ -322,18 +318,11 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
         for (int i = 0; i < 4; ++i) {
             const int row = (tid >> 3) + 32 * i;
             const int arow = POOL ? 4 * (tid >> 3) + i : row;
-#ifdef GEMM_F32_MFMA
-            *reinterpret_cast<float4*>(&As[arow * LDS_LD + 4 * kq]) = ra[i];
-            *reinterpret_cast<float4*>(&Bs[row * LDS_LD + 4 * kq]) = rb[i];
-#else
             store_split4(As_w, arow, kq, ra[i]);
             if (!PRE) store_split4(Bs_w, row, kq, rb[PRE ? 0 : i]);
-#endif
         }
-#ifndef GEMM_F32_MFMA
 #pragma unroll
         for (int i = 0; i < (PRE ? 6 : 0); ++i) *reinterpret_cast<uint4*>(Bs_w + tid * 16 + 4096 * i) = rbi[i];
-#endif
     };
 
     // 32 x 32 blocks of this wave that lie entirely past M or N get no MFMAs (wave-uniform): the final Dense has
@@ -359,91 +348,9 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
     // tests between the MFMAs), EDGE = true the one of a wave that owns a padded block
     auto mma_tile = [&](auto edge_c) {
         constexpr bool EDGE = decltype(edge_c)::value;
-#ifdef GEMM_F32_MFMA
-        // Two register sets for the LDS fragments: the ds_read_b128 of MFMA step q + 1 are requested before the 16 MFMAs
-        // of step q are issued, so a step never starts by waiting for LDS (hipcc leaves part of that latency exposed
-        // when the steps are written as one loop: 105 -> 119 TFLOP/s on the 64000 x 256 x 3072 shape in
-        // tools/gemm_microbench.hip).
-        auto frag = [&](int q, float4 (&a)[2], float4 (&b)[2]) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t] = *reinterpret_cast<const float4*>(&As[(wm * 64 + t * 32 + li) * LDS_LD + 8 * q + 4 * lh]);
-                b[t] = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + t * 32 + li) * LDS_LD + 8 * q + 4 * lh]);
-            }
-        };
-        auto mma = [&](const float4 (&a)[2], const float4 (&b)[2]) {
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn) {
-                    if (EDGE && !blk_live[tm][tn]) continue;   // wave-uniform
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b[tn].x, acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b[tn].y, acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].z, b[tn].z, acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].w, b[tn].w, acc[tm][tn], 0, 0, 0);
-                }
-        };
-        {
-            float4 a0[2], b0[2], a1[2], b1[2];
-            frag(0, a0, b0);
-            frag(1, a1, b1);
-            mma(a0, b0);
-            frag(2, a0, b0);
-            mma(a1, b1);
-            frag(3, a1, b1);
-            mma(a0, b0);
-            mma(a1, b1);
-        }
-#else
         // Two 16-deep steps per tile.  Lane (li, lh) of a 32-row block holds k = 16 q + 8 lh .. + 7 of row li: chunk
         // 2 q + lh of the row, one ds_read_b128 per split.  The A fragments of both row blocks stay for the step, the B
         // fragments of one column block at a time (36 fragment registers).
-#ifdef GEMM_FRAG_PIPE
-        // Round 5: the fragment reads of a step are requested one step ahead of its MFMAs, in second register sets (a step =
-        // one column block of one 16-deep half: twelve MFMAs).  Written as reads-then-MFMAs per step, every step began by
-        // waiting for its own ds_read_b128 -- six exposed LDS round trips per tile and wave.
-        auto ld_a = [&](int q, uint4 (&fa)[2][3]) {
-            const int ch = 2 * q + lh;
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                const int row = wm * 64 + tm * 32 + li;
-                const int off = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp) fa[tm][sp] = *reinterpret_cast<const uint4*>(As + sp * BM * 64 + off);
-            }
-        };
-        auto ld_b = [&](int q, int tn, uint4 (&fb)[3]) {
-            const int ch = 2 * q + lh;
-            const int row = wn * 64 + tn * 32 + li;
-            const int off = (row * 4 + (ch ^ ((row >> 2) & 3))) * 16;
-#pragma unroll
-            for (int sp = 0; sp < 3; ++sp) fb[sp] = *reinterpret_cast<const uint4*>(Bs + sp * BN * 64 + off);
-        };
-        auto mma_step = [&](const uint4 (&fa)[2][3], const uint4 (&fb)[3], int tn) {
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                if (EDGE && !blk_live[tm][tn]) continue;   // wave-uniform
-#define GEMM_MMA(SA, SB)                                                                                              \
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[tm][SA]),    \
-                                                                      __builtin_bit_cast(bf16x8_t, fb[SB]), acc[tm][tn], 0, 0, 0);
-                GEMM_MMA(0, 2) GEMM_MMA(2, 0) GEMM_MMA(1, 1) GEMM_MMA(0, 1) GEMM_MMA(1, 0) GEMM_MMA(0, 0)
-#undef GEMM_MMA
-            }
-        };
-        {
-            uint4 fa0[2][3], fa1[2][3], fb0[3], fb1[3];
-            ld_a(0, fa0);
-            ld_b(0, 0, fb0);
-            ld_b(0, 1, fb1);
-            mma_step(fa0, fb0, 0);
-            ld_a(1, fa1);
-            ld_b(1, 0, fb0);
-            mma_step(fa0, fb1, 1);
-            ld_b(1, 1, fb1);
-            mma_step(fa1, fb0, 0);
-            mma_step(fa1, fb1, 1);
-        }
-#else
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int ch = 2 * q + lh;
@@ -473,8 +380,6 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
                 }
             }
         }
-#endif
-#endif
     };
     auto k_loop = [&](auto edge_c) {
         if (!PS) {
@@ -488,7 +393,6 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
             }
             return;
         }
-#ifndef GEMM_F32_MFMA
         // PS: the producers are one tile ahead in LDS and one more in registers
         unsigned char* const A0 = ps_smem, * const B0 = ps_smem + 3 * BM * 64;
         unsigned char* const A1 = ps_smem + 3 * (BM + BN) * 64, * const B1 = A1 + 3 * BM * 64;
@@ -514,7 +418,6 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
             __syncthreads();
             cur ^= 1;
         }
-#endif
     };
     if (blk_live[0][0] && blk_live[0][1] && blk_live[1][0] && blk_live[1][1]) k_loop(std::false_type{});
     else k_loop(std::true_type{});
@@ -582,11 +485,12 @@ __device__ __forceinline__ void gemm_body(const GemmBatch& batch) {
     }
 }
 
-#ifdef GEMM_F32_MFMA
-#define GEMM_PRE_OK false
-#else
+#ifdef GEMM_EXPERIMENTS
 #define GEMM_PRE_OK true
+#else
+#define GEMM_PRE_OK false
 #endif
+bool gemm_experiments_built() { return GEMM_PRE_OK; }
 template <bool DENORM, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR))) void gemm_f32_kernel(GemmBatch batch) {
     gemm_body<DENORM, false, PRE && GEMM_PRE_OK>(batch);
@@ -598,15 +502,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(GEMM_NUM_VGPR_P
     gemm_body<false, true, PRE && GEMM_PRE_OK>(batch);
 }
 
+#ifdef GEMM_EXPERIMENTS
 // the producer / consumer form (gemm_body, PS): 512 threads, two LDS image pairs in dynamic shared memory
 #define GEMM_PS_LDS (2 * 3 * (BM + BN) * 64)
 template <bool DENORM, bool PRE>
 __global__ __launch_bounds__(512) void gemm_ps_kernel(GemmBatch batch) {
-    gemm_body<DENORM, false, PRE && GEMM_PRE_OK, GEMM_PRE_OK>(batch);
+    gemm_body<DENORM, false, PRE, true>(batch);
 }
 template <bool PRE>
 __global__ __launch_bounds__(512) void gemm_ps_pool_kernel(GemmBatch batch) {
-    gemm_body<false, true, PRE && GEMM_PRE_OK, GEMM_PRE_OK>(batch);
+    gemm_body<false, true, PRE, true>(batch);
 }
 template <typename K>
 static hipError_t gemm_ps_launch(K kernel, dim3 grid, hipStream_t s, const GemmBatch& b) {
@@ -621,7 +526,6 @@ static hipError_t gemm_ps_launch(K kernel, dim3 grid, hipStream_t s, const GemmB
 // the order the k loop of a GEMM with this (K, Cin) visits them -- linear, or for a convolution whose channel count is a
 // multiple of the tile depth: channel chunk outer, tap inner.  Rows past N and k past K are zeros.
 __global__ __launch_bounds__(256) void gemm_pack_weights_kernel(const float* __restrict__ Wt, unsigned char* __restrict__ img, int N, int K, int Cin) {
-#ifndef GEMM_F32_MFMA
     const int it = blockIdx.x, nb = blockIdx.y, tid = threadIdx.x;
     const int ktaps = K / Cin;
     const bool tap_inner = ktaps > 1 && (Cin % BK) == 0;
@@ -636,12 +540,17 @@ __global__ __launch_bounds__(256) void gemm_pack_weights_kernel(const float* __r
         if (n < N && kk < K) v = ld4(Wt + (size_t)n * K + kk);
         store_split4(tile, row, kq, v);
     }
-#endif
 }
+#endif
 size_t gemm_weight_image_bytes(int N, int K) { return (size_t)((N + BN - 1) / BN) * (size_t)((K + BK - 1) / BK) * (3 * BN * 64); }
 hipError_t launch_gemm_pack_weights(hipStream_t s, const float* Wt, unsigned char* img, int N, int K, int Cin) {
+#ifdef GEMM_EXPERIMENTS
     hipLaunchKernelGGL(gemm_pack_weights_kernel, dim3((K + BK - 1) / BK, (N + BN - 1) / BN), dim3(256), 0, s, Wt, img, N, K, Cin);
     return hipGetLastError();
+#else
+    (void)s; (void)Wt; (void)img; (void)N; (void)K; (void)Cin;
+    return hipErrorNotSupported;
+#endif
 }
 
 hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups) {
@@ -661,24 +570,27 @@ hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups) {
     for (int i = 0; i < n_groups; ++i) pool = pool || b.g[i].pool != 0;
     for (int i = 0; i < n_groups; ++i)
         if (pool && (!b.g[i].pool || b.g[i].C2)) return hipErrorInvalidValue;   // a pooled launch is homogeneous, never de-normalising
+#ifdef GEMM_EXPERIMENTS
     // pre-split weight images: all groups of a launch or none (api.hip attaches them to every weight it launches with)
-    bool pre = GEMM_PRE_OK;
+    bool pre = true;
     for (int i = 0; i < n_groups; ++i) pre = pre && b.g[i].Wimg != nullptr;
-    if (b.ps && GEMM_PRE_OK) {
+    if (b.ps) {
         if (pool) return pre ? gemm_ps_launch(gemm_ps_pool_kernel<true>, grid, s, b) : gemm_ps_launch(gemm_ps_pool_kernel<false>, grid, s, b);
         if (denorm) return pre ? gemm_ps_launch(gemm_ps_kernel<true, true>, grid, s, b) : gemm_ps_launch(gemm_ps_kernel<true, false>, grid, s, b);
         return pre ? gemm_ps_launch(gemm_ps_kernel<false, true>, grid, s, b) : gemm_ps_launch(gemm_ps_kernel<false, false>, grid, s, b);
     }
-    if (pool) {
-        if (pre) hipLaunchKernelGGL((gemm_f32_pool_kernel<true>), grid, dim3(256), 0, s, b);
-        else hipLaunchKernelGGL((gemm_f32_pool_kernel<false>), grid, dim3(256), 0, s, b);
-    } else if (denorm) {
-        if (pre) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, b);
-        else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, b);
-    } else {
-        if (pre) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, b);
-        else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, b);
+    if (pre) {
+        if (pool) hipLaunchKernelGGL((gemm_f32_pool_kernel<true>), grid, dim3(256), 0, s, b);
+        else if (denorm) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, b);
+        return hipGetLastError();
     }
+#else
+    if (b.ps) return hipErrorNotSupported;
+#endif
+    if (pool) hipLaunchKernelGGL((gemm_f32_pool_kernel<false>), grid, dim3(256), 0, s, b);
+    else if (denorm) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, b);
     return hipGetLastError();
 }
 

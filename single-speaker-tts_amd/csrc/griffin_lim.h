@@ -48,7 +48,7 @@ int gl_stream_ring_frames(int win, int hop, int n_stage = 1);   // 0: the window
 void gl_plan_stream(GlParams& p, int n_workers, int n_stage = 1, int force_runs = 0, int force_run_len = 0);  // needs T, B, win, hop, ncol; sets the item classes (cut for launches of n_stage iterations)
 hipError_t launch_gl_stream(hipStream_t s, const GlParams& p, int n_cus, int final_istft, int n_stage = 1);
 hipError_t gl_configure();
-size_t gl_state_bytes();   // bytes per bin of the state between launches (4: a phasor code; 8 with -DGL_STATE_F2: the raw spectrum)
+size_t gl_state_bytes();   // bytes per bin of the state between launches (4: a phasor code)
 hipError_t launch_gl_mse_reduce(hipStream_t s, const float* partial, int B, int nchunks, float denom, float* mse);
 hipError_t launch_mag_ft_to_tf(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP);
 hipError_t launch_tf_to_ft(hipStream_t s, const float* in, float* out, int B, int F, int T, int FP);

@@ -425,18 +425,12 @@ __device__ __forceinline__ cf gl_normalise(cf x, float mag) {
     const float g = mag * __builtin_amdgcn_rsqf(s2);
     return cmk(xr, x.y) * g;
 }
-// The state of a bin between launches.  Default: the 32-bit phasor code (4 B in, 4 B out per bin and launch, 7 + 6 VALU
-// instructions to decode / encode).  -DGL_STATE_F2 (experiment): the raw spectrum value as it leaves the merge pass, 8 B each
-// way, decoded by the normalisation (6 instructions), encoded by nothing.
-#ifdef GL_STATE_F2
-typedef cf gl_state_t;
-__device__ __forceinline__ gl_state_t gl_state_encode(cf x) { return x; }
-__device__ __forceinline__ cf gl_state_decode(gl_state_t s, float mag) { return gl_normalise(s, mag); }
-#else
+// The state of a bin between launches: the 32-bit phasor code (4 B in, 4 B out per bin and launch, 7 + 6 VALU instructions to
+// decode / encode).  (Round 4 measured the raw spectrum value instead -- 8 B each way, decoded by the normalisation, encoded
+// by nothing: the bytes cost more than the instructions; that build switch is in git history.)
 typedef unsigned gl_state_t;
 __device__ __forceinline__ gl_state_t gl_state_encode(cf x) { return gl_pack_phasor(x); }
 __device__ __forceinline__ cf gl_state_decode(gl_state_t s, float mag) { return gl_unpack_phasor(s, mag); }
-#endif
 size_t gl_state_bytes() { return sizeof(gl_state_t); }
 
 // tools-only ablations (garbage results, timing only): -DGL_ABL_NOSTORE drops the spectrum stores, -DGL_ABL_NOLOAD the

@@ -83,6 +83,7 @@ struct GemmBatch {
 };
 // Launches one grouped GEMM; all groups must share M (grid.x) and have N <= max_n.
 hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups);
+bool gemm_experiments_built();   // gemm_f32.hip compiled with -DGEMM_EXPERIMENTS (tools): the PRE / PS variants exist
 // One GEMM whose K range is cut into `slices` parts computed by separate workgroups (for problems with too
 // few output tiles to fill the GPU); `partial` holds slices*M*N floats.  The partial sums are added in slice
 // order and the group's epilogue (bias, activation, affine, residual) is applied by a second small kernel.

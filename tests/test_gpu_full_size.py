@@ -307,3 +307,31 @@ def test_pipelining_on_an_adopted_stream(engine):
         engine.set_option('pipeline', 1)
         engine.set_option('persistent_decoder', 1)
         hip.hipStreamDestroy(stream)
+
+
+def test_deterministic_option_pins_the_bits_across_call_histories(engine):
+    """Option "deterministic": the outputs of a call -- waveform included -- are the same bits whether the call ran pipelined
+    behind other calls or alone in a drained pipeline (without the option the Griffin-Lim run cut differs between the two, and
+    the waveforms agree to rounding only)."""
+    batches = [bench_ids(6, 25, 300 + i) for i in range(4)]
+
+    def run(pipeline):
+        engine.set_option('pipeline', pipeline)
+        dev = [engine.to_device(b) for b in batches]
+        outs = [engine.synthesize(d, 40, 6.02, 99.89, 1.3, 7, WIN, HOP, seed=40 + i, want_mel=True, want_linear=True, want_alignments=True)
+                for i, d in enumerate(dev)]
+        engine.synchronize()
+        return [{k: v.to_host() for k, v in o.items() if v is not None} for o in outs]
+
+    try:
+        engine.set_option('deterministic', 1)
+        run(1)   # shapes known
+        seq = run(0)
+        pip = run(1)
+        for i, (a, b) in enumerate(zip(seq, pip)):
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (i, k)
+        assert np.isfinite(seq[0]['wav']).all() and np.abs(seq[0]['wav']).max() > 0
+    finally:
+        engine.set_option('deterministic', 0)
+        engine.set_option('pipeline', 1)

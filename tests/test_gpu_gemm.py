@@ -51,11 +51,17 @@ def test_gemm_conv_matches_numpy(engine, B, T, Cin, ktaps, N, pool):
 
 @pytest.mark.parametrize('option', ['gemm_ps', 'gemm_presplit'])
 def test_gemm_variant_forms_match_numpy(engine, option):
-    """The two GEMM forms that are in the source but off (measured, not faster: profiles/r05_experiment_gemm_presplit.txt) --
-    producer / consumer waves (`gemm_ps`) and pre-split weight images (`gemm_presplit`) -- stay correct: dense, conv3 with
-    the max-pool loader, and the split-K shape."""
+    """Round 5's two GEMM variants (measured, not faster: profiles/r05_experiment_gemm_presplit.txt) -- producer / consumer
+    waves (`gemm_ps`) and pre-split weight images (`gemm_presplit`): the shipped library does not carry their kernels and
+    refuses the options; a tools build (-DGEMM_EXPERIMENTS, SSTTS_HIP_LIB) keeps them correct: dense, conv3 with the
+    max-pool loader, and the split-K shape."""
+    H = pkg('_hip')
     try:
-        engine.set_option(option, 1)
+        try:
+            engine.set_option(option, 1)
+        except H.TtsError as e:
+            assert e.code == H.TTS_ERR_UNSUPPORTED and 'GEMM_EXPERIMENTS' in str(e)
+            return
         for B, T, Cin, ktaps, N, pool in [(3, 50, 128, 1, 256, 0), (2, 77, 256, 3, 128, 1), (5, 30, 2048, 3, 128, 1), (4, 40, 80, 5, 128, 0)]:
             rng = np.random.default_rng(B * 1000 + Cin)
             M = B * T

@@ -29,6 +29,24 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared <= exported
 
 
+def test_config_struct_of_another_size_is_refused():
+    """tts_config_t starts with its own size (tts_default_config fills it): a zero-initialised struct, or one laid out by
+    another version of the header, is refused by tts_create before anything behind the first field is read (no GPU needed)."""
+    import ctypes
+    H = pkg('_hip')
+    lib = H.load_library()
+    cfg = H.TtsConfig()
+    lib.tts_default_config(ctypes.byref(cfg))
+    assert cfg.struct_size == ctypes.sizeof(H.TtsConfig) and cfg.apply_post_processing == 1
+    for bad in (0, cfg.struct_size - 4, cfg.struct_size + 4):
+        c2 = H.TtsConfig()
+        ctypes.memmove(ctypes.byref(c2), ctypes.byref(cfg), ctypes.sizeof(cfg))
+        c2.struct_size = bad
+        h = ctypes.c_void_p()
+        assert lib.tts_create(ctypes.byref(c2), 0, ctypes.byref(h)) == H.TTS_ERR_INVALID
+        assert b'struct_size' in lib.tts_last_error(None)
+
+
 def test_missing_library_fails_loudly(tmp_path):
     H = pkg('_hip')
     with pytest.raises(OSError):
