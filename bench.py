@@ -219,7 +219,7 @@ def rank_cpu_share(cpus, local_rank, local_world):
 def rank_env():
     """Environment and CPU binding of a rank process; returns what was applied (reported in the JSON line and compared
     between the two launch paths by tests/test_distributed_cpu.py).  The call path blocks in hipEventSynchronize and
-    hipStreamSynchronize (csrc/api.hip, tts_synthesize): eight ranks' host threads wandering over all cores of the node
+    hipStreamSynchronize (csrc/api_pipeline.hip, tts_synthesize): eight ranks' host threads wandering over all cores of the node
     wake each other's caches; each rank keeps to its share."""
     applied = {}
     if 'RANK' in os.environ:

@@ -103,7 +103,7 @@ int tts_set_stream(tts_handle_t h, void* hip_stream);
 /* Options: "use_graph" (launch-per-layer decoder loop replayed from a hipGraph; default 0; 1 is refused with
  * TTS_ERR_UNSUPPORTED when the process runs the library on a HIP runtime older than the one it was built with -- a host that
  * loads another ROCm's libamdhip64 first, e.g. by importing torch, serves the library with that one, and graph replays were
- * wrong on PyTorch's bundled 7.0 runtime; see csrc/api.hip), "profile" (record
+ * wrong on PyTorch's bundled 7.0 runtime; see csrc/api_internal.h, `use_graph`), "profile" (record
  * per-stage HIP events, default 0), "pipeline" (default 1: tts_synthesize runs the encoder and
  * the decoder loop of a call on a second stream so that they overlap the Griffin-Lim iterations of
  * the PREVIOUS call still in flight; inputs must be complete when the call is made, which is why 1 applies

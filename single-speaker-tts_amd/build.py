@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsstts_hip.so')
-SOURCES = ['gemm_f32.hip', 'cbhg_tail.hip', 'gru.hip', 'decoder.hip', 'decoder_persistent.hip', 'decoder_ws.hip', 'griffin_lim.hip', 'griffin_lim_generic.hip', 'reserve.hip', 'api.hip']
-HEADERS = ['tts_common.h', 'decoder.h', 'griffin_lim.h', os.path.join('..', '..', 'include', 'sstts_hip.h')]
+SOURCES = ['gemm_f32.hip', 'cbhg_tail.hip', 'gru.hip', 'decoder.hip', 'decoder_persistent.hip', 'decoder_ws.hip', 'griffin_lim.hip', 'griffin_lim_generic.hip', 'reserve.hip', 'api_handle.hip', 'api_stages.hip', 'api_pipeline.hip']
+HEADERS = ['tts_common.h', 'decoder.h', 'griffin_lim.h', 'api_internal.h', os.path.join('..', '..', 'include', 'sstts_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
 # Packed f32 VALU ops (v_pk_add/mul/fma_f32) issue slower than the two scalar ops they replace on gfx950 and
 # need aligned register pairs (extra v_mov); the SLP vectoriser forms them from complex arithmetic.  Measured

@@ -1,4 +1,4 @@
-// Decoder-loop internals shared between decoder.hip and api.hip.
+// Decoder-loop internals shared between decoder.hip and the api_*.hip files.
 #pragma once
 #include "tts_common.h"
 

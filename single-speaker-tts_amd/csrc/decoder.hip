@@ -19,7 +19,7 @@
 //    local (max, sum) and an unnormalised partial context; the attention-layer GEMM merges the
 //    partials in its A loader (flash-decoding style), and the alignment history is normalised
 //    once for all steps after the loop.
-//  * The whole loop is captured into one hipGraph by the caller (api.hip).
+//  * The whole loop is captured into one hipGraph by the caller (api_stages.hip).
 #include "tts_common.h"
 #include "decoder.h"
 #include <cstring>

@@ -27,7 +27,7 @@
 //     needs no cross-workgroup merge and the alignments are written normalised.
 // Every wait is bounded (PD_SPIN_LIMIT polls); on a timeout the status word is set, every workgroup of the grid
 // sees it at its next wait and the kernel drains.  All workgroups must be co-resident: the host only uses this
-// path when 8 * ceil(B / 16) compute units are free for it (api.hip).
+// path when 8 * ceil(B / 16) compute units are free for it (api_stages.hip).
 #include "tts_common.h"
 #include "decoder.h"
 #include <cstdio>
@@ -648,7 +648,7 @@ hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, co
     hipError_t e;
     if ((e = hipMemsetAsync(sc.state, 0, sc.state_bytes, s)) != hipSuccess) return e;
     // counters and resident count start at zero for every launch; the status word behind them is sticky (the host
-    // clears it when it has read it, api.hip), so a timeout is not lost when several calls are queued before a sync
+    // clears it when it has read it, api_handle.hip), so a timeout is not lost when several calls are queued before a sync
     if ((e = hipMemsetAsync(sync, 0, ((size_t)64 * clusters + 1) * sizeof(unsigned), s)) != hipSuccess) return e;
     PdParams p;
     p.w1 = w.prenet1_wt; p.b1 = w.prenet1_b; p.w1f = w.prenet1f_wt; p.b1f = w.prenet1f_b; p.w2 = w.prenet2_wt; p.b2 = w.prenet2_b;

@@ -22,7 +22,7 @@
 //     an sc1 load in one lane, then a workgroup barrier, then sc1 loads.  No cache-wide release / acquire, no grid barrier;
 //   * attention: workgroup j scores, normalises and contracts rows 2 j and 2 j + 1 of its cluster (4 waves each).
 // Every wait is bounded; on a timeout the sticky status word is set and the grid drains.  All workgroups must be
-// co-resident: 16 * ceil(B / 32) compute units (api.hip checks the budget).  Configurations this kernel does not cover
+// co-resident: 16 * ceil(B / 32) compute units (api_stages.hip checks the budget).  Configurations this kernel does not cover
 // (CudnnCompatibleGRUCell arithmetic, LocalLuongAttention, other layer sizes) run in decoder_persistent.hip / decoder.hip.
 #include "tts_common.h"
 #include "decoder.h"

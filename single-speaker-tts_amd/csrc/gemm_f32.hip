@@ -571,7 +571,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmBatch& b, int n_groups) {
     for (int i = 0; i < n_groups; ++i)
         if (pool && (!b.g[i].pool || b.g[i].C2)) return hipErrorInvalidValue;   // a pooled launch is homogeneous, never de-normalising
 #ifdef GEMM_EXPERIMENTS
-    // pre-split weight images: all groups of a launch or none (api.hip attaches them to every weight it launches with)
+    // pre-split weight images: all groups of a launch or none (api_stages.hip attaches them to every weight it launches with)
     bool pre = true;
     for (int i = 0; i < n_groups; ++i) pre = pre && b.g[i].Wimg != nullptr;
     if (b.ps) {

@@ -1,4 +1,4 @@
-// Griffin-Lim / audio kernel launchers shared between griffin_lim.hip and api.hip.
+// Griffin-Lim / audio kernel launchers shared between griffin_lim.hip and the api_*.hip files.
 #pragma once
 #include "tts_common.h"
 

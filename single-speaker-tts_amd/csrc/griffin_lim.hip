@@ -1163,7 +1163,7 @@ void gl_plan_stream(GlParams& p, int n_workers, int n_stage, int force_runs, int
     struct Cut { int L, n_full, rem; };
     Cut best{p.T, 1, 0};
     bool forced = false;
-    // tests / experiments only (per-handle options "gl_runs" / "gl_run_len" behind "debug_hooks", api.hip): a forced cut.
+    // tests / experiments only (per-handle options "gl_runs" / "gl_run_len" behind "debug_hooks", api_handle.hip): a forced cut.
     // Nothing in the process environment reaches this function: the cut is part of the waveform's bits.
     if (force_runs >= 1 && force_runs <= p.T) {   // runs per utterance
         const int L = ((p.T + force_runs - 1) / force_runs + GL_NW - 1) / GL_NW * GL_NW;
@@ -1263,7 +1263,7 @@ hipError_t launch_gl_stream(hipStream_t s, const GlParams& p_in, int n_cus, int 
     }
 #define GLS_LAUNCH(MODE, W, H, M) GLS_LAUNCH_N(MODE, W, H, M, 1)
     // only the model's window / hop pair is instantiated (both windows in registers, every span bound static): any other
-    // pair takes the general kernels of griffin_lim_generic.hip (api.hip: gl_is_streaming).  The run-time (WIN_CT = HOP_CT = 0)
+    // pair takes the general kernels of griffin_lim_generic.hip (api_stages.hip: gl_is_streaming).  The run-time (WIN_CT = HOP_CT = 0)
     // form of the kernel body stays in the source for the tools; it needed ~100 spilled registers per lane.
     if (!ref_cfg) return hipErrorInvalidValue;
 #ifdef GL_FAST_BUILD
@@ -1314,7 +1314,7 @@ void gl_build_wlane(const float* window, const float* rwss, int win, int hop, in
 
 static hipError_t stft_configure();
 
-// Function attributes are per device: called once per handle (on the handle's device) by api.hip.
+// Function attributes are per device: called once per handle (on the handle's device) by api_stages.hip.
 hipError_t gl_configure() {
     const hipError_t e = gl_stream_configure();
     return e != hipSuccess ? e : stft_configure();

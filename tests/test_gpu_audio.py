@@ -73,7 +73,7 @@ def test_griffin_lim_seeded_is_deterministic(engine):
 
 def test_griffin_lim_work_counter_ring_wraps(engine):
     """The work counters of the launches are slots of a 256-entry ring that is zeroed once; every launch zeroes the slot of the
-    launch before it (csrc/api.hip, gl_run).  More launches than slots on one handle: the result of a call does not depend
+    launch before it (csrc/api_stages.hip, gl_run).  More launches than slots on one handle: the result of a call does not depend
     on where in the ring it falls (a slot that was not cleared would hand a launch no work: frames left unwritten)."""
     rng = np.random.default_rng(14)
     mag = engine.to_device(synth_mag(rng, 2, 24))

@@ -67,7 +67,7 @@ def test_decoder(engine, hparams, weights64, B, Ts, S):
 def test_decoder_graph_matches_eager(engine):
     """Option "use_graph": the launch-per-layer decoder loop replayed from a cached hipGraph gives the bits of the directly
     enqueued launches -- on the HIP runtime the library was built with.  A process that loaded an older libamdhip64 first (this
-    suite's collection imports torch, which bundles HIP 7.0) is refused the option: replays were wrong there (csrc/api.hip)."""
+    suite's collection imports torch, which bundles HIP 7.0) is refused the option: replays were wrong there (csrc/api_internal.h, `use_graph`)."""
     rng = np.random.default_rng(7)
     memory = engine.to_device((rng.standard_normal((4, 21, 256))).astype(np.float32))
     engine.set_option('use_graph', 0)

@@ -112,7 +112,7 @@ def test_pipelined_full_size_calls_repeat_bit_identically(engine):
 def test_weight_stationary_decoder_same_bits_at_16_and_32_rows_per_cluster(engine, B, Ts, S):
     """decoder_ws.hip with 16 and with 32 utterances per cluster: the same K slices in the same order, four waves per
     attention row in both, independent MFMA rows -- mel spectrograms and alignments equal BIT FOR BIT, which is what lets the
-    library choose the form by what else is running (csrc/api.hip, decoder_impl)."""
+    library choose the form by what else is running (csrc/api_stages.hip, decoder_impl)."""
     rng = np.random.default_rng(900 + B)
     memory = engine.to_device((rng.standard_normal((B, Ts, 256)) * 1.2).astype(np.float32))
     out = {}

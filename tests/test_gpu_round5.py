@@ -271,7 +271,7 @@ def test_pipelined_synthesize_with_the_general_griffin_lim_kernels(engine):
 
 @pytest.mark.parametrize('peak', [True, False])
 def test_wide_last_griffin_lim_launches(engine, peak):
-    """Option "gl_wide_from" (api.hip, gl_wide_from()): the launches of a pipelined call from that index on are cut for all
+    """Option "gl_wide_from" (api_pipeline.hip, gl_wide_from()): the launches of a pipelined call from that index on are cut for all
     compute units instead of all but `reserve_cus`.  Another overlap-add order, so: equal to the one-cut form to the
     reconstruction's own rounding, bit-identical call after call, and the peak normalisation / the sample count intact."""
     B, S, n_iter = 24, 60, 12   # 300 frames, four launches of three iterations and the final one
@@ -305,7 +305,7 @@ def test_wide_last_griffin_lim_launches(engine, peak):
 
 def test_wide_launches_between_calls_of_other_shapes(engine):
     """The decoder of a call waits for the post-net of the call before it when the call two back ended its Griffin-Lim phase
-    in wide launches (api.hip, gl_wide_used): calls of two shapes alternate here, so the gate, the two cuts and the
+    in wide launches (api_pipeline.hip, gl_wide_used): calls of two shapes alternate here, so the gate, the two cuts and the
     workspaces of both shapes meet in one sequence.  Bit-identical run to run, equal to the one-cut form to rounding."""
     shapes = [(24, 60), (6, 30), (24, 60), (6, 30), (24, 60), (24, 60)]
     batches = [bench_ids(B, 100, 700 + i) for i, (B, _) in enumerate(shapes)]

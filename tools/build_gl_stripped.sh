@@ -14,5 +14,5 @@ $L/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $W/dev_stripped.
 $L/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared $W/dev.o -o $W/dev.out
 $L/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 -input=/dev/null -input=$W/dev.out -output=$W/dev.hipfb
 hipcc $CF --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang $W/dev.hipfb -c $R/single-speaker-tts_amd/csrc/griffin_lim.hip -o $W/gl.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/bin/lib_$name.so $B/gemm_f32.o $B/cbhg_tail.o $B/gru.o $B/decoder.o $B/decoder_persistent.o $B/decoder_ws.o $W/gl.o $B/griffin_lim_generic.o $B/reserve.o $B/api.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/bin/lib_$name.so $B/gemm_f32.o $B/cbhg_tail.o $B/gru.o $B/decoder.o $B/decoder_persistent.o $B/decoder_ws.o $W/gl.o $B/griffin_lim_generic.o $B/reserve.o $B/api_handle.o $B/api_stages.o $B/api_pipeline.o
 echo built $name

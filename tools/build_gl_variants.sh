@@ -9,7 +9,7 @@ mkdir -p $R/tools/bin
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -fno-slp-vectorize $flags -c $R/single-speaker-tts_amd/csrc/griffin_lim.hip -o $R/tools/bin/gl_$name.o \
-    && hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/bin/lib_$name.so $B/gemm_f32.o $B/cbhg_tail.o $B/gru.o $B/decoder.o $B/decoder_persistent.o $B/decoder_ws.o $R/tools/bin/gl_$name.o $B/griffin_lim_generic.o $B/reserve.o $B/api.o \
+    && hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/bin/lib_$name.so $B/gemm_f32.o $B/cbhg_tail.o $B/gru.o $B/decoder.o $B/decoder_persistent.o $B/decoder_ws.o $R/tools/bin/gl_$name.o $B/griffin_lim_generic.o $B/reserve.o $B/api_handle.o $B/api_stages.o $B/api_pipeline.o \
     && echo built $name ) &
 done
 wait

@@ -11,7 +11,7 @@ extra=""
 [ "$unit" = "griffin_lim.hip" ] && extra="-fno-slp-vectorize"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w $extra $flags -I$R/single-speaker-tts_amd/csrc -c $src -o $R/tools/bin/${name}_unit.o
 objs=""
-for u in gemm_f32 cbhg_tail gru decoder decoder_persistent decoder_ws griffin_lim griffin_lim_generic reserve api; do
+for u in gemm_f32 cbhg_tail gru decoder decoder_persistent decoder_ws griffin_lim griffin_lim_generic reserve api_handle api_stages api_pipeline; do
   if [ "$u.hip" = "$unit" ]; then objs="$objs $R/tools/bin/${name}_unit.o"; else objs="$objs $B/$u.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o $R/tools/bin/lib_$name.so $objs
