@@ -217,7 +217,7 @@ int stft_run(tts_handle_t h, const float* wav, int B, int n, int n_fft, int win,
 // ---- general path: any power-of-two n_fft, any window / hop (griffin_lim_generic.hip)
 int gl_fp(int n_fft) { return ((n_fft / 2 + 1) + 31) & ~31; }   // padded row length (TTS_GL_FP for 2048)
 // The streaming kernel is specialised to the model's configuration; everything else takes the general kernels.
-bool gl_is_streaming(int n_fft, int win, int hop) { return n_fft == TTS_GL_NFFT && win == 1102 && hop == 275; }
+bool gl_is_streaming(int n_fft, int win, int hop) { return n_fft == TTS_GL_NFFT && gl_stream_instantiated(win, hop); }
 
 // periodic hann (scipy get_window('hann', win, fftbins=True)), float64 then float32
 void hann_window(int win, std::vector<double>& wd, std::vector<float>& wf) {
@@ -337,7 +337,7 @@ int gl_run_generic(tts_handle_t h, const float* mag_int, const float* init_ft, u
 
 
 int gl_prepare(tts_handle_t h, int T, int win, int hop, int n_fft) {
-    if (!gl_is_streaming(n_fft, win, hop)) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: the streaming kernel runs the model's configuration only");
+    if (!gl_is_streaming(n_fft, win, hop)) return fail(h, TTS_ERR_UNSUPPORTED, "griffin_lim: the streaming kernel is instantiated for 1102 / 275 and 800 / 200 at n_fft 2048 only");
     if (win < 2 || win > n_fft || hop < 1 || T < 1)
         return fail(h, TTS_ERR_INVALID, "griffin_lim: need 2 <= win_length <= n_fft, hop_length >= 1, T >= 1");
     const int ncol = (win + hop - 1) / hop;

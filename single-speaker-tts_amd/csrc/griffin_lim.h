@@ -45,6 +45,7 @@ struct GlParams {
 void gl_build_wlane(const float* window, const float* rwss, int win, int hop, int T, float* out);
 // streaming form of the iteration / final iSTFT (gl_stream_kernel): no chunks, a run is one stream through an LDS ring
 int gl_stream_ring_frames(int win, int hop, int n_stage = 1);   // 0: the window / hop pair does not fit
+bool gl_stream_instantiated(int win, int hop);                  // the (window, hop) pairs gl_stream_kernel is compiled for (n_fft 2048)
 void gl_plan_stream(GlParams& p, int n_workers, int n_stage = 1, int force_runs = 0, int force_run_len = 0);  // needs T, B, win, hop, ncol; sets the item classes (cut for launches of n_stage iterations)
 hipError_t launch_gl_stream(hipStream_t s, const GlParams& p, int n_cus, int final_istft, int n_stage = 1);
 hipError_t gl_configure();

@@ -1243,6 +1243,37 @@ static hipError_t gl_stream_set_attr() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
+// The (window, hop) pairs the streaming kernel is instantiated for (both windows in registers, every span bound static): the
+// model's 50 ms / 12.5 ms at the reference's 22.05 kHz (1102 / 275, dataset_params.sampling_rate; audio/conversion.py:122-136)
+// and, round 6, the same 50 / 12.5 ms at 16 kHz (800 / 200).  Any other pair takes the general kernels of
+// griffin_lim_generic.hip.  The run-time (WIN_CT = HOP_CT = 0) form of the kernel body stays in the source for the tools; it
+// needed ~100 spilled registers per lane.
+bool gl_stream_instantiated(int win, int hop) { return (win == 1102 && hop == 275) || (win == 800 && hop == 200); }
+
+template <int W, int H>
+static hipError_t gl_stream_launch_wh(hipStream_t s, const GlParams& p, dim3 grid, size_t lds, int final_istft, int n_stage, bool mse) {
+#define GLS_LAUNCH_N(MODE, M, N)                                                                                         \
+    {                                                                                                                    \
+        if (MODE == 0 && p.seeded) hipLaunchKernelGGL((gl_stream_kernel<0, W, H, M, N, true>), grid, dim3(GL_THREADS), lds, s, p);   \
+        else hipLaunchKernelGGL((gl_stream_kernel<MODE, W, H, M, N, false>), grid, dim3(GL_THREADS), lds, s, p);        \
+    }
+#ifdef GL_FAST_BUILD
+    if (mse) return hipErrorInvalidValue;
+    if (final_istft) GLS_LAUNCH_N(1, false, 1)
+    else if (n_stage == 2) GLS_LAUNCH_N(0, false, 2)
+    else if (n_stage == 3) GLS_LAUNCH_N(0, false, 3)
+    else GLS_LAUNCH_N(0, false, 1)
+#else
+    if (n_stage == 3) GLS_LAUNCH_N(0, false, 3)
+    else if (n_stage == 2) GLS_LAUNCH_N(0, false, 2)
+    else if (final_istft) GLS_LAUNCH_N(1, false, 1)
+    else if (mse) GLS_LAUNCH_N(0, true, 1)
+    else GLS_LAUNCH_N(0, false, 1)
+#endif
+#undef GLS_LAUNCH_N
+    return hipGetLastError();
+}
+
 // p.work_counter must point at a zeroed counter that no other launch uses; p planned by gl_plan_stream.
 // n_stage = 2: two iterations in this launch (phase_in -> phase_out is then TWO Griffin-Lim iterations); not for the final
 // iSTFT and not with the mse.
@@ -1253,47 +1284,33 @@ hipError_t launch_gl_stream(hipStream_t s, const GlParams& p_in, int n_cus, int 
     if (p.ring_frames < GL_NW || n_stage < 1 || n_stage > 3 || (n_stage > 1 && (final_istft || p.mse_partial))) return hipErrorInvalidValue;
     const size_t lds = gl_stream_lds_bytes(p);
     const int nwg = p.n_items < n_cus ? p.n_items : n_cus;   // one workgroup per compute unit (256 registers x 8 waves)
-    dim3 grid(nwg);
-    const bool ref_cfg = p.win == 1102 && p.hop == 275;
+    const dim3 grid(nwg);
     const bool mse = p.mse_partial != nullptr;
-#define GLS_LAUNCH_N(MODE, W, H, M, N)                                                                                   \
-    {                                                                                                                    \
-        if (MODE == 0 && p.seeded) hipLaunchKernelGGL((gl_stream_kernel<0, W, H, M, N, true>), grid, dim3(GL_THREADS), lds, s, p);   \
-        else hipLaunchKernelGGL((gl_stream_kernel<MODE, W, H, M, N, false>), grid, dim3(GL_THREADS), lds, s, p);        \
-    }
-#define GLS_LAUNCH(MODE, W, H, M) GLS_LAUNCH_N(MODE, W, H, M, 1)
-    // only the model's window / hop pair is instantiated (both windows in registers, every span bound static): any other
-    // pair takes the general kernels of griffin_lim_generic.hip (api_stages.hip: gl_is_streaming).  The run-time (WIN_CT = HOP_CT = 0)
-    // form of the kernel body stays in the source for the tools; it needed ~100 spilled registers per lane.
-    if (!ref_cfg) return hipErrorInvalidValue;
-#ifdef GL_FAST_BUILD
-    if (mse) return hipErrorInvalidValue;
-    if (final_istft) GLS_LAUNCH(1, 1102, 275, false)
-    else if (n_stage == 2) GLS_LAUNCH_N(0, 1102, 275, false, 2)
-    else if (n_stage == 3) GLS_LAUNCH_N(0, 1102, 275, false, 3)
-    else GLS_LAUNCH(0, 1102, 275, false)
-#else
-    if (n_stage == 3) GLS_LAUNCH_N(0, 1102, 275, false, 3)
-    else if (n_stage == 2) GLS_LAUNCH_N(0, 1102, 275, false, 2)
-    else if (final_istft) GLS_LAUNCH(1, 1102, 275, false)
-    else if (mse) GLS_LAUNCH(0, 1102, 275, true)
-    else GLS_LAUNCH(0, 1102, 275, false)
+    if (p.win == 1102 && p.hop == 275) return gl_stream_launch_wh<1102, 275>(s, p, grid, lds, final_istft, n_stage, mse);
+#ifndef GL_FAST_BUILD
+    if (p.win == 800 && p.hop == 200) return gl_stream_launch_wh<800, 200>(s, p, grid, lds, final_istft, n_stage, mse);
 #endif
-#undef GLS_LAUNCH_N
-#undef GLS_LAUNCH
-    return hipGetLastError();
+    return hipErrorInvalidValue;
 }
 
-hipError_t gl_stream_configure() {
+template <int W, int H>
+static hipError_t gl_stream_configure_wh() {
     hipError_t e;
 #ifndef GL_FAST_BUILD
-    if ((e = gl_stream_set_attr<0, 1102, 275, true>()) != hipSuccess) return e;
+    if ((e = gl_stream_set_attr<0, W, H, true>()) != hipSuccess) return e;
 #endif
-    if ((e = gl_stream_set_attr<0, 1102, 275, false>()) != hipSuccess) return e;
-    if ((e = gl_stream_set_attr<0, 1102, 275, false, 2>()) != hipSuccess) return e;
-    if ((e = gl_stream_set_attr<0, 1102, 275, false, 3>()) != hipSuccess) return e;
-    if ((e = gl_stream_set_attr<1, 1102, 275, false>()) != hipSuccess) return e;
+    if ((e = gl_stream_set_attr<0, W, H, false>()) != hipSuccess) return e;
+    if ((e = gl_stream_set_attr<0, W, H, false, 2>()) != hipSuccess) return e;
+    if ((e = gl_stream_set_attr<0, W, H, false, 3>()) != hipSuccess) return e;
+    if ((e = gl_stream_set_attr<1, W, H, false>()) != hipSuccess) return e;
     return hipSuccess;
+}
+hipError_t gl_stream_configure() {
+    hipError_t e = gl_stream_configure_wh<1102, 275>();
+#ifndef GL_FAST_BUILD
+    if (e == hipSuccess) e = gl_stream_configure_wh<800, 200>();
+#endif
+    return e;
 }
 
 void gl_build_wlane(const float* window, const float* rwss, int win, int hop, int T, float* out) {

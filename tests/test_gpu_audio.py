@@ -233,6 +233,8 @@ def test_griffin_lim_forced_run_cuts(engine, run_len, per_launch, n_iter, want_m
     (512, 512, 128, 2, 50),        # win == n_fft, hop = win / 4 (librosa's defaults)
     (256, 200, 50, 1, 45),
     (2048, 1200, 300, 2, 40),      # the model's n_fft with another window / hop: the general kernels as well
+    (2048, 800, 200, 3, 60),       # 50 / 12.5 ms at 16 kHz: the streaming kernel's second instantiation (round 6)
+    (2048, 800, 200, 1, 260),      # ... several laps of its LDS ring
     (2048, 2048, 512, 1, 30),
 ])
 def test_griffin_lim_other_sizes_one_iteration(engine, n_fft, win, hop, B, T):
@@ -256,7 +258,7 @@ def test_griffin_lim_other_sizes_one_iteration(engine, n_fft, win, hop, B, T):
     assert rel_l2(wav0.to_host()[0], ref0) < 2e-5
 
 
-@pytest.mark.parametrize('n_fft,win,hop', [(1024, 800, 200), (4096, 2400, 600)])
+@pytest.mark.parametrize('n_fft,win,hop', [(1024, 800, 200), (4096, 2400, 600), (2048, 800, 200)])
 def test_griffin_lim_other_sizes_30_iterations(engine, n_fft, win, hop):
     """30 iterations: the mse (the reference's convergence measure, audio/synthesis.py:115) within 1 % of the oracle's and the
     same spectral convergence of the result; a seeded start is reproducible."""
@@ -295,3 +297,24 @@ def test_stft_and_mel_other_sizes(engine, n_fft, win, hop):
     assert mel.shape == rmel.shape == (80, 38) and rel_l2(mel, rmel) < 1e-5
     p2 = engine.stft_magnitude(y[None], n_fft, win, hop, 2.0).to_host()[0]
     assert rel_l2(p2, np.abs(ref) ** 2) < 1e-5
+
+
+@pytest.mark.parametrize('per_launch', [1, 2, 3])
+def test_streaming_kernel_second_window_iterations_per_launch(engine, per_launch):
+    """The streaming kernel's 800 / 200 instantiation (n_fft 2048: the reference's 50 ms / 12.5 ms at 16 kHz) with one, two and
+    three iterations per launch, runs cut by the planner for a batch that does not fit one run per workgroup: 7 iterations
+    against the oracle through the mse and sample-wise within the bound of test_griffin_lim_few_iterations."""
+    B, T, n_iter, win, hop = 3, 150, 7, 800, 200
+    rng = np.random.default_rng(800 + per_launch)
+    mag = ((rng.random((B, 1025, T)) ** 4) * 10).astype(np.float32)
+    init = rng.random((B, 1025, T)).astype(np.float32)
+    try:
+        engine.set_option('gl_pair', per_launch)
+        wav, mse = engine.griffin_lim(mag, n_iter, win, hop, N_FFT, init_phase=init, want_mse=True)
+    finally:
+        engine.set_option('gl_pair', 3)
+    wav, mse = wav.to_host(), mse.to_host()
+    for b in range(B):
+        ref_wav, ref_mse = A.griffin_lim_v2(mag[b], win, hop, N_FFT, n_iter, init_phase=init[b])
+        assert rel_l2(wav[b], ref_wav) < 1e-4 * n_iter, (per_launch, b)
+        assert abs(mse[b] - ref_mse) <= 1e-3 * ref_mse

@@ -269,6 +269,27 @@ def test_pipelined_synthesize_with_the_general_griffin_lim_kernels(engine):
         engine.set_option('persistent_decoder', 1)
 
 
+def test_synthesize_at_the_16_khz_window_runs_the_streaming_kernel(engine, weights64, hparams):
+    """win 800 / hop 200 (the reference's 50 ms / 12.5 ms at a 16 kHz sampling rate, audio/conversion.py:122-136) at the model's
+    n_fft: tts_synthesize reconstructs in the streaming kernel's second instantiation (round 6) -- same stages, same seeded
+    start -- and its waveform equals the staged path's (tts_griffin_lim on the de-normalised spectrogram: same kernel, same
+    cut) to rounding, the oracle's within the bounds of the 1102 / 275 tests."""
+    ids = bench_ids(3, 30, 21)
+    S, n_iter, win, hop = 12, 5, 800, 200
+    T = S * hparams.reduction
+    init = np.random.default_rng(16).random((3, 1025, T)).astype(np.float32)
+    out = engine.synthesize(ids, S, REF_DB, MAX_DB, POWER, n_iter, win, hop, init_phase=init, peak_normalize=True, want_mel=True,
+                            want_linear=True)
+    wav = out['wav'].to_host()
+    lin = out['linear'].to_host()
+    for b in range(3):
+        mag = A.linear_to_magnitude(lin[b], REF_DB, MAX_DB, POWER)
+        ref = A.peak_normalize(A.spectrogram_to_wav(mag, win, hop, 2048, n_iter, init_phase=init[b]))
+        assert ref.shape == wav[b].shape == (hop * (T - 1),)
+        assert rel_l2(wav[b], ref) < 1e-4 * n_iter, b
+    assert np.isfinite(wav).all() and np.abs(wav).max() > 0
+
+
 @pytest.mark.parametrize('peak', [True, False])
 def test_wide_last_griffin_lim_launches(engine, peak):
     """Option "gl_wide_from" (api_pipeline.hip, gl_wide_from()): the launches of a pipelined call from that index on are cut for all

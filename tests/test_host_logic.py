@@ -262,7 +262,7 @@ def _ring_frames(win, hop, n_stage=1):
 @pytest.mark.parametrize('win,hop,T,n_stage', [
     (1102, 275, 200, 1), (1102, 275, 75, 3), (1102, 275, 40, 2), (1024, 256, 40, 1), (1024, 256, 130, 3), (2048, 512, 100, 2),
     (400, 100, 150, 1), (64, 8, 300, 1), (2048, 1024, 30, 1), (1000, 250, 90, 2), (1101, 275, 50, 1), (2, 1, 700, 1),
-    (1500, 1400, 20, 1), (2047, 256, 60, 1), (1200, 300, 70, 3),
+    (1500, 1400, 20, 1), (2047, 256, 60, 1), (1200, 300, 70, 3), (800, 200, 130, 3), (800, 200, 45, 1),
 ])
 def test_stream_ring_emulation(win, hop, T, n_stage):
     """The index arithmetic of gl_stream_kernel, emulated in numpy with the frames' windowed signals as random vectors:
