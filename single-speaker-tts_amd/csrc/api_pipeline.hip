@@ -22,8 +22,14 @@ int gl_wide_from(tts_handle_t h, int B, int Ts, int n_steps, int T, int n_iter) 
     if (h->gl_wide >= 0) return h->gl_wide;    // (tools: an explicit launch index)
     if (pd != 2) return -1;                    // the streamed-weights decoder outlasts Griffin-Lim
     const int per_launch = h->gl_pair < 1 ? 1 : (h->gl_pair > 3 ? 3 : h->gl_pair);
-    const double launch_ms = 3.125e-6 * (double)B * T * per_launch;
-    const double dec_ms = (h->cfg.force_cudnn ? 0.038 : 0.045) * n_steps + 0.1;   // (seven hand-offs per step instead of ten: 6.9 ms alone)
+    // The constants were measured on 256 compute units with 32 reserved (224 for Griffin-Lim) at T_s = 150: a launch scales
+    // with the units Griffin-Lim really has, a decoder step with the memory length through its attention phase (8.9 of 44.5 us
+    // at T_s = 150: keys and values of the whole memory per step, decoder_ws.hip).  On a device of another size the model is
+    // not trusted at all: no wide launches there (they only ever cost time, never bits, but a wrong guess costs 0.5 ms a launch).
+    if (h->n_cus_dev != 256 || h->n_cus_dev - h->reserve_cus < 16) return -1;
+    const double launch_ms = 3.125e-6 * (double)B * T * per_launch * 224.0 / (double)(h->n_cus_dev - h->reserve_cus);
+    const double step_ms = (0.0356 + 0.0089 * (double)Ts / 150.0) * (h->cfg.force_cudnn ? 0.038 / 0.045 : 1.0);   // (seven hand-offs per step instead of ten)
+    const double dec_ms = step_ms * n_steps + 0.1;
     const int n_launches = (n_iter + per_launch - 1) / per_launch;
     const int from = (int)std::ceil((dec_ms + 0.5 * launch_ms + 0.1) / launch_ms);
     return from <= n_launches ? from : -1;

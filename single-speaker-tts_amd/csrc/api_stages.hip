@@ -737,7 +737,8 @@ int decoder_impl(tts_handle_t h, const float* memory, int B, int Ts, int n_steps
         if (ws_sync != h->pd_sync || clusters != h->pd_clusters)   // new buffer / new layout: the sticky status word starts clean
             HIPCHK(h, hipMemsetAsync(ws_sync + 64 * clusters + 1, 0, sizeof(unsigned), h->stream));
         HIPCHK(h, decoder_ws_enqueue(h->stream, h->dec, ws_scratch, yhist, memory, keys, B, Ts, n_steps, alignments, ws_sync,
-                                     h->cur_hold_flag, c.force_cudnn, h->debug_hooks ? h->pd_debug_delay : 0, rows, clusters));
+                                     h->cur_hold_flag, c.force_cudnn, h->debug_hooks ? h->pd_debug_delay : 0, rows, clusters, sc.p_hist,
+                                     sc.err_flag));
         h->pd_rows_used = rows;
         h->pd_sync = ws_sync;
         h->pd_clusters = clusters;

@@ -109,7 +109,7 @@ hipError_t decoder_persistent_enqueue(hipStream_t s, const DecoderWeights& w, co
                                       int* hold_flag, int cudnn, int dbg_delay);
 
 // ---- weight-stationary persistent form (decoder_ws.hip, round 5): clusters of 16 workgroups x 32 utterances, every
-// workgroup's share of the weights resident in registers; both GRU formulations, global attention only
+// workgroup's share of the weights resident in registers; both GRU formulations, global and (round 6) local attention
 #define DEC_WS_NREG 176          // weight registers per lane (172 used by the GRUCell form, 176 by the CudnnCompatibleGRUCell form)
 #define DEC_WS_BIAS_SLOTS 10     // b1 folded | b1 (step 0) | b2 | attention GRU gates, candidate | (attention layer: none) | 2 x (gates, candidate)
 struct WsParams {
@@ -122,6 +122,10 @@ struct WsParams {
     unsigned* counters; unsigned* resident; int* status; int* hold_flag;   // as PdParams
     int B, Ts, n_steps, dbg_delay;
     int cudnn;                                    // CudnnCompatibleGRUCell arithmetic (the register image is packed for it)
+    int local_d, local_gaussian, local_predictive;   // LocalLuongAttention (0 = global attention), as PdParams
+    const float *local_wp, *local_vp;
+    float* p_hist;                                // [n_steps][B] predicted window centres (predictive mode)
+    int* err_flag;                                // raised when a predicted window leaves the memory
 };
 struct DecWsHostWeights {                         // host pointers to the packed [N][K] matrices and biases of DecoderWeights
     const float *w1f, *b1f, *b1, *w2, *b2, *ag_w, *ag_b, *ac_w, *ac_b, *al_w;
@@ -141,6 +145,6 @@ hipError_t decoder_ws_configure();                // per device
 // `sync`: 64 * max(clusters, sync_clusters) + 2 unsigned words (counters, resident count, sticky status word)
 hipError_t decoder_ws_enqueue(hipStream_t s, const DecoderWeights& w, float* scratch, float* yhist, const float* memory,
                               const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync, int* hold_flag,
-                              int cudnn, int dbg_delay, int rows = 32, int sync_clusters = 0);
+                              int cudnn, int dbg_delay, int rows = 32, int sync_clusters = 0, float* p_hist = nullptr, int* err_flag = nullptr);
 
 }  // namespace tts

@@ -23,7 +23,7 @@
 //   * attention: workgroup j scores, normalises and contracts rows 2 j and 2 j + 1 of its cluster (4 waves each).
 // Every wait is bounded; on a timeout the sticky status word is set and the grid drains.  All workgroups must be
 // co-resident: 16 * ceil(B / 32) compute units (api_stages.hip checks the budget).  Configurations this kernel does not cover
-// (CudnnCompatibleGRUCell arithmetic, LocalLuongAttention, other layer sizes) run in decoder_persistent.hip / decoder.hip.
+// (other layer sizes or counts) run in decoder_persistent.hip / decoder.hip.
 #include "tts_common.h"
 #include "decoder.h"
 #include <cstring>
@@ -433,10 +433,21 @@ __device__ __forceinline__ void ws_phase_hx(const float (&w)[DEC_WS_NREG], const
 // _luong_score / _compute_attention; dot form at reference attention.py:396-400): softmax over ALL Ts positions, context =
 // alignments . memory.  FOUR waves per row in both forms (the same partial sums in the same order: a row's bits do not depend
 // on M); with one row the other four waves only keep the barriers.
-template <int M>
+// LOCAL: LocalLuongAttention (reference tacotron/attention.py:32-342; decoder.hip / decoder_persistent.hip have the other two
+// forms): only the window of 2D+1 positions around the step index (monotonic) or around the predicted centre
+// p = Ts sigmoid(v_p . tanh(W_p h)) is scored; the reported alignments are zero outside it and, with `gaussian`, weighted as
+// the reference writes it (attention.py:73-80); a predicted window that leaves the memory raises the error flag (the
+// reference's padding arithmetic fails there, attention.py:288-304).
+struct WsLocal {
+    int d, gaussian, predictive, step;
+    const float* wp; const float* vp;   // [256][256] (q @ W_p), [256]
+    float* p_hist_t;                    // [B] predicted centres of this step
+    int* err_flag;
+};
+template <int M, bool LOCAL>
 __device__ __forceinline__ void ws_attention(const float* __restrict__ query, const float* __restrict__ keys,
                                              const float* __restrict__ values, float* ctx, float* align_t, int Ts, float* lds,
-                                             int j, int b0, int B, unsigned* cnt, unsigned target, int* status) {
+                                             int j, int b0, int B, unsigned* cnt, unsigned target, int* status, const WsLocal& lc) {
     constexpr int RPW = M / 16;            // rows per workgroup
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));   // (see ws_phase)
@@ -461,17 +472,16 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
     // not depend on the query: the first WS_KB passes are requested BEFORE the wait for the cluster.
     const int sub = lane >> 4, l16 = lane & 15;
     float4 kpre[WS_KB][4];
-    auto load_keys = [&](const float* kbase, int j0) {
+    auto load_keys = [&](const float* kbase, int j0, int n_pos) {
 #pragma unroll
         for (int p = 0; p < WS_KB; ++p) {
             const int jj = j0 + 16 * p + hw * 4 + sub;
-            const float* kr = kbase + (size_t)(jj < Ts ? jj : Ts - 1) * WS_D;   // clamped, never branched on
+            const float* kr = kbase + (size_t)(jj < n_pos ? jj : n_pos - 1) * WS_D;   // clamped, never branched on
 #pragma unroll
             for (int i = 0; i < 4; ++i) kpre[p][i] = *reinterpret_cast<const float4*>(kr + (l16 + 16 * i) * 4);
         }
     };
-    const float* kb = keys + (size_t)mr * Ts * WS_D;
-    if (active) load_keys(kb, 0);
+    if (active && !LOCAL) load_keys(keys + (size_t)mr * Ts * WS_D, 0, Ts);   // (the window of the local form may depend on the query)
     WS_STAMP(0)
 
     ws_wait(cnt, target, status, ctrl);
@@ -483,9 +493,50 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
             ws_ld4(ws_rsrc(query), (unsigned)(((t256 >> 2) * M + rl) * 16 + 4 * (t256 & 3)) * 4u);
     __syncthreads();
 
+    // scored positions [w_lo, w_lo + w_n): the whole memory, or the local window
+    int w_lo = 0, w_n = Ts;
+    float pc = 0.f;   // window centre as the gaussian sees it
+    if (LOCAL) {
+        w_n = 2 * lc.d + 1;
+        if (lc.predictive) {
+            // (q W_p)[n] by thread n of the row's 256 (columns coalesced), then v_p . tanh(.) over them
+            float v = 0.f;
+            if (active) {
+                float a0 = 0.f, a1 = 0.f;
+                const float* wpn = lc.wp + t256;
+                for (int k = 0; k < WS_D; k += 2) {
+                    a0 = fmaf(qs[k], wpn[(size_t)k * WS_D], a0);
+                    a1 = fmaf(qs[k + 1], wpn[(size_t)(k + 1) * WS_D], a1);
+                }
+                v = tanhf_(a0 + a1) * lc.vp[t256];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                if (lane == 0) redm[hw] = v;
+            }
+            __syncthreads();
+            const float pp = (float)Ts * sigmoidf_((redm[0] + redm[1]) + (redm[2] + redm[3]));
+            const int c = (int)floorf(pp);
+            // a window that leaves the memory: the reference's padding arithmetic fails there (decoder.hip)
+            if (active && t256 == 0 && row_ok) {
+                lc.p_hist_t[row] = pp;
+                if (c - lc.d < 0 || c + lc.d + 1 > Ts) *lc.err_flag = 1;
+            }
+            w_lo = min(max(c - lc.d, 0), Ts - w_n);
+            pc = pp;
+            __syncthreads();   // redm is reused below
+        } else {
+            int c = lc.step > lc.d ? lc.step : lc.d;
+            const int hi = Ts - (lc.d + 1);
+            c = c < hi ? c : hi;
+            w_lo = c - lc.d;
+            pc = (float)c;
+        }
+    }
+    const float* kb = keys + ((size_t)mr * Ts + w_lo) * WS_D;
+
     if (active) {
-        for (int j0 = 0; j0 < Ts; j0 += 16 * WS_KB) {
-            if (j0 > 0) load_keys(kb, j0);
+        for (int j0 = 0; j0 < w_n; j0 += 16 * WS_KB) {
+            if (LOCAL || j0 > 0) load_keys(kb, j0, w_n);
 #pragma unroll
             for (int p = 0; p < WS_KB; ++p) {
                 const int jj = j0 + 16 * p + hw * 4 + sub;
@@ -503,7 +554,7 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
                 s += __shfl_xor(s, 4);
                 s += __shfl_xor(s, 2);
                 s += __shfl_xor(s, 1);
-                if (jj < Ts && l16 == 0) sc[jj] = s;
+                if (jj < w_n && l16 == 0) sc[jj] = s;
             }
         }
     }
@@ -512,7 +563,7 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
 
     float m = -INFINITY;
     if (active) {
-        for (int jj = t256; jj < Ts; jj += 256) m = fmaxf(m, sc[jj]);
+        for (int jj = t256; jj < w_n; jj += 256) m = fmaxf(m, sc[jj]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if (lane == 0) redm[hw] = m;
@@ -521,7 +572,7 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
     float sum = 0.f;
     if (active) {
         m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
-        for (int jj = t256; jj < Ts; jj += 256) {
+        for (int jj = t256; jj < w_n; jj += 256) {
             const float e = __expf(sc[jj] - m);
             sc[jj] = e;
             sum += e;
@@ -543,19 +594,19 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
     // WS_VB rows requested together
     WS_STAMP(3)
     if (active) {
-        const float* vb = values + (size_t)mr * Ts * WS_D + 4 * lane;
+        const float* vb = values + ((size_t)mr * Ts + w_lo) * WS_D + 4 * lane;
         float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int j0 = hw; j0 < Ts; j0 += 4 * WS_VB) {
+        for (int j0 = hw; j0 < w_n; j0 += 4 * WS_VB) {
             float4 vv[WS_VB];
 #pragma unroll
             for (int p = 0; p < WS_VB; ++p) {
                 const int jj = j0 + 4 * p;
-                vv[p] = *reinterpret_cast<const float4*>(vb + (size_t)(jj < Ts ? jj : Ts - 1) * WS_D);
+                vv[p] = *reinterpret_cast<const float4*>(vb + (size_t)(jj < w_n ? jj : w_n - 1) * WS_D);
             }
 #pragma unroll
             for (int p = 0; p < WS_VB; ++p) {
                 const int jj = j0 + 4 * p;
-                const float e = jj < Ts ? sc[jj] : 0.f;
+                const float e = jj < w_n ? sc[jj] : 0.f;
                 c0.x = fmaf(e, vv[p].x, c0.x); c0.y = fmaf(e, vv[p].y, c0.y); c0.z = fmaf(e, vv[p].z, c0.z); c0.w = fmaf(e, vv[p].w, c0.w);
             }
         }
@@ -584,11 +635,30 @@ __device__ __forceinline__ void ws_attention(const float* __restrict__ query, co
         ws_publish_wave(cnt, WS_ARRIVALS);
         WS_STAMP(6)
     }
-    if (active && align_t && row_ok)
-        for (int k = t256; k < Ts; k += 256) align_t[(size_t)row * Ts + k] = sc[k] * inv;
+    if (active && align_t && row_ok) {
+        if (!LOCAL) {
+            for (int k = t256; k < Ts; k += 256) align_t[(size_t)row * Ts + k] = sc[k] * inv;
+        } else {
+            // the reference pads the window back to the memory length (attention.py:85-92) and, with `gaussian`, weights it by
+            // exp(-(j - p)^2 / 2 * (D/2)^2) as written at attention.py:73-80 (the context uses the plain softmax)
+            const float gk = 0.5f * (0.5f * lc.d) * (0.5f * lc.d);
+            for (int k = t256; k < Ts; k += 256) {
+                const int jw = k - w_lo;
+                float a = 0.f;
+                if (jw >= 0 && jw < w_n) {
+                    a = sc[jw] * inv;
+                    if (lc.gaussian) {
+                        const float dist = (float)k - pc;
+                        a *= __expf(-(dist * dist) * gk);
+                    }
+                }
+                align_t[(size_t)row * Ts + k] = a;
+            }
+        }
+    }
 }
 
-template <bool CUDNN, int M>
+template <bool CUDNN, int M, bool LOCAL = false>
 __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
     constexpr int PRE = WS_D * M / 4 / WS_THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -671,8 +741,14 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
             ws_phase<M, WS_P2, 8, WS_D, 1, 16, WS_CAND, ACT_NONE, WS_R3, true, 4, false, false>(w, ph, lds, j, b0, p.B, cnt, p.status, pre);
         }
         WS_TL_PHASE(t, 4)
-        ws_attention<M>(h_att, p.keys, p.memory, ctx, p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr, p.Ts, lds, j, b0, p.B,
-                     cnt, per * g++, p.status);
+        {
+            WsLocal lc;
+            lc.d = p.local_d; lc.gaussian = p.local_gaussian; lc.predictive = p.local_predictive; lc.step = t;
+            lc.wp = p.local_wp; lc.vp = p.local_vp; lc.p_hist_t = p.p_hist ? p.p_hist + (size_t)t * p.B : nullptr;
+            lc.err_flag = p.err_flag;
+            ws_attention<M, LOCAL>(h_att, p.keys, p.memory, ctx, p.align ? p.align + (size_t)t * p.B * p.Ts : nullptr, p.Ts, lds, j, b0,
+                                   p.B, cnt, per * g++, p.status, lc);
+        }
         // attention_layer(concat([cell_output, context])), no bias
         ph.a0 = h_att; ph.a1 = ctx; ph.out = att; ph.bias_slot = 5; ph.target = per * g++; ph.next1 = h_d1_o;
         WS_TL_PHASE(t, 5)
@@ -714,7 +790,8 @@ __global__ __launch_bounds__(WS_THREADS) void dec_ws_kernel(WsParams p) {
 
 bool decoder_ws_supports(const DecoderWeights& w, int cudnn, int B, int Ts) {
     (void)cudnn;   // both GRU formulations (the register image is packed for the handle's)
-    return w.local_d == 0 && w.n_layers == 2 && w.att_units == WS_D && w.dec_units == WS_D && w.mem_units == WS_D &&
+    if (w.local_d > 0 && Ts < 2 * w.local_d + 1) return false;
+    return w.n_layers == 2 && w.att_units == WS_D && w.dec_units == WS_D && w.mem_units == WS_D &&
            w.prenet1_units == WS_D && w.prenet2_units == WS_P2 && w.n_mels <= WS_D && w.ws_wimg && w.ws_bimg && B >= 1 && Ts >= 1 &&
            ws_lds_bytes(Ts, 32) <= 160 * 1024 - 64 && (size_t)B * Ts * WS_D * 4 < 0xFFFFFFF0ull;
 }
@@ -729,8 +806,10 @@ size_t decoder_ws_scratch_floats(int B, int rows) {
 int decoder_ws_clusters(int B, int rows) { const int M = ws_rows(rows); return (B + M - 1) / M; }
 
 hipError_t decoder_ws_configure() {
-    const void* fns[4] = {reinterpret_cast<const void*>(&dec_ws_kernel<false, 32>), reinterpret_cast<const void*>(&dec_ws_kernel<true, 32>),
-                          reinterpret_cast<const void*>(&dec_ws_kernel<false, 16>), reinterpret_cast<const void*>(&dec_ws_kernel<true, 16>)};
+    const void* fns[8] = {reinterpret_cast<const void*>(&dec_ws_kernel<false, 32>), reinterpret_cast<const void*>(&dec_ws_kernel<true, 32>),
+                          reinterpret_cast<const void*>(&dec_ws_kernel<false, 16>), reinterpret_cast<const void*>(&dec_ws_kernel<true, 16>),
+                          reinterpret_cast<const void*>(&dec_ws_kernel<false, 32, true>), reinterpret_cast<const void*>(&dec_ws_kernel<true, 32, true>),
+                          reinterpret_cast<const void*>(&dec_ws_kernel<false, 16, true>), reinterpret_cast<const void*>(&dec_ws_kernel<true, 16, true>)};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         if (e != hipSuccess) return e;
@@ -821,7 +900,7 @@ size_t decoder_ws_bimg_floats() { return (size_t)WS_W * DEC_WS_BIAS_SLOTS * 32; 
 // rows: utterances per cluster (32: 16 compute units per 32 utterances; 16: per 16 -- same bits, see the LDS map)
 hipError_t decoder_ws_enqueue(hipStream_t s, const DecoderWeights& w, float* scratch, float* yhist, const float* memory,
                               const float* keys, int B, int Ts, int n_steps, float* align, unsigned* sync, int* hold_flag,
-                              int cudnn, int dbg_delay, int rows, int sync_clusters) {
+                              int cudnn, int dbg_delay, int rows, int sync_clusters, float* p_hist, int* err_flag) {
     const int M = ws_rows(rows);
     const int clusters = (B + M - 1) / M;
     // (the resident count and the sticky status word sit behind the counters of `sync_clusters` clusters: one place for
@@ -839,15 +918,23 @@ hipError_t decoder_ws_enqueue(hipStream_t s, const DecoderWeights& w, float* scr
     p.counters = sync; p.resident = sync + 64 * sync_clusters; p.status = reinterpret_cast<int*>(sync + 64 * sync_clusters + 1);
     p.hold_flag = hold_flag;
     p.B = B; p.Ts = Ts; p.n_steps = n_steps; p.dbg_delay = dbg_delay; p.cudnn = cudnn;
+    p.local_d = w.local_d; p.local_gaussian = w.local_gaussian; p.local_predictive = w.local_d > 0 && w.local_predictive;
+    p.local_wp = w.local_wp; p.local_vp = w.local_vp; p.p_hist = p_hist; p.err_flag = err_flag;
+    if (p.local_predictive) {
+        if (!p_hist || !err_flag) return hipErrorInvalidValue;
+        if ((e = hipMemsetAsync(err_flag, 0, sizeof(int), s)) != hipSuccess) return e;
+    }
     const dim3 grid(WS_W * clusters), block(WS_THREADS);
     const size_t lds = ws_lds_bytes(Ts, M);
-    if (M == 16) {
-        if (cudnn) hipLaunchKernelGGL((dec_ws_kernel<true, 16>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((dec_ws_kernel<false, 16>), grid, block, lds, s, p);
+#define WS_LAUNCH(C, MM, L) hipLaunchKernelGGL((dec_ws_kernel<C, MM, L>), grid, block, lds, s, p)
+    if (w.local_d > 0) {
+        if (M == 16) { if (cudnn) WS_LAUNCH(true, 16, true); else WS_LAUNCH(false, 16, true); }
+        else { if (cudnn) WS_LAUNCH(true, 32, true); else WS_LAUNCH(false, 32, true); }
     } else {
-        if (cudnn) hipLaunchKernelGGL((dec_ws_kernel<true, 32>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((dec_ws_kernel<false, 32>), grid, block, lds, s, p);
+        if (M == 16) { if (cudnn) WS_LAUNCH(true, 16, false); else WS_LAUNCH(false, 16, false); }
+        else { if (cudnn) WS_LAUNCH(true, 32, false); else WS_LAUNCH(false, 32, false); }
     }
+#undef WS_LAUNCH
 #ifdef WS_TIMELINE
     {
         (void)hipStreamSynchronize(s);

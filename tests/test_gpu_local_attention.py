@@ -24,6 +24,17 @@ def _setup(hparams, weights, D, gaussian):
     return hp, eng
 
 
+def _decoder_form(eng, form):
+    """form = (persistent_decoder, pd_ws, rows per cluster of the weight-stationary kernel) or just persistent_decoder:
+    the launch-per-layer decoder (decoder.hip), decoder_ws.hip with 32 / 16 utterances per cluster (round 6: it scores the
+    local window too), decoder_persistent.hip."""
+    pd, pd_ws, rows = form if isinstance(form, tuple) else (form, 1, 0)
+    eng.set_option('persistent_decoder', pd)
+    eng.set_option('pd_ws', pd_ws)
+    eng.set_option('debug_hooks', 1)
+    eng.set_option('pd_rows', rows)
+
+
 @pytest.mark.parametrize('B,Ts,S,D,gaussian', [
     (3, 21, 6, 10, True),      # window == memory
     (4, 60, 40, 10, True),     # window slides: steps 0..10 pinned left, then moves with t
@@ -31,10 +42,11 @@ def _setup(hparams, weights, D, gaussian):
     (5, 30, 12, 3, True),      # small D, 7 positions split over 4 attention slices
     (2, 150, 30, 1, False),    # 3 positions: some slices empty
 ])
-@pytest.mark.parametrize('pd', [0, 2], ids=['launch-per-layer', 'persistent'])
+@pytest.mark.parametrize('pd', [(0, 1, 0), (2, 1, 32), (2, 1, 16), (2, 0, 0)],
+                         ids=['launch-per-layer', 'weight-stationary-32', 'weight-stationary-16', 'streamed-weights'])
 def test_local_attention_decoder(hparams, weights, weights64, B, Ts, S, D, gaussian, pd):
     hp, eng = _setup(hparams, weights, D, gaussian)
-    eng.set_option('persistent_decoder', pd)
+    _decoder_form(eng, pd)
     try:
         rng = np.random.default_rng(100 * B + D)
         memory = rng.standard_normal((B, Ts, 256)).astype(np.float32) * 0.5
@@ -100,7 +112,7 @@ def test_local_short_memory_is_refused(hparams, weights, weights64, gaussian):
             O.tacotron_predict(ids, weights64, hp, n_steps=3)
         memory = np.zeros((1, 20, 256), np.float32)
         for pd in (0, 2):
-            eng.set_option('persistent_decoder', pd)
+            _decoder_form(eng, pd)
             with pytest.raises(pkg('_hip').TtsError) as ei:
                 eng.decoder_forward(memory, 3)
             assert ei.value.code == -5
@@ -142,12 +154,13 @@ def _setup_predictive(hparams, D, gaussian, seed=11, vp_scale=1.0, vp_shift=0.0)
 
 @pytest.mark.parametrize('B,Ts,S,D,gaussian,vp_scale', [(3, 60, 12, 10, True, 1.0), (4, 90, 20, 5, False, 4.0),
                                                         (2, 150, 9, 10, True, 8.0)])
-@pytest.mark.parametrize('pd', [0, 2], ids=['launch-per-layer', 'persistent'])
+@pytest.mark.parametrize('pd', [(0, 1, 0), (2, 1, 32), (2, 1, 16), (2, 0, 0)],
+                         ids=['launch-per-layer', 'weight-stationary-32', 'weight-stationary-16', 'streamed-weights'])
 def test_predictive_local_attention_decoder(hparams, B, Ts, S, D, gaussian, vp_scale, pd):
     """LocalLuongAttention in PREDICTIVE mode (reference tacotron/attention.py:246-258): the window centre
     p = T_s sigmoid(v_p^T tanh(W_p h)) is predicted per utterance and step; larger v_p spreads the centres."""
     hp, eng, w = _setup_predictive(hparams, D, gaussian, vp_scale=vp_scale)
-    eng.set_option('persistent_decoder', pd)
+    _decoder_form(eng, pd)
     try:
         assert len(eng.manifest()) == len(pkg('tacotron.weights').manifest(hp))
         rng = np.random.default_rng(7 * B + D)
@@ -168,13 +181,14 @@ def test_predictive_local_attention_decoder(hparams, B, Ts, S, D, gaussian, vp_s
         eng.close()
 
 
-@pytest.mark.parametrize('pd', [0, 2], ids=['launch-per-layer', 'persistent'])
+@pytest.mark.parametrize('pd', [(0, 1, 0), (2, 1, 32), (2, 1, 16), (2, 0, 0)],
+                         ids=['launch-per-layer', 'weight-stationary-32', 'weight-stationary-16', 'streamed-weights'])
 def test_predictive_window_leaving_the_memory_is_an_error(hparams, pd):
     """Where the predicted window leaves the memory the reference's padding arithmetic (attention.py:288-304)
     breaks and TensorFlow fails at run time; the library reports TTS_ERR_UNSUPPORTED, the oracle raises."""
     # T_s = 2D+1: only floor(p) == D keeps the window inside, and a large v_p spreads p = 21 sigmoid(.) well beyond
     hp, eng, w = _setup_predictive(hparams, 10, True, vp_scale=8.0)
-    eng.set_option('persistent_decoder', pd)
+    _decoder_form(eng, pd)
     try:
         memory = np.random.default_rng(1).standard_normal((2, 21, 256)).astype(np.float32)
         w64 = {k: v.astype(np.float64) for k, v in w.items()}
