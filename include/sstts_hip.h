@@ -111,8 +111,13 @@ int tts_set_stream(tts_handle_t h, void* hip_stream);
  * caller vouching for its inputs), "reserve_cus" (default 32: compute units kept free of
  * Griffin-Lim workgroups for that second stream, 0 = none), "hold_lds_kb" (default 64: LDS one sleeper workgroup
  * of that reservation allocates), "persistent_decoder" (the whole decoder loop as ONE launch of co-resident
- * workgroup clusters, two decoder GRU layers, at most 64 utterances under the pipeline: 1 = under the call pipeline
- * with more than 48 utterances per call, where it pays (default), 2 = whenever the configuration allows, 0 = never; tts_synchronize reports TTS_ERR_HIP if one of its bounded waits timed out),
+ * workgroup clusters; two decoder GRU layers, layer widths of the reference: 1 (default) = the weight-stationary kernel
+ * wherever it covers the configuration and its workgroups fit -- pipelined calls of up to 64 utterances, unpipelined calls of
+ * up to 512 -- with 16 or 32 utterances per cluster of 16 compute units as the free units allow (the same bits either way,
+ * so a call's spectrograms do not depend on what the handle ran before); 2 = any persistent kernel whenever the configuration
+ * allows; 0 = never: one launch per layer; tts_synchronize reports TTS_ERR_HIP if one of its bounded waits timed out),
+ * "deterministic" (default 0; 1: the waveform, too, is the same bits whether a call was pipelined or not -- every call
+ * takes the pipelined calls' Griffin-Lim run cut and none the second, wide one; costs a pipelined step ~0.25 ms),
  * "gl_pair" (Griffin-Lim iterations per launch, 1..3, default 3: the spectrum passes from one iteration to the next in
  * registers; identical arithmetic per iteration), "gl_wide_from" (pipelined calls: the first Griffin-Lim launch that is cut
  * for all compute units instead of all but "reserve_cus" -- the next call's decoder has left them by then; -1 (default) =
@@ -128,12 +133,18 @@ int tts_set_stream(tts_handle_t h, void* hip_stream);
  * every persistent-decoder cluster stages its tile that many x ~3.4 us late), "gl_runs" / "gl_run_len" (force the cut of
  * an utterance's frames into Griffin-Lim runs: runs per utterance / frames per run; the cut is part of the waveform's
  * rounding), "gl_workers" (plan and launch Griffin-Lim for that many workgroups instead of one per free compute unit),
+ * "pd_rows" (16 / 32: utterances per cluster of the weight-stationary decoder instead of the library's choice),
  * "timeline" (tts_profile_get prints the absolute times of every profiled span); tts_debug_hold.
  * Initial phases of Griffin-Lim: `init_phase` (a (B, F, T) array of U[0,1) numbers, angle = 2 pi u) or, when it is NULL,
  * a counter-based draw from `seed` made inside the first iteration's launch (the reference draws np.random.rand per call,
  * audio/synthesis.py:91). */
 int tts_set_option(tts_handle_t h, const char* key, int value);
 int tts_synchronize(tts_handle_t h);
+
+/* Numerics: float32 throughout.  The dense and convolution layers form their f32 products from exact three-way bf16 splits of
+ * both operands on the bf16 matrix pipe (same measured error against float64 as f32-input MFMA, tests/test_gpu_gemm.py).  One
+ * difference from IEEE f32 arithmetic on non-finite values: an output that depends on a +-Inf operand is NaN (the split of Inf
+ * contains Inf - Inf), not +-Inf; NaN operands give NaN; every output that depends on finite operands only is unaffected. */
 
 /* ---- weights: replaces tf.train.Saver().restore (tacotron/inference.py:55,71) ---------- */
 /* Manifest: names follow the TF variable scopes (see single-speaker-tts_amd/tacotron/weights.py). */
