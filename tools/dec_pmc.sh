@@ -17,7 +17,7 @@ i=0
 for G in "$G1" "$G2" "$G3" "$G4" "$G5"; do
   i=$((i+1))
   rm -rf $OUT/p$i
-  rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT/p$i -- python3 $R/tools/dec_bench.py 64 persistent $DEC_ARGS > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
+  rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT/p$i -- python3 $R/tools/dec_bench.py 64 persistent ${DEC_ARGS:-rows32} > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
   echo "pass $i done"
 done
 python3 $R/tools/pmc_summary.py $OUT dec_ws_kernel dec_persistent_kernel > $R/gpurun_out/${TAG}_dec_pmc.txt

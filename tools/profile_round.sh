@@ -1,11 +1,13 @@
 #!/bin/bash
-# Everything profiles/ holds for a round, in one gpurun call:   bash tools/profile_round.sh r02
+# Everything profiles/ holds for a round:   bash tools/profile_round.sh r06 [A|B]   (two gpurun calls of <= 20 minutes: parts A and B)
 # (counter passes never share a run with a trace domain other than the kernel trace)
-TAG=${1:-r05}
+TAG=${1:-r06}
+PART=${2:-AB}   # A: bench, kernel stats, Griffin-Lim counters; B: GEMM counters, timeline, driver's form, decoder counters, stage benchmarks
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+if [[ $PART == *A* ]]; then
 echo "== bench"; python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/bench.err; tail -c 400 $O/${TAG}_bench.json; echo
 for PL in 1 0; do
   rm -rf $O/stats$PL
@@ -40,6 +42,8 @@ print(out)
 PY
 echo "== GL SQ counters"; bash $R/tools/gl_pmc.sh $TAG > $O/gl_pmc.log 2>&1; cp $R/gpurun_out/${TAG}_gl_pmc.txt $O/${TAG}_gl_iter_sq_counters.txt
 python3 $R/tools/gl_counters_json.py $O/${TAG}_gl_iter_sq_counters.txt $O/${TAG}_gl_iter_valu.json 3
+fi
+if [[ $PART == *B* ]]; then
 echo "== GEMM MFMA counters"
 G1="SQ_INSTS_VALU_MFMA_BF16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"
 G2="SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
@@ -53,3 +57,4 @@ echo "== decoder L2 counters"; ( cd $R && bash tools/dec_pmc.sh ${TAG} ) > $O/de
 echo "== stage benchmarks"
 ( echo "# tools/gemm_bench.py"; python3 $R/tools/gemm_bench.py; echo; echo "# tools/net_bench.py"; python3 $R/tools/net_bench.py; echo; echo "# tools/dec_bench.py"; python3 $R/tools/dec_bench.py; echo; echo "# tools/gl_bench.py"; python3 $R/tools/gl_bench.py; echo; echo "# tools/latency_bench.py"; python3 $R/tools/latency_bench.py; echo; echo "# tools/pipeline_sweep.py"; python3 $R/tools/pipeline_sweep.py ) > $O/${TAG}_stage_benchmarks.txt 2>&1
 tail -12 $O/${TAG}_stage_benchmarks.txt
+fi
