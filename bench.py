@@ -393,6 +393,8 @@ def gl_beside_decoder(sstts, eng, hp, blob, ids, mags, B, T, dev_cus, reserve, p
             eng2.set_stream(decoder_stream)
         eng2.load_weights_blob(blob)
         eng2.set_option('persistent_decoder', 2)
+        eng2.set_option('debug_hooks', 1)
+        eng2.set_option('pd_rows', 32)   # the pipeline's form: 32 workgroups on the `reserve` units (a stand-alone call would take 64)
         mem2 = eng2.encoder_forward(ids)
         mel2, al2 = eng2.decoder_forward(mem2, n_steps)
         eng2.synchronize()
