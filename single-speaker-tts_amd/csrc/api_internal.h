@@ -137,7 +137,7 @@ struct tts_handle_s {
     //  call pipeline: `defer_projection`.  On the front stream behind its decoder it gave the same 14.45 ms per step in round 5;
     //  the option that switched it is gone)
     bool ws_configured = false;
-    // Round 5's two GEMM variants, measured and not faster (profiles/r05_experiment_gemm_presplit.txt): weights
+    // Round 5's two GEMM variants, measured and not faster (profiles/r05_experiment_gemm_presplit.txt, HISTORY.md part C): weights
     // pre-split into the kernel's bf16 LDS images ("gemm_presplit": images made on first use per weight matrix, keyed by its
     // address in the arena; tts_finalize_weights drops them) and the producer / consumer form of the kernel ("gemm_ps").  Their
     // kernels are only compiled into a tools build of gemm_f32.hip (-DGEMM_EXPERIMENTS); the shipped library refuses both options.

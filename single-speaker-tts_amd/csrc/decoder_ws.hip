@@ -5,7 +5,7 @@
 // helpers.py:83-110,161-205; TF-1.8 GRUCell form, global LuongAttention).  What changed against decoder_persistent.hip:
 // there a cluster of 8 workgroups x 16 utterances re-streamed its share of the 6 MB of weights from L2 in EVERY step
 // (128 KB per workgroup and phase: 101 M L2 read requests = 12.6 GB per launch for an algorithmic 44 MB, 20 of the 78 us of
-// a step by ablation: profiles/r04_decoder_l2_counters.txt).  Here
+// a step by ablation: profiles/r04_decoder_l2_counters.txt, HISTORY.md part C).  Here
 //   * a CLUSTER is 16 workgroups (one per CU, 512 threads = 2 waves per SIMD, 256 registers per lane) x 32 utterances;
 //     workgroup j owns units [16 j, 16 j + 16) of every 256-unit layer (for a GRU its r AND u columns: the update gate
 //     and the cell state of its units never leave its LDS) and units [8 j, 8 j + 8) of pre-net 2;

@@ -80,7 +80,7 @@ __device__ __forceinline__ float4 max4(float4 a, float4 b) {
 // powf out of the register allocation of every other GEMM)
 // POOL: instantiation whose A loader takes max(x[t], x[t+1]) (the two k = 3 projections that follow a max-pool): kept
 // apart so that every other GEMM carries neither its second load nor its registers.
-// PRE and PS are round 5's two measured-and-not-faster variants (profiles/r05_experiment_gemm_presplit.txt).
+// PRE and PS are round 5's two measured-and-not-faster variants (HISTORY.md part C, profiles/r05_experiment_gemm_presplit.txt).
 // They stay in the body's source as template parameters, but the shipped library instantiates neither: only a tools build
 // with -DGEMM_EXPERIMENTS (tools/build_variant.sh) compiles their kernels and accepts the options "gemm_presplit" / "gemm_ps".
 // PRE: the weights come PRE-SPLIT (round 5): `g.Wimg` holds, per 128-row block of N and per k tile in the order the k loop

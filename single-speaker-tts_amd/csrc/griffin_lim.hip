@@ -427,7 +427,7 @@ __device__ __forceinline__ cf gl_normalise(cf x, float mag) {
 }
 // The state of a bin between launches: the 32-bit phasor code (4 B in, 4 B out per bin and launch, 7 + 6 VALU instructions to
 // decode / encode).  (Round 4 measured the raw spectrum value instead -- 8 B each way, decoded by the normalisation, encoded
-// by nothing: the bytes cost more than the instructions; that build switch is in git history.)
+// by nothing: the bytes cost more than the instructions, HISTORY.md part C; that build switch is in git history.)
 typedef unsigned gl_state_t;
 __device__ __forceinline__ gl_state_t gl_state_encode(cf x) { return gl_pack_phasor(x); }
 __device__ __forceinline__ cf gl_state_decode(gl_state_t s, float mag) { return gl_unpack_phasor(s, mag); }
