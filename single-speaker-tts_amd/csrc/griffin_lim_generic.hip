@@ -14,9 +14,17 @@
 //   glg_stft_kernel    one workgroup per frame: reflect-padded, windowed samples -> FFT -> the new unit phasors (or the
 //                      complex spectrum for tts_stft), optionally the frame's squared magnitude error
 //                                                                                 (librosa.stft, synthesis.py:108-112)
-// The state between iterations is a float2 unit phasor per bin.  FFT: iterative radix-2 on bit-reversed input, twiddles
-// from a table computed in double precision on the host.  Not tuned: bound by HBM (the windowed frames make a round trip)
-// and by one barrier per FFT stage; the configuration the path is measured on runs in griffin_lim.hip.
+// The state between iterations is a float2 unit phasor per bin.  FFT (round 6): the real n_fft-point transforms run as
+// n_fft / 2-point COMPLEX transforms of (even, odd) sample pairs with a split / merge pass (as in griffin_lim.hip), in place in LDS
+// on bit-reversed input, two radix-2 stages per pass (a radix-4 butterfly in registers: half the passes, barriers and LDS
+// traffic of the radix-2 form), twiddles from a table computed in double precision on the host; a frame's workgroup is a quarter
+// of the half-size transform's points (64 ... 256 threads: one radix-4 group per thread and pass).  4.4 x less LDS traffic per
+// frame than round 4's full-size radix-2 transform, which bounded these kernels.  Measured per iteration at B = 64, T = 1000
+// (tools/gl_generic_bench.py): n_fft 4096 / 2400 / 600 5365 -> 1909 us, 2048 / 1200 / 300 2156 -> 928, 1024 / 800 / 200
+// 1012 -> 524, 512 / 400 / 100 481 -> 251 (the streaming kernel at 2048: 239).  What is left is mostly HBM: a float2 phasor per
+// bin written and read, and the windowed frames' round trip -- 30 KB per frame and iteration at 2048 / 1200 / 300 against the
+// streaming kernel's 8 (32-bit phasor codes, overlap-add in LDS).  Still one workgroup per frame: the configurations the path
+// is measured on run in griffin_lim.hip.
 #include "tts_common.h"
 #include "griffin_lim.h"
 
@@ -28,17 +36,44 @@ typedef float gcf __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ gcf gmul(gcf a, gcf b) { return (gcf){a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 
-// in-place radix-2 decimation-in-time FFT of `a` (N = 1 << m complex values in LDS, ALREADY in bit-reversed order);
-// tw[k] = exp(-2 pi i k / N), k < N / 2; INVERSE conjugates the twiddles (no 1/N scale)
+__device__ __forceinline__ gcf gconj(gcf a) { return (gcf){a.x, -a.y}; }
+__device__ __forceinline__ gcf gmul_i(gcf a) { return (gcf){-a.y, a.x}; }     // i a
+__device__ __forceinline__ gcf gmul_mi(gcf a) { return (gcf){a.y, -a.x}; }    // -i a
+
+// In-place decimation-in-time FFT of `a`: M = 1 << mm complex values in LDS, ALREADY in bit-reversed order.  tw[k] =
+// exp(-2 pi i k / (2 M)), k < M (the table of the real transform of 2 M points): W_M^j = tw[2 j].  INVERSE conjugates the
+// twiddles (no 1 / M scale).  Two radix-2 stages per pass: the four values (base + q half, q < 4) of a radix-4 group go through
+// stage s (pairs (0,1), (2,3), one twiddle) and stage s + 1 (pairs (0,2), (1,3), twiddles w and -i w) in registers; a last single
+// stage when mm is odd.
 template <bool INVERSE>
-__device__ __forceinline__ void glg_fft(gcf* a, const gcf* __restrict__ tw, int N, int m) {
-    for (int s = 1; s <= m; ++s) {
+__device__ __forceinline__ void glg_fft(gcf* a, const gcf* __restrict__ tw, int M, int mm) {
+    int s = 1;
+    for (; s + 1 <= mm; s += 2) {
         const int half = 1 << (s - 1);
         __syncthreads();
-        for (int i = threadIdx.x; i < N / 2; i += GLG_THREADS) {
+        for (int i = threadIdx.x; i < M / 4; i += blockDim.x) {
+            const int j = i & (half - 1);
+            const int base = ((i - j) << 2) + j;
+            gcf w1 = tw[(j << (mm - s)) << 1];          // stage s:     W_M^(j M / 2^s)
+            gcf w2 = tw[(j << (mm - s - 1)) << 1];      // stage s + 1: W_M^(j M / 2^(s+1)); its partner at j + half is -i (forward) times that
+            if (INVERSE) { w1.y = -w1.y; w2.y = -w2.y; }
+            const gcf x0 = a[base], x1 = gmul(a[base + half], w1), x2 = a[base + 2 * half], x3 = gmul(a[base + 3 * half], w1);
+            const gcf u0 = x0 + x1, u1 = x0 - x1, u2 = gmul(x2 + x3, w2);
+            const gcf t3 = gmul(x2 - x3, w2);
+            const gcf u3 = INVERSE ? gmul_i(t3) : gmul_mi(t3);
+            a[base] = u0 + u2;
+            a[base + half] = u1 + u3;
+            a[base + 2 * half] = u0 - u2;
+            a[base + 3 * half] = u1 - u3;
+        }
+    }
+    if (s == mm) {   // one radix-2 stage left
+        const int half = 1 << (s - 1);
+        __syncthreads();
+        for (int i = threadIdx.x; i < M / 2; i += blockDim.x) {
             const int j = i & (half - 1);
             const int base = ((i - j) << 1) + j;
-            gcf w = tw[j << (m - s)];
+            gcf w = tw[(j << (mm - s)) << 1];
             if (INVERSE) w.y = -w.y;
             const gcf u = a[base], v = gmul(a[base + half], w);
             a[base] = u + v;
@@ -59,20 +94,27 @@ __global__ __launch_bounds__(GLG_THREADS) void glg_istft_kernel(const float* __r
     gcf* a = reinterpret_cast<gcf*>(smem);
     const int t = blockIdx.x, b = blockIdx.y;
     const size_t row = ((size_t)b * T + t) * Fp;
-    const int H = N >> 1;
-    for (int k = threadIdx.x; k <= H; k += GLG_THREADS) {
-        const float s = mag[row + k];
-        const gcf e = ph[row + k];
-        gcf x = (gcf){s * e.x, s * e.y};
-        if (k == 0 || k == H) x.y = 0.f;   // irfft ignores them
-        a[glg_bitrev(k, m)] = x;
-        if (k > 0 && k < H) a[glg_bitrev(N - k, m)] = (gcf){x.x, -x.y};
+    // real inverse transform of N = 2 M points as a complex one of M: with z[n] = x[2n] + i x[2n+1],
+    //   Z[k] = (X[k] + conj X[M-k]) + i conj(W_N^k) (X[k] - conj X[M-k])   (= 2 FFT_M(z)[k]),   x = IFFT_M(Z) / N
+    const int M = N >> 1, mm = m - 1;
+    for (int k = threadIdx.x; k < M; k += blockDim.x) {
+        const float s0 = mag[row + k], s1 = mag[row + M - k];
+        const gcf e0 = ph[row + k], e1 = ph[row + M - k];
+        gcf xk = (gcf){s0 * e0.x, s0 * e0.y}, xm = (gcf){s1 * e1.x, s1 * e1.y};
+        if (k == 0) { xk.y = 0.f; xm.y = 0.f; }   // irfft ignores the imaginary parts of the DC and Nyquist bins
+        const gcf cm = gconj(xm);
+        const gcf d = gmul(gconj(tw[k]), xk - cm);
+        a[glg_bitrev(k, mm)] = (xk + cm) + gmul_i(d);
     }
-    glg_fft<true>(a, tw, N, m);
+    glg_fft<true>(a, tw, M, mm);
     const int pad = (N - win) >> 1;
     const float inv = 1.0f / (float)N;
     float* out = frames + ((size_t)b * T + t) * win;
-    for (int j = threadIdx.x; j < win; j += GLG_THREADS) out[j] = window[j] * (a[pad + j].x * inv);
+    for (int j = threadIdx.x; j < win; j += blockDim.x) {
+        const int n = pad + j;
+        const gcf z = a[n >> 1];
+        out[j] = window[j] * (((n & 1) ? z.y : z.x) * inv);
+    }
 }
 
 // wav[b][s] = rwss[s + N/2] * sum_t frames[b][t][s + N/2 - t hop - pad], frames in increasing t; s < L = hop (T - 1)
@@ -108,23 +150,32 @@ __global__ __launch_bounds__(GLG_THREADS) void glg_stft_kernel(const float* __re
     const int H = N >> 1, pad = (N - win) >> 1;
     const float* y = wav + (size_t)b * n;
     const int y0 = t * hop - H;               // signal index of padded-frame sample 0
-    for (int j = threadIdx.x; j < N; j += GLG_THREADS) {
-        float x = 0.f;
+    // real transform of N = 2 M points as a complex one of M: z[n] = x[2n] + i x[2n+1], Z = FFT_M(z),
+    //   X[k] = ((Z[k] + conj Z[M-k]) - i W_N^k (Z[k] - conj Z[M-k])) / 2,  k <= M  (Z[M] = Z[0])
+    const int M = N >> 1, mm = m - 1;
+    auto sample = [&](int j) -> float {
         const int jw = j - pad;
-        if (jw >= 0 && jw < win) {
-            int yi = y0 + j;
-            yi = yi < 0 ? -yi : yi;                       // reflect (numpy.pad mode='reflect')
-            yi = yi >= n ? 2 * (n - 1) - yi : yi;
-            x = window[jw] * y[yi];
-        }
-        a[glg_bitrev(j, m)] = (gcf){x, 0.f};
-    }
-    glg_fft<false>(a, tw, N, m);
+        if (jw < 0 || jw >= win) return 0.f;
+        int yi = y0 + j;
+        yi = yi < 0 ? -yi : yi;                           // reflect (numpy.pad mode='reflect')
+        yi = yi >= n ? 2 * (n - 1) - yi : yi;
+        return window[jw] * y[yi];
+    };
+    for (int q = threadIdx.x; q < M; q += blockDim.x) a[glg_bitrev(q, mm)] = (gcf){sample(2 * q), sample(2 * q + 1)};
+    glg_fft<false>(a, tw, M, mm);
     const size_t row = ((size_t)b * Tf + t) * Fp;
     float err = 0.f;
-    for (int k = threadIdx.x; k < Fp; k += GLG_THREADS) {
+    for (int k = threadIdx.x; k < Fp; k += blockDim.x) {
         gcf z = (gcf){0.f, 0.f};
-        if (k <= H) z = a[k];
+        if (k <= H) {
+            const gcf zk = a[k & (M - 1)], zm = gconj(a[(M - k) & (M - 1)]);
+            if (k == 0) z = (gcf){zk.x + zk.y, 0.f};
+            else if (k == M) z = (gcf){zk.x - zk.y, 0.f};
+            else {
+                const gcf e = zk + zm, d = gmul(tw[k], zk - zm);
+                z = (gcf){0.5f * (e.x + d.y), 0.5f * (e.y - d.x)};   // (e - i d) / 2
+            }
+        }
         if (MODE == 1) {
             out[row + k] = z;
         } else {
@@ -143,7 +194,11 @@ __global__ __launch_bounds__(GLG_THREADS) void glg_stft_kernel(const float* __re
         for (int o = 32; o > 0; o >>= 1) err += __shfl_xor(err, o);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = err;
         __syncthreads();
-        if (threadIdx.x == 0) mse_partial[(size_t)b * Tf + t] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (threadIdx.x == 0) {   // (fixed order over the workgroup's waves: 1, 2 or 4)
+            float e = red[0];
+            for (int w = 1; w < (int)(blockDim.x >> 6); ++w) e += red[w];
+            mse_partial[(size_t)b * Tf + t] = e;
+        }
     }
 }
 
@@ -170,7 +225,9 @@ __global__ void glg_phase_init_kernel(const float* __restrict__ init_ft, unsigne
     }
 }
 
-static size_t glg_lds(int N) { return (size_t)N * sizeof(gcf); }
+// threads per frame: a quarter of the half-size transform's points (one radix-4 group each), 64 ... 256
+static int glg_threads(int N) { const int t = N / 8; return t < 64 ? 64 : (t > GLG_THREADS ? GLG_THREADS : t); }
+static size_t glg_lds(int N) { return (size_t)(N / 2) * sizeof(gcf); }   // the half-size complex transform of a real frame
 
 hipError_t glg_configure() {
     hipError_t e;
@@ -196,7 +253,7 @@ hipError_t launch_glg_phase_init(hipStream_t s, const float* init_ft, uint64_t s
 hipError_t launch_glg_istft(hipStream_t s, const float* mag, const float2* ph, const float* window, const float* rwss, const float2* tw,
                             float* frames, float* wav, int B, int T, int Fp, int n_fft, int win, int hop) {
     const int m = glg_log2(n_fft);
-    hipLaunchKernelGGL(glg_istft_kernel, dim3(T, B), dim3(GLG_THREADS), glg_lds(n_fft), s, mag, reinterpret_cast<const gcf*>(ph), window,
+    hipLaunchKernelGGL(glg_istft_kernel, dim3(T, B), dim3(glg_threads(n_fft)), glg_lds(n_fft), s, mag, reinterpret_cast<const gcf*>(ph), window,
                        reinterpret_cast<const gcf*>(tw), frames, T, Fp, n_fft, m, win);
     const int L = hop * (T - 1);
     hipLaunchKernelGGL(glg_ola_kernel, dim3((L + 255) / 256 > 1024 ? 1024 : (L + 255) / 256, B), dim3(256), 0, s, frames, rwss, wav, T, n_fft,
@@ -208,10 +265,10 @@ hipError_t launch_glg_stft(hipStream_t s, const float* wav, int n, const float* 
                            int n_fft, int win, int hop, int mode, const float* mag, float* mse_partial) {
     const int m = glg_log2(n_fft);
     if (mode == 1)
-        hipLaunchKernelGGL((glg_stft_kernel<1>), dim3(Tf, B), dim3(GLG_THREADS), glg_lds(n_fft), s, wav, n, window,
+        hipLaunchKernelGGL((glg_stft_kernel<1>), dim3(Tf, B), dim3(glg_threads(n_fft)), glg_lds(n_fft), s, wav, n, window,
                            reinterpret_cast<const gcf*>(tw), reinterpret_cast<gcf*>(out), Tf, Fp, n_fft, m, win, hop, mag, mse_partial);
     else
-        hipLaunchKernelGGL((glg_stft_kernel<0>), dim3(Tf, B), dim3(GLG_THREADS), glg_lds(n_fft), s, wav, n, window,
+        hipLaunchKernelGGL((glg_stft_kernel<0>), dim3(Tf, B), dim3(glg_threads(n_fft)), glg_lds(n_fft), s, wav, n, window,
                            reinterpret_cast<const gcf*>(tw), reinterpret_cast<gcf*>(out), Tf, Fp, n_fft, m, win, hop, mag, mse_partial);
     return hipGetLastError();
 }
