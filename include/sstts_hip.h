@@ -285,9 +285,9 @@ int tts_decoder_kernel_choice(tts_handle_t h, int B, int T_sent, int pipelined);
  * ("enc.bank", "enc.p1", "post.xproj", ...); contents are only valid until the next call. */
 int tts_debug_workspace(tts_handle_t h, const char* name, void** dptr, size_t* bytes);
 /* Host-only: the Griffin-Lim work-item cut for T frames x B utterances on n_workers compute units.
- * classes[8] = {frames per run, runs per utterance} x 4 in execution order; *max_item_frames = frames the LDS ring of
- * the kernel holds; returns the number of classes. */
-int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_workers, int* classes, int* max_item_frames);
+ * items[n][4] = {utterance, first frame, frames, slot word} in the order the workgroups draw them (at most max_items
+ * are written); *ring_frames = frames the LDS ring of the kernel holds; returns the number of items. */
+int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_workers, int* items, int max_items, int* ring_frames);
 /* Diagnostic: one GEMM / conv1d launch on device buffers (A [M][Cin] rows of sequences of length T, Wt [N][ktaps*Cin]). */
 int tts_debug_gemm(tts_handle_t h, const float* A, const float* Wt, float* C, int M, int N, int Cin, int ktaps, int T,
                    int pool);

@@ -100,7 +100,7 @@ _PROTOTYPES = {
     'tts_debug_workspace': (c_int, [c_void_p, c_char_p, POINTER(c_void_p), POINTER(c_size_t)]),
     'tts_debug_hold': (c_int, [c_void_p, c_int, c_int, ctypes.c_double]),
     'tts_debug_gemm': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
-    'tts_debug_gl_plan': (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    'tts_debug_gl_plan': (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int), c_int, POINTER(c_int)]),
     'tts_device_info': (c_int, [c_void_p, c_char_p, POINTER(c_int)]),
 }
 

@@ -18,7 +18,9 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-val
 # Packed f32 VALU ops (v_pk_add/mul/fma_f32) issue slower than the two scalar ops they replace on gfx950 and
 # need aligned register pairs (extra v_mov); the SLP vectoriser forms them from complex arithmetic.  Measured
 # on the wave-level FFT: 2.70 -> 2.02 us, 92 -> 67 VGPRs (tools/fft_microbench.hip).
-EXTRA_FLAGS = {'griffin_lim.hip': ['-fno-slp-vectorize']}
+# griffin_lim_generic.hip: no packed-f32 selection at all (its complex type is two scalars; see the note there -- packed results
+# were stored wrong when MFMA waves of another stream shared the compute unit)
+EXTRA_FLAGS = {'griffin_lim.hip': ['-fno-slp-vectorize'], 'griffin_lim_generic.hip': ['-fno-slp-vectorize']}
 
 
 def _digest(paths, extra=()):

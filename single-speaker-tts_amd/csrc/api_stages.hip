@@ -436,15 +436,15 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     // `reserve_cus` workgroups), never the second, wide one; an unpipelined call then runs that cut on all compute units
     // (the cut decides the overlap-add order, the number of workgroups that draw its items does not)
     const int plan_held = (h->deterministic && h->reserve_cus > 0) ? h->reserve_cus : held;
-    gl_plan_stream(p, n_cus - plan_held > 16 ? n_cus - plan_held : n_cus, per_launch, h->debug_hooks ? h->gl_runs : 0,
-                   h->debug_hooks ? h->gl_run_len : 0);
+    HIPCHK(h, gl_plan_stream(p, n_cus - plan_held > 16 ? n_cus - plan_held : n_cus, per_launch, h->debug_hooks ? h->gl_runs : 0,
+                             h->debug_hooks ? h->gl_run_len : 0, h->stream));
     // wide_from >= 0 (the pipelined tts_synthesize, see gl_wide_from there): launches from that index on are cut for ALL
     // compute units -- the second stream's decoder has left its share by then.  A second cut, fixed per launch index, so
     // the waveform's bits stay a function of the call's arguments and options alone.
     GlParams pw = p;
     const bool two_cuts = held > 0 && wide_from >= 0 && n_cus - held > 16 && !h->deterministic &&
                           !(h->debug_hooks && (h->gl_runs || h->gl_run_len));
-    if (two_cuts) gl_plan_stream(pw, n_cus, per_launch, 0, 0);
+    if (two_cuts) HIPCHK(h, gl_plan_stream(pw, n_cus, per_launch, 0, 0, h->stream));
     const int nchunks = std::max(p.slots_per_utt, pw.slots_per_utt);
     WS(h, "gl.mse_partial", float, (size_t)B * nchunks, msep);
     // One zeroed work counter per launch (the persistent workgroups draw their item ids from it): slots of a ring that is
@@ -534,6 +534,13 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
             double mean = 0; for (double e : ends) mean += e; mean /= n ? n : 1;
             fprintf(stderr, "workgroups %zu: start last %.1f us; end min %.1f p10 %.1f median %.1f mean %.1f p90 %.1f max %.1f us\n", n,
                     starts.back(), ends.front(), ends[n / 10], ends[n / 2], mean, ends[n * 9 / 10], ends.back());
+            if (getenv("GL_TIMELINE_WGS"))   // every workgroup: block, XCC, first item, runs, start, end
+                for (int w = 0; w < 512; ++w)
+                    if (host[2 * w]) {
+                        const unsigned long long m = host[1536 + w];
+                        fprintf(stderr, "wg %3d xcc %d item %4d runs %d start %.1f end %.1f\n", w, (int)((m >> 48) & 0xf), (int)(m & 0xffffffffu),
+                                (int)((m >> 32) & 0xffff), (host[2 * w] - t0) * 0.01, (host[2 * w + 1] - t0) * 0.01);
+                    }
             p.dbg = pw.dbg = nullptr;
         }
 #endif
@@ -1054,27 +1061,24 @@ int tts_db_convert(tts_handle_t h, const float* in, size_t n, int mode, float re
 }
 
 
-// Host-only view of the Griffin-Lim work-item planner (no GPU needed): classes[4][2] = {frames per run, runs
-// per utterance} in execution order, *max_item_frames = the chunk size the runs are processed in; returns the
-// number of classes or a negative status.
-int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_workers, int* classes, int* max_item_frames) {
-    if (T < 1 || B < 1 || win_length < 2 || win_length > TTS_GL_NFFT || hop_length < 1 || n_workers < 1 || !classes)
+// Host-only view of the Griffin-Lim work-item planner (no GPU needed): items[n][4] = {utterance, first frame, frames, slot word}
+// in the order the workgroups draw them (at most max_items are written), *ring_frames = frames the kernel's LDS ring holds;
+// returns the number of items or a negative status.
+int tts_debug_gl_plan(int T, int B, int win_length, int hop_length, int n_workers, int* items, int max_items, int* ring_frames) {
+    if (T < 1 || B < 1 || win_length < 2 || win_length > TTS_GL_NFFT || hop_length < 1 || n_workers < 1 || !items || max_items < 0)
         return TTS_ERR_INVALID;
-    GlParams p;
-    std::memset(&p, 0, sizeof(p));
-    p.T = T; p.B = B; p.win = win_length; p.hop = hop_length;
-    p.ncol = (win_length + hop_length - 1) / hop_length;
     const int ring = gl_stream_ring_frames(win_length, hop_length);
-    if (p.ncol > 8 || ring < 1) return TTS_ERR_UNSUPPORTED;
+    if ((win_length + hop_length - 1) / hop_length > 8 || ring < 1) return TTS_ERR_UNSUPPORTED;
     int n_stage = 3;   // the handle's default launch form (option "gl_pair")
     while (n_stage > 1 && gl_stream_ring_frames(win_length, hop_length, n_stage) <= 0) --n_stage;
-    gl_plan_stream(p, n_workers, n_stage);
-    if (max_item_frames) *max_item_frames = ring;
-    for (int k = 0; k < GL_MAX_CLASSES; ++k) {
-        classes[2 * k] = p.cls_C[k];
-        classes[2 * k + 1] = p.cls_n[k];
+    std::vector<int4> v;
+    int slots = 0;
+    const int n = gl_plan_items(T, B, win_length, hop_length, n_workers, n_stage, 0, 0, &v, &slots);
+    if (ring_frames) *ring_frames = ring;
+    for (int k = 0; k < n && k < max_items; ++k) {
+        items[4 * k] = v[k].x; items[4 * k + 1] = v[k].y; items[4 * k + 2] = v[k].z; items[4 * k + 3] = v[k].w;
     }
-    return p.n_classes;
+    return n;
 }
 
 

@@ -1,12 +1,12 @@
 // Griffin-Lim / audio kernel launchers shared between griffin_lim.hip and the api_*.hip files.
 #pragma once
 #include "tts_common.h"
+#include <vector>
 
 namespace tts {
 
 #define TTS_GL_FP 1056      // padded row length of the frame-major spectra (F = 1025): rows start on 128-byte lines
 #define TTS_GL_NFFT 2048
-#define GL_MAX_CLASSES 4
 
 struct GlParams {
     const float* mag;        // [B][T][FP]
@@ -24,12 +24,13 @@ struct GlParams {
     int T, FP, win, hop;
     int B;                   // utterances
     int ncol;                // ceil(win / hop): frames that overlap a sample, halo = ncol - 1
-    // work items of a launch (gl_plan_stream): class k cuts cls_n[k] RUNS of cls_C[k] consecutive frames out of
-    // every utterance, starting at frame cls_t0[k]; item ids are class-major, utterance index fastest:
-    // id = cls_first[k] + j * B + b  <->  utterance b, frames [cls_t0[k] + j L, + L), L = cls_C[k]; the run's partial
-    // results (mse, peak) go to slot cls_slot0[k] + j of the utterance.
-    int n_classes, n_items, slots_per_utt;
-    int cls_C[GL_MAX_CLASSES], cls_n[GL_MAX_CLASSES], cls_t0[GL_MAX_CLASSES], cls_slot0[GL_MAX_CLASSES], cls_first[GL_MAX_CLASSES];
+    // work items of a launch (gl_plan_stream): a table of RUNS in device memory, {utterance, first frame, frames, slot};
+    // item ids are drawn in table order (first every workgroup's first run, then the runs that follow them).  A run's
+    // partial results (mse, peak) go to slot (w & 0xffff) of its utterance; the run with the utterance's last slot carries
+    // in w >> 16 how many slots up to slots_per_utt it has to zero (utterances are not all cut into the same number of runs).
+    const int4* items;
+    int n_items, slots_per_utt;
+    int n_workers;           // workgroups the cut was made for (= the launch's grid)
     int ring_frames;         // streaming form (gl_stream_kernel): frames an LDS ring holds
     int n_stage;             // ... iterations per launch (1..3), set by launch_gl_stream
     // seeded start (no initial-phase array): the first launch of a call makes the initial phasor of every bin itself
@@ -46,7 +47,13 @@ void gl_build_wlane(const float* window, const float* rwss, int win, int hop, in
 // streaming form of the iteration / final iSTFT (gl_stream_kernel): no chunks, a run is one stream through an LDS ring
 int gl_stream_ring_frames(int win, int hop, int n_stage = 1);   // 0: the window / hop pair does not fit
 bool gl_stream_instantiated(int win, int hop);                  // the (window, hop) pairs gl_stream_kernel is compiled for (n_fft 2048)
-void gl_plan_stream(GlParams& p, int n_workers, int n_stage = 1, int force_runs = 0, int force_run_len = 0);  // needs T, B, win, hop, ncol; sets the item classes (cut for launches of n_stage iterations)
+// needs T, B, win, hop, ncol; sets items / n_items / slots_per_utt (the cut for launches of n_stage iterations on n_workers
+// workgroups; the table is uploaded to the current device once per shape and set of speeds and lives as long as the process)
+// stream: the stream the launches that use the cut will be enqueued on (a table that is new is uploaded there)
+hipError_t gl_plan_stream(GlParams& p, int n_workers, int n_stage = 1, int force_runs = 0, int force_run_len = 0, hipStream_t stream = nullptr);
+// the same cut on the host alone (no device): items[n][4] = {utterance, first frame, frames, slot word}; returns n
+int gl_plan_items(int T, int B, int win, int hop, int n_workers, int n_stage, int force_runs, int force_run_len,
+                  std::vector<int4>* items, int* slots_per_utt, int* workers_out = nullptr);
 hipError_t launch_gl_stream(hipStream_t s, const GlParams& p, int n_cus, int final_istft, int n_stage = 1);
 hipError_t gl_configure();
 size_t gl_state_bytes();   // bytes per bin of the state between launches (4: a phasor code)

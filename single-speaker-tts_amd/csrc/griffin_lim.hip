@@ -37,6 +37,7 @@
 #include "tts_common.h"
 #include "griffin_lim.h"
 #include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <cstdlib>
 
@@ -570,19 +571,15 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
     }
     __syncthreads();
     int item = __builtin_amdgcn_readfirstlane(ctrl[CT_SNEXT]);
+#ifdef GL_TIMELINE
+    int tl_runs = 0;
+    const int tl_first = item;
+#endif
 
     // ---------------- work item -> (utterance, first frame, frames, slot of its partial results); wave-uniform
     auto decode_item = [&](int it, int& b, int& t0, int& len, int& slot) {
-        int k = 0;
-#pragma unroll
-        for (int q = 1; q < GL_MAX_CLASSES; ++q)
-            if (q < p.n_classes && it >= p.cls_first[q]) k = q;
-        const int rel = it - p.cls_first[k];
-        b = rel % p.B;
-        const int jc = rel / p.B;
-        len = p.cls_C[k];
-        t0 = p.cls_t0[k] + jc * len;
-        slot = p.cls_slot0[k] + jc;
+        const int4 q = p.items[it];   // (wave-uniform index: a scalar load)
+        b = q.x; t0 = q.y; len = q.z; slot = q.w;
     };
 
     // prefetch registers of one spectrum row in the pair-owner layout: phasor codes and magnitudes of bins lane + 64 j
@@ -1086,16 +1083,24 @@ __global__ __launch_bounds__(GL_THREADS) void gl_stream_kernel(GlParams p) {
             if (tid == 0) {
                 float a = 0.f;
                 for (int w = 0; w < GL_NW; ++w) a = MODE == 0 ? a + red[w] : fmaxf(a, red[w]);
-                (MODE == 0 ? p.mse_partial : p.peak_partial)[(size_t)b * p.slots_per_utt + slot] = a;
+                float* part = (MODE == 0 ? p.mse_partial : p.peak_partial) + (size_t)b * p.slots_per_utt + (slot & 0xffff);
+                part[0] = a;
+                for (int q = 1; q <= (slot >> 16); ++q) part[q] = 0.f;   // (the utterance's last run: slots other utterances have)
             }
         }
         __syncthreads();
         item = next_item;
+#ifdef GL_TIMELINE
+        ++tl_runs;
+#endif
     }
 #ifdef GL_TIMELINE
     if (p.dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         p.dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (blockIdx.x < 512) p.dbg[1536 + blockIdx.x] = (unsigned long long)(unsigned)tl_first | ((unsigned long long)tl_runs << 32) | ((unsigned long long)(xcc & 0xf) << 48);
     }
 #endif
 #ifdef GL_CLOCK
@@ -1151,87 +1156,181 @@ size_t gl_stream_lds_bytes(const GlParams& p) {
            (size_t)(p.n_stage < 1 ? 1 : p.n_stage) * (size_t)((p.hop * p.ring_frames + g.acc_len + 128 + 3) & ~3) * sizeof(float);
 }
 
-// Work items of the streaming form: every utterance is cut into nr runs of (almost) equal length, a multiple of the
-// eight waves; a run costs its frames plus the 2 halo indices that are only inverse-transformed plus a constant for
-// filling and draining the stream.  nr is chosen by simulating the list schedule on the workgroups that really run.
-void gl_plan_stream(GlParams& p, int n_workers, int n_stage, int force_runs, int force_run_len) {
-    const int halo = p.ncol - 1;
+// Work items of the streaming form.  The frames of all utterances, one after another, are dealt to the workgroups in
+// contiguous pieces of equal COST; a piece that crosses the end of an utterance is two runs (the tail of one utterance
+// and the head of the next).  What a run costs beyond its frames was measured per workgroup (tools: -DGL_TIMELINE,
+// profiles/r06_experiment_gl_cut.txt): at three iterations per launch every stage starts halo + lag indices before the
+// next one's first frame -- 24 indices per run that carry 72 of a frame's 6 transforms, 12 frames' worth with start and
+// drain, a little less at an utterance's end where the frames outside are skipped but the reflect-padded ones take the
+// index-mapped path.  Until round 6 every utterance was cut alike into runs of one length (a multiple of the eight waves)
+// and a rest: at T = 1000, B = 64 on 224 workgroups three runs of 296 frames and one of 112, so that 192 workgroups took
+// one long run (640 us) and 32 two short ones (515 us) -- 4.7 % of the chip idle in every launch; on 256 workgroups three of
+// 256 and one of 232 (572 / 515 us, 4.5 %).  The waveform's bits do not depend on the cut (every sample is summed over the
+// frames that cover it in ascending order whatever run they are in: tests/test_gpu_audio.py).
+namespace {
+struct GlRun { int b, t0, len; };
+struct GlCutCost { double interior, edge; };   // per END of a run, in frames
+GlCutCost gl_cut_cost(int halo, int lag, int n_stage) {
+    // interior end: (halo + lag) / 2 * n_stage^2 transforms of the 2 n_stage a frame takes = (halo + lag) n_stage / 4
+    // frames (6 at 4 / 4 / 3), measured 5.5 with the start and drain of the stream; an utterance's end: about half
+    const double c = (halo + lag) * n_stage / 4.0;
+    return GlCutCost{c * (5.5 / 6.0), c * 0.5};
+}
+// deals the frames to `W` workers with at most `M` cost each; returns false if they do not fit.  workers[w] = its runs
+bool gl_deal(int T, int B, int W, double M, const GlCutCost& cc, int min_len, std::vector<std::vector<GlRun>>& workers, double* makespan) {
+    workers.assign((size_t)W, {});
+    int b = 0, t = 0, w = 0;
+    double load = 0.0, worst = 0.0;
+    while (b < B) {
+        if (w >= W) return false;
+        const int rest = T - t;
+        const double left = t > 0 ? cc.interior : cc.edge;
+        const double whole = rest + left + cc.edge;                    // the rest of the utterance as one run
+        if (load + whole <= M + 1e-9) {
+            workers[w].push_back(GlRun{b, t, rest});
+            load += whole;
+            ++b; t = 0;
+            continue;
+        }
+        int len = (int)std::floor(M - load - left - cc.interior + 1e-9);   // a run that ends inside the utterance
+        if (rest - len < min_len) len = rest - min_len;                     // (never leave a sliver to the next worker)
+        if (len >= min_len) {
+            workers[w].push_back(GlRun{b, t, len});
+            load += len + left + cc.interior;
+            t += len;
+        } else if (workers[w].empty()) {
+            return false;                                                   // M is smaller than the smallest run
+        }
+        worst = std::max(worst, load);
+        ++w; load = 0.0;
+    }
+    worst = std::max(worst, load);
+    if (makespan) *makespan = worst;
+    return true;
+}
+}  // namespace
+
+int gl_plan_items(int T, int B, int win, int hop, int n_workers, int n_stage, int force_runs, int force_run_len,
+                  std::vector<int4>* items, int* slots_per_utt, int* workers_out) {
+    const int ncol = (win + hop - 1) / hop, halo = ncol - 1;
     n_stage = n_stage < 1 ? 1 : (n_stage > 3 ? 3 : n_stage);
-    // ONE cut for all launches of a call (single and double iterations alike: the overlap-add order, hence the waveform
-    // bits, must not depend on which kernel form ran an iteration); ring_frames is set per launch (launch_gl_stream)
-    p.ring_frames = gl_stream_ring_frames(p.win, p.hop, 1);
-    struct Cut { int L, n_full, rem; };
-    Cut best{p.T, 1, 0};
-    bool forced = false;
-    // tests / experiments only (per-handle options "gl_runs" / "gl_run_len" behind "debug_hooks", api_handle.hip): a forced cut.
-    // Nothing in the process environment reaches this function: the cut is part of the waveform's bits.
-    if (force_runs >= 1 && force_runs <= p.T) {   // runs per utterance
-        const int L = ((p.T + force_runs - 1) / force_runs + GL_NW - 1) / GL_NW * GL_NW;
-        best = Cut{L, p.T / L, p.T - (p.T / L) * L};
-        forced = true;
-    }
-    if (force_run_len >= GL_NW) {   // frames per (full) run
-        const int L = force_run_len / GL_NW * GL_NW;
-        best = Cut{L, p.T / L, p.T - (p.T / L) * L};
-        forced = true;
-    }
-    if (!forced) {
-        static std::map<std::vector<int>, Cut> cache;
-        static std::mutex cache_mutex;
-        std::lock_guard<std::mutex> lock(cache_mutex);
-        const std::vector<int> key = {p.T, p.B, p.win, p.hop, n_workers, n_stage};
-        auto it = cache.find(key);
-        if (it != cache.end()) {
-            best = it->second;
-        } else {
-            double best_t = 1e300;
-            const double fill = 6.0;   // frames' worth of time to fill and drain the stream of a run
-            // What a run costs beyond its own frames: every stage of a launch starts halo + lag indices before the next
-            // one's first frame (gl_stream_kernel: n_idx = run_len + NST (halo + lag)) -- 24 indices per run (halo 4, lag 4 for the 1102 / 275 window) at three
-            // iterations per launch, which is why the cut is made for the launch form the call will mostly use.
-            const int wpad = (TTS_GL_NFFT - p.win) >> 1;
-            const int lag = (halo + 1) * p.hop > 2 * (TTS_GL_NFFT / 2 - wpad) ? halo : halo + 1;
-            const double over = (double)n_stage * (halo + lag) + fill;
-            // Every run length that is a multiple of the eight waves is a candidate: n_full runs of L frames and one of the
-            // rest per utterance.  (Only the equal cuts ceil(T / n) used to be: at T = 1000, 64 utterances, 224 workgroups
-            // they give two runs of 144 / 136 frames per workgroup = 2 x (144 + 24) indices; three runs of 296 frames and
-            // one of 112 per utterance give 192 workgroups one long run and 32 workgroups two short ones: 296 + 24 = 40 rounds of the eight waves.)
-            for (int L = GL_NW; L < p.T + GL_NW; L += GL_NW) {
-                const int n_full = p.T / L, rem = p.T - n_full * L;
-                // list schedule, longest runs first: n_full * B items of cost cL, then B items of cost cR
-                const double cL = L + over, cR = rem > 0 ? rem + over : 0.0;
-                std::vector<double> heap((size_t)n_workers, 0.0);
-                auto cmp = [](double a, double b) { return a > b; };
-                auto deal = [&](long long items, double cost) {
-                    for (long long i = 0; i < items; ++i) {
-                        std::pop_heap(heap.begin(), heap.end(), cmp);
-                        heap.back() += cost;
-                        std::push_heap(heap.begin(), heap.end(), cmp);
-                    }
-                };
-                deal((long long)n_full * p.B, cL);
-                if (rem > 0) deal(p.B, cR);
-                const double t = *std::max_element(heap.begin(), heap.end());
-                if (t < best_t - 1e-9) { best_t = t; best = Cut{L, n_full, rem}; }
-            }
-            cache[key] = best;
+    n_workers = n_workers < 1 ? 1 : n_workers;
+    const int wpad = (TTS_GL_NFFT - win) >> 1;
+    const int lag = (halo + 1) * hop > 2 * (TTS_GL_NFFT / 2 - wpad) ? halo : halo + 1;
+    std::vector<std::vector<GlRun>> workers;
+    // tests / experiments only (per-handle options "gl_runs" / "gl_run_len" behind "debug_hooks", api_handle.hip): every
+    // utterance cut alike into runs of one length and a rest, one run per list entry
+    int forced_len = 0;
+    if (force_runs >= 1 && force_runs <= T) forced_len = ((T + force_runs - 1) / force_runs + GL_NW - 1) / GL_NW * GL_NW;
+    if (force_run_len >= GL_NW) forced_len = force_run_len / GL_NW * GL_NW;
+    if (forced_len > 0) {
+        for (int t0 = 0; t0 < T; t0 += forced_len)
+            for (int b = 0; b < B; ++b) workers.push_back({GlRun{b, t0, std::min(forced_len, T - t0)}});
+    } else {
+        const GlCutCost cc = gl_cut_cost(halo, lag, n_stage);
+        const int min_len = std::min(T, (int)GL_NW);   // (a run per round of the eight waves at least: what one utterance on a whole chip is cut into)
+        // the smallest makespan over a scan of the bound (the deal is greedy: a lower bound does not always give a lower result)
+        const double total = (double)B * (T + 2 * cc.edge);
+        double lo = std::max(total / n_workers, (double)min_len + 2 * cc.edge), best_t = 1e300;
+        std::vector<std::vector<GlRun>> cand;
+        for (int step = 0; step < 400; ++step) {
+            const double M = lo * (1.0 + 0.0025 * step);
+            double t = 0.0;
+            if (!gl_deal(T, B, n_workers, M, cc, min_len, cand, &t)) continue;
+            if (t < best_t - 1e-9) { best_t = t; workers = cand; }
+        }
+        if (workers.empty()) {   // (cannot happen: at twice the average every deal fits) one run per utterance
+            for (int b = 0; b < B; ++b) workers.push_back({GlRun{b, 0, T}});
         }
     }
-    for (int k = 0; k < GL_MAX_CLASSES; ++k) {
-        p.cls_C[k] = p.cls_n[k] = p.cls_t0[k] = p.cls_slot0[k] = p.cls_first[k] = 0;
-    }
-    int nc = 0, t = 0, slot = 0, first = 0;
-    auto add = [&](int len, int n) {
-        p.cls_C[nc] = len; p.cls_n[nc] = n;
-        p.cls_t0[nc] = t; p.cls_slot0[nc] = slot; p.cls_first[nc] = first;
-        t += len * n; slot += n; first += n * p.B;
-        ++nc;
+    // table order = the order the persistent workgroups draw in: every worker's first run, then the runs that follow in
+    // the order their workers come free (the shortest first runs first)
+    std::vector<int> slot_of((size_t)B, 0), runs_of((size_t)B, 0);
+    for (const auto& w : workers) for (const GlRun& r : w) ++runs_of[r.b];
+    int spu = 1;
+    for (int b = 0; b < B; ++b) spu = std::max(spu, runs_of[b]);
+    std::vector<int> slot_at;   // slot of a run = its ordinal inside the utterance (by first frame)
+    auto slot_word = [&](const GlRun& r) {
+        int ord = 0;
+        for (const auto& w : workers) for (const GlRun& q : w) if (q.b == r.b && q.t0 < r.t0) ++ord;
+        const int pad = ord == runs_of[r.b] - 1 ? spu - runs_of[r.b] : 0;
+        return ord | (pad << 16);
     };
-    if (best.n_full > 0) add(best.L, best.n_full);
-    if (best.rem > 0) add(best.rem, 1);
-    p.n_classes = nc;
-    p.n_items = first;
-    p.slots_per_utt = slot;
+    // table order = the order the persistent workgroups draw in: every worker's first run, then the runs that follow in
+    // the order their workers come free (the shortest first runs first)
+    items->clear();
+    size_t depth = 0;
+    for (const auto& w : workers) depth = std::max(depth, w.size());
+    for (size_t d = 0; d < depth; ++d) {
+        std::vector<std::pair<double, const GlRun*>> level;
+        for (const auto& w : workers) {
+            if (w.size() <= d) continue;
+            double before = 0.0;
+            for (size_t q = 0; q < d; ++q) before += w[q].len;
+            level.push_back({before, &w[d]});
+        }
+        std::stable_sort(level.begin(), level.end(), [](const std::pair<double, const GlRun*>& a, const std::pair<double, const GlRun*>& b) { return a.first < b.first; });
+        for (const auto& e : level) items->push_back(make_int4(e.second->b, e.second->t0, e.second->len, slot_word(*e.second)));
+    }
+    if (workers_out) {
+        int nw = 0;
+        for (const auto& w : workers) nw += !w.empty();
+        *workers_out = nw;
+    }
+    if (slots_per_utt) *slots_per_utt = spu;
+    return (int)items->size();
+}
+
+// The cut of a shape is made once per process and uploaded once per device (a table of 16 bytes per run).
+hipError_t gl_plan_stream(GlParams& p, int n_workers, int n_stage, int force_runs, int force_run_len, hipStream_t stream) {
+    // A table on a device: uploaded by an asynchronous copy on the stream of the call that first needs it (the host copy lives
+    // in the cache, at a stable address) -- a cut made in the middle of a run of pipelined calls must not wait for the streams to
+    // drain, as a synchronous copy does.  Calls on other streams wait for the `ready` event until it has been seen complete.
+    struct Table { int4* ptr = nullptr; hipEvent_t ready = nullptr; hipStream_t owner = nullptr; bool seen = false; };
+    struct Plan { std::vector<int4> items; int slots = 1, workers = 1; std::map<int, Table> dev; };
+    struct Pool { char* base = nullptr; size_t used = 0, size = 0; };   // tables are carved from 1 MB blocks and never freed
+    static std::map<std::vector<int>, Plan> cache;
+    static std::map<int, Pool> pools;
+    static std::mutex cache_mutex;
+    std::lock_guard<std::mutex> lock(cache_mutex);
+    // ONE cut for all launches of a call; ring_frames is set per launch (launch_gl_stream)
+    p.ring_frames = gl_stream_ring_frames(p.win, p.hop, 1);
+    const std::vector<int> key = {p.T, p.B, p.win, p.hop, n_workers, n_stage, force_runs, force_run_len};
+    Plan& plan = cache[key];
+    if (plan.items.empty())
+        gl_plan_items(p.T, p.B, p.win, p.hop, n_workers, n_stage, force_runs, force_run_len, &plan.items, &plan.slots, &plan.workers);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    Table& t = plan.dev[dev];
+    if (!t.ptr) {
+        const size_t bytes = (plan.items.size() * sizeof(int4) + 255) & ~(size_t)255;
+        Pool& pool = pools[dev];
+        if (pool.used + bytes > pool.size) {
+            const size_t block = std::max<size_t>(bytes, 1u << 20);
+            void* m = nullptr;
+            if ((e = hipMalloc(&m, block)) != hipSuccess) return e;
+            pool.base = static_cast<char*>(m); pool.used = 0; pool.size = block;
+        }
+        int4* d = reinterpret_cast<int4*>(pool.base + pool.used);
+        hipEvent_t ev = nullptr;
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(d, plan.items.data(), plan.items.size() * sizeof(int4), hipMemcpyHostToDevice, stream)) != hipSuccess ||
+            (e = hipEventRecord(ev, stream)) != hipSuccess) {
+            (void)hipEventDestroy(ev);
+            return e;
+        }
+        pool.used += bytes;
+        t.ptr = d; t.ready = ev; t.owner = stream; t.seen = false;
+    } else if (!t.seen) {
+        if (hipEventQuery(t.ready) == hipSuccess) t.seen = true;
+        else if (stream != t.owner && (e = hipStreamWaitEvent(stream, t.ready, 0)) != hipSuccess) return e;
+    }
+    p.items = t.ptr;
+    p.n_items = (int)plan.items.size();
+    p.slots_per_utt = plan.slots;
+    p.n_workers = plan.workers;
+    return hipSuccess;
 }
 
 template <int MODE, int W, int H, bool MSE, int NST = 1>
@@ -1283,7 +1382,8 @@ hipError_t launch_gl_stream(hipStream_t s, const GlParams& p_in, int n_cus, int 
     p.ring_frames = gl_stream_ring_frames(p.win, p.hop, n_stage);
     if (p.ring_frames < GL_NW || n_stage < 1 || n_stage > 3 || (n_stage > 1 && (final_istft || p.mse_partial))) return hipErrorInvalidValue;
     const size_t lds = gl_stream_lds_bytes(p);
-    const int nwg = p.n_items < n_cus ? p.n_items : n_cus;   // one workgroup per compute unit (256 registers x 8 waves)
+    // one workgroup per compute unit (256 registers x 8 waves), as many as the cut was made for
+    const int nwg = p.n_workers > 0 && p.n_workers < n_cus ? p.n_workers : (p.n_items < n_cus ? p.n_items : n_cus);
     const dim3 grid(nwg);
     const bool mse = p.mse_partial != nullptr;
     if (p.win == 1102 && p.hop == 275) return gl_stream_launch_wh<1102, 275>(s, p, grid, lds, final_istft, n_stage, mse);

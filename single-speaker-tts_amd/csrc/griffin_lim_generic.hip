@@ -32,7 +32,16 @@ namespace tts {
 
 #define GLG_THREADS 256
 
-typedef float gcf __attribute__((ext_vector_type(2)));
+// A complex number as two SCALAR floats, and the file is built with -fno-slp-vectorize (build.py): no v_pk_*_f32 instruction is
+// selected for these kernels.  Round 6 measured why (profiles/r06_experiment_packed_f32_beside_mfma.txt): written with a float2
+// vector type the compiler made the butterflies from packed-f32 VOP3P instructions, and whenever waves of the MFMA GEMM
+// (gemm_f32_kernel, another stream) shared the compute unit, single frames came out wrong -- the low dword of a packed result in
+// lanes 48-63 of one wave, as stored to LDS by the next instruction: 129 of 200 calls beside GEMM launches, 0 of 3100 for the
+// same source without packed selection (and 0 of 120 for every other stage of the library under the same neighbour).  The
+// kernels are bound by memory: the scalar form costs nothing (926 / 523 us per iteration at n_fft 2048 / 1024 either way).
+struct __attribute__((aligned(8))) gcf { float x, y; };
+__device__ __forceinline__ gcf operator+(gcf a, gcf b) { return gcf{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ gcf operator-(gcf a, gcf b) { return gcf{a.x - b.x, a.y - b.y}; }
 
 __device__ __forceinline__ gcf gmul(gcf a, gcf b) { return (gcf){a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 
@@ -100,10 +109,11 @@ __global__ __launch_bounds__(GLG_THREADS) void glg_istft_kernel(const float* __r
     for (int k = threadIdx.x; k < M; k += blockDim.x) {
         const float s0 = mag[row + k], s1 = mag[row + M - k];
         const gcf e0 = ph[row + k], e1 = ph[row + M - k];
+        const gcf twk = tw[k];
         gcf xk = (gcf){s0 * e0.x, s0 * e0.y}, xm = (gcf){s1 * e1.x, s1 * e1.y};
         if (k == 0) { xk.y = 0.f; xm.y = 0.f; }   // irfft ignores the imaginary parts of the DC and Nyquist bins
         const gcf cm = gconj(xm);
-        const gcf d = gmul(gconj(tw[k]), xk - cm);
+        const gcf d = gmul(gconj(twk), xk - cm);
         a[glg_bitrev(k, mm)] = (xk + cm) + gmul_i(d);
     }
     glg_fft<true>(a, tw, M, mm);

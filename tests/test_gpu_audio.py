@@ -225,6 +225,36 @@ def test_griffin_lim_forced_run_cuts(engine, run_len, per_launch, n_iter, want_m
             assert abs(mse[b] - ref_mse) <= 1e-3 * abs(ref_mse) + 1e-9
 
 
+def test_griffin_lim_bits_do_not_depend_on_the_cut(engine):
+    """The waveform is the same BITS whatever runs the utterances are cut into and however many workgroups draw them: every
+    sample is summed over the frames that cover it in ascending order, in whatever run they lie, and a run's halo recomputes
+    its neighbours' frames exactly.  (Until round 6 the cut was believed to be part of the bits; it is what lets a pipelined
+    call use one cut beside the decoder and another on the whole chip without its result depending on either.)"""
+    B, T = 8, 1000
+    rng = np.random.default_rng(77)
+    mag = engine.to_device((rng.random((B, 1025, T), dtype=np.float32) ** 4) * 10)
+    init = engine.to_device(rng.random((B, 1025, T), dtype=np.float32))
+    engine.set_option('debug_hooks', 1)
+    outs = {}
+    try:
+        for runs, rl, workers in ((0, 0, 0), (3, 0, 0), (5, 0, 0), (0, 296, 0), (0, 104, 0), (0, 56, 0), (0, 0, 224), (0, 0, 100), (0, 0, 17)):
+            engine.set_option('gl_runs', runs)
+            engine.set_option('gl_run_len', rl)
+            engine.set_option('gl_workers', workers)
+            wav, _ = engine.griffin_lim(mag, 12, WIN, HOP, N_FFT, init_phase=init, want_mse=False)
+            engine.synchronize()
+            outs[(runs, rl, workers)] = wav.to_host().copy()
+            wav.free()
+    finally:
+        for k in ('gl_runs', 'gl_run_len', 'gl_workers', 'debug_hooks'):
+            engine.set_option(k, 0)
+        mag.free(); init.free()
+    ref = outs[(0, 0, 0)]
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 0
+    for k, v in outs.items():
+        assert np.array_equal(ref.view(np.uint32), v.view(np.uint32)), k
+
+
 # ---- every power-of-two n_fft / window / hop on the audio surface (csrc/griffin_lim_generic.hip): the reference passes
 # n_fft, win_length and hop_length as arguments (audio/synthesis.py:5-40, 43-125; audio/features.py:5-86, 116-145)
 @pytest.mark.parametrize('n_fft,win,hop,B,T', [

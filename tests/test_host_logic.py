@@ -211,36 +211,61 @@ def test_permlane_swap_transpose_emulation():
 def _gl_plan(T, B, win, hop, workers):
     lib = pkg('_hip').load_library()
     import ctypes
-    cls = (ctypes.c_int * 8)()
-    cmax = ctypes.c_int(0)
-    n = lib.tts_debug_gl_plan(T, B, win, hop, workers, cls, ctypes.byref(cmax))
-    assert n >= 1, n
-    return [(cls[2 * k], cls[2 * k + 1]) for k in range(n)], cmax.value
+    cap = 16384
+    buf = (ctypes.c_int * (4 * cap))()
+    ring = ctypes.c_int(0)
+    n = lib.tts_debug_gl_plan(T, B, win, hop, workers, buf, cap, ctypes.byref(ring))
+    assert 1 <= n <= cap, n
+    return [(buf[4 * k], buf[4 * k + 1], buf[4 * k + 2], buf[4 * k + 3]) for k in range(n)], ring.value
 
 
 @pytest.mark.parametrize('T,B,win,hop,workers', [
     (1000, 64, 1102, 275, 256), (1000, 64, 1102, 275, 224), (1000, 1, 1102, 275, 256), (5, 2, 1102, 275, 256),
     (37, 3, 1102, 275, 248), (1000, 512, 1102, 275, 256), (400, 16, 2048, 512, 256), (333, 7, 400, 160, 256),
-    (1000, 64, 551, 275, 224),
+    (1000, 64, 551, 275, 224), (1000, 64, 800, 200, 224), (1, 1, 1102, 275, 256), (813, 5, 1102, 275, 224),
+    (1000, 63, 1102, 275, 224), (200, 300, 1102, 275, 256),
 ])
 def test_griffin_lim_item_plan_covers_every_frame_once(T, B, win, hop, workers):
-    """Host planner of the streaming Griffin-Lim kernel (gl_plan_stream): the runs tile [0, T) exactly, run lengths
-    descend (long runs first), all runs but the last have one length (a multiple of the eight waves), and the LDS ring
-    holds enough frames."""
-    classes, ring = _gl_plan(T, B, win, hop, workers)
-    assert 1 <= len(classes) <= 2
-    assert sum(c * n for c, n in classes) == T
-    assert all(c >= 1 and n >= 1 for c, n in classes)
-    assert all(classes[i][0] >= classes[i + 1][0] for i in range(len(classes) - 1))
-    if len(classes) == 2:
-        assert classes[0][0] % 8 == 0 and classes[1][1] == 1
+    """Host planner of the streaming Griffin-Lim kernel (gl_plan_items): the runs tile [0, T) of every utterance exactly, a
+    run's slot is its ordinal inside the utterance, the utterance's last run carries the number of slots other utterances
+    have beyond it, the table starts with one run per worker (the runs that follow a worker's first come after them), no
+    worker's frames + per-run cost exceed the average by more than a run's rounding, and the LDS ring holds enough frames."""
+    items, ring = _gl_plan(T, B, win, hop, workers)
     assert ring >= 8
-    # same inputs -> same cut (the waveform's summation order depends on it)
-    assert _gl_plan(T, B, win, hop, workers)[0] == classes
+    runs = {}
+    for b, t0, n, w in items:
+        assert 0 <= b < B and n >= 1
+        runs.setdefault(b, []).append((t0, n, w))
+    assert sorted(runs) == list(range(B))
+    spu = max(len(r) for r in runs.values())
+    for b, r in runs.items():
+        r.sort()
+        t = 0
+        for k, (t0, n, w) in enumerate(r):
+            assert t0 == t
+            t += n
+            assert (w & 0xffff) == k
+            assert (w >> 16) == (spu - len(r) if k == len(r) - 1 else 0)
+        assert t == T
+    # same inputs -> same cut
+    assert _gl_plan(T, B, win, hop, workers)[0] == items
+    if len(items) > workers:
+        # the frames a worker gets: a first run and the runs dealt after the first `workers` entries, in table order to the
+        # worker that comes free first -- the list schedule the kernel's item counter produces
+        import heapq
+        heap = [(n, k) for k, (_, _, n, _) in enumerate(items[:workers])]
+        heapq.heapify(heap)
+        for _, _, n, _ in items[workers:]:
+            load, k = heapq.heappop(heap)
+            heapq.heappush(heap, (load + n + 11, k))
+        worst = max(l for l, _ in heap)
+        assert worst <= B * T / workers * 1.06 + 24, (worst, B * T / workers)
     if (T, B, win, hop, workers) == (1000, 64, 1102, 275, 224):
-        # three iterations per launch cost a run 24 indices beyond its frames: 192 workgroups take one run of 296 frames,
-        # 32 take two of 112 (the equal cut, two runs of 144 / 136 per workgroup, is 2 x 168 indices against 320)
-        assert classes == [(296, 3), (112, 1)]
+        # 2 utterances on 7 workgroups: 288 + 286 + 286 + (140 | 140) + 286 + 286 + 288 -- the workgroup in the middle takes the
+        # tail of one utterance and the head of the next (until round 6: 3 x 296 + 112 for every utterance, 32 of the 224
+        # workgroups idle for a fifth of every launch)
+        assert sorted({n for _, _, n, _ in items}) == [140, 286, 288]
+        assert [n for b, t0, n, w in items[224:]] == [140] * 32
 
 
 def _ring_frames(win, hop, n_stage=1):
