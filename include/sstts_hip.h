@@ -116,12 +116,10 @@ int tts_set_stream(tts_handle_t h, void* hip_stream);
  * up to 512 -- with 16 or 32 utterances per cluster of 16 compute units as the free units allow (the same bits either way,
  * so a call's spectrograms do not depend on what the handle ran before); 2 = any persistent kernel whenever the configuration
  * allows; 0 = never: one launch per layer; tts_synchronize reports TTS_ERR_HIP if one of its bounded waits timed out),
- * "deterministic" (default 0; 1: the waveform, too, is the same bits whether a call was pipelined or not -- every call
- * takes the pipelined calls' Griffin-Lim run cut and none the second, wide one; costs a pipelined step ~0.25 ms),
  * "gl_pair" (Griffin-Lim iterations per launch, 1..3, default 3: the spectrum passes from one iteration to the next in
  * registers; identical arithmetic per iteration), "gl_wide_from" (pipelined calls: the first Griffin-Lim launch that is cut
  * for all compute units instead of all but "reserve_cus" -- the next call's decoder has left them by then; -1 (default) =
- * from a model of the two durations, -2 = never, n >= 0 = launch n; a second overlap-add order: rounding only),
+ * from a model of the two durations, -2 = never, n >= 0 = launch n; the waveform's bits do not depend on the cut),
  * "fused_tail" (default 1: lifter + highway stack + GRU input
  * projections of a CBHG as one launch; 0 = layer by layer), "enc_stream" (default 1: under the call pipeline with the
  * persistent decoder the encoder of a call runs on a stream of its own, one inter-Griffin-Lim gap ahead of its decoder, so

@@ -756,7 +756,6 @@ int tts_set_option(tts_handle_t h, const char* key, int value) {
     }
     else if (!std::strcmp(key, "gl_pair")) h->gl_pair = value;
     else if (!std::strcmp(key, "gl_wide_from")) h->gl_wide = value < -2 ? -2 : value;
-    else if (!std::strcmp(key, "deterministic")) h->deterministic = value ? 1 : 0;
     else if (!std::strcmp(key, "gemm_presplit") || !std::strcmp(key, "gemm_ps")) {
         if (value && !gemm_experiments_built())
             return fail(h, TTS_ERR_UNSUPPORTED, std::string(key) + ": a measured-and-not-faster GEMM variant of round 5; its kernels are only "

@@ -149,10 +149,6 @@ struct tts_handle_s {
     // First Griffin-Lim launch of a pipelined call that is cut for all compute units (gl_run, `wide_from`): -1 = by the rule
     // in gl_wide_from() below, -2 = never, >= 0 = that launch index.
     int gl_wide = -1;
-    // option "deterministic" (default 0): 1 = a call's outputs are bit-identical whatever the handle ran before -- the decoder
-    // already is (one kernel form's bits everywhere), this pins the Griffin-Lim run cut: the pipelined calls' cut for every
-    // call, no wide launches (costs the pipelined step ~0.25 ms and an unpipelined call ~5 % of its Griffin-Lim phase)
-    int deterministic = 0;
     int n_cus_dev = 0;
     bool pd_configured = false;
     // Test / diagnostic hooks, all per handle and all inert unless the option "debug_hooks" has been set to 1 on THIS handle

@@ -293,7 +293,7 @@ int tts_synthesize(tts_handle_t h, const int32_t* ids, int B, int Ts, const tts_
         HIPCHK(h, hipEventRecord(h->ev_post_done[parity], h->stream));
         h->post_pending[parity] = true;
     }
-    const int wide_from = (pipelined && gl_streaming && !h->deterministic) ? gl_wide_from(h, B, Ts, sp->n_steps, T, sp->n_iter) : -1;
+    const int wide_from = (pipelined && gl_streaming) ? gl_wide_from(h, B, Ts, sp->n_steps, T, sp->n_iter) : -1;
     h->gl_wide_used[parity] = wide_from >= 0;
     if (gl_streaming)
         rc = gl_run(h, magi, init_phase, sp->seed, B, T, sp->n_iter, sp->win_length, sp->hop_length, c.n_fft, wav, nullptr,

@@ -432,17 +432,14 @@ int gl_run(tts_handle_t h, const float* mag_int, const float* init_ft, uint64_t 
     int per_launch = h->gl_pair;
     per_launch = per_launch < 1 ? 1 : (per_launch > 3 ? 3 : per_launch);
     while (per_launch > 1 && gl_stream_ring_frames(win, hop, per_launch) <= 0) --per_launch;
-    // option "deterministic": ONE cut for every call of a shape, pipelined or not -- the cut of the pipelined calls (all but
-    // `reserve_cus` workgroups), never the second, wide one; an unpipelined call then runs that cut on all compute units
-    // (the cut decides the overlap-add order, the number of workgroups that draw its items does not)
-    const int plan_held = (h->deterministic && h->reserve_cus > 0) ? h->reserve_cus : held;
-    HIPCHK(h, gl_plan_stream(p, n_cus - plan_held > 16 ? n_cus - plan_held : n_cus, per_launch, h->debug_hooks ? h->gl_runs : 0,
+    // (the cut decides who does which frames, never the waveform's bits: every sample is summed over the frames that cover it in
+    //  ascending order whatever run they lie in -- tests/test_gpu_audio.py::test_griffin_lim_bits_do_not_depend_on_the_cut)
+    HIPCHK(h, gl_plan_stream(p, n_cus - held > 16 ? n_cus - held : n_cus, per_launch, h->debug_hooks ? h->gl_runs : 0,
                              h->debug_hooks ? h->gl_run_len : 0, h->stream));
     // wide_from >= 0 (the pipelined tts_synthesize, see gl_wide_from there): launches from that index on are cut for ALL
-    // compute units -- the second stream's decoder has left its share by then.  A second cut, fixed per launch index, so
-    // the waveform's bits stay a function of the call's arguments and options alone.
+    // compute units -- the second stream's decoder has left its share by then.  A second cut of the same frames.
     GlParams pw = p;
-    const bool two_cuts = held > 0 && wide_from >= 0 && n_cus - held > 16 && !h->deterministic &&
+    const bool two_cuts = held > 0 && wide_from >= 0 && n_cus - held > 16 &&
                           !(h->debug_hooks && (h->gl_runs || h->gl_run_len));
     if (two_cuts) HIPCHK(h, gl_plan_stream(pw, n_cus, per_launch, 0, 0, h->stream));
     const int nchunks = std::max(p.slots_per_utt, pw.slots_per_utt);
