@@ -129,8 +129,8 @@ int tts_set_stream(tts_handle_t h, void* hip_stream);
  * Test and diagnostic hooks -- per handle, inert (and refused with a non-zero value) until "debug_hooks" has been set to 1
  * on the same handle; nothing in the process environment changes what a call computes: "pd_debug_delay" (workgroup 3 of
  * every persistent-decoder cluster stages its tile that many x ~3.4 us late), "gl_runs" / "gl_run_len" (force the cut of
- * an utterance's frames into Griffin-Lim runs: runs per utterance / frames per run; the cut is part of the waveform's
- * rounding), "gl_workers" (plan and launch Griffin-Lim for that many workgroups instead of one per free compute unit),
+ * an utterance's frames into Griffin-Lim runs: runs per utterance / frames per run; the waveform's bits do not depend on
+ * the cut), "gl_workers" (plan and launch Griffin-Lim for that many workgroups instead of one per free compute unit),
  * "pd_rows" (16 / 32: utterances per cluster of the weight-stationary decoder instead of the library's choice),
  * "timeline" (tts_profile_get prints the absolute times of every profiled span); tts_debug_hold.
  * Initial phases of Griffin-Lim: `init_phase` (a (B, F, T) array of U[0,1) numbers, angle = 2 pi u) or, when it is NULL,

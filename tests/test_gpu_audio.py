@@ -198,8 +198,8 @@ def test_griffin_lim_seeded_start(engine, per_launch, n_iter, want_mse, seed):
 @pytest.mark.parametrize('run_len', [8, 16, 40, 104, 296])
 @pytest.mark.parametrize('per_launch,n_iter,want_mse', [(1, 2, True), (3, 4, False)])
 def test_griffin_lim_forced_run_cuts(engine, run_len, per_launch, n_iter, want_mse):
-    """Every cut of the utterances into runs gives the same waveform (to rounding: the overlap-add order at the run borders
-    is part of the sums): forced run lengths from one round of the waves to longer than the utterance -- many runs per
+    """Every cut of the utterances into runs gives the same waveform (the same BITS even:
+    test_griffin_lim_bits_do_not_depend_on_the_cut; here against the oracle): forced run lengths from one round of the waves to longer than the utterance -- many runs per
     workgroup, runs too short to draw the next item late (fewer than four rounds: drawn at the start) next to runs that draw
     it 24 indices before their end, remainders of one class."""
     import os
