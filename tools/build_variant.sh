@@ -8,7 +8,7 @@ B=$R/single-speaker-tts_amd/build
 name=$1; unit=$2; flags=$3; src=${4:-$R/single-speaker-tts_amd/csrc/$unit}
 mkdir -p $R/tools/bin
 extra=""
-[ "$unit" = "griffin_lim.hip" ] && extra="-fno-slp-vectorize"
+[ "$unit" = "griffin_lim.hip" -o "$unit" = "griffin_lim_generic.hip" ] && extra="-fno-slp-vectorize"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w $extra $flags -I$R/single-speaker-tts_amd/csrc -c $src -o $R/tools/bin/${name}_unit.o
 objs=""
 for u in gemm_f32 cbhg_tail gru decoder decoder_persistent decoder_ws griffin_lim griffin_lim_generic reserve api_handle api_stages api_pipeline; do
