@@ -255,6 +255,45 @@ def test_griffin_lim_bits_do_not_depend_on_the_cut(engine):
         assert np.array_equal(ref.view(np.uint32), v.view(np.uint32)), k
 
 
+def test_griffin_lim_utterances_cut_into_different_numbers_of_runs(engine, weights):
+    """The frames are dealt to the workgroups across utterance ends (gl_plan_items), so utterances are not all cut into the same
+    number of runs (T = 120, B = 7 on 17 workgroups: six utterances in 3 runs, one in 4): the per-run partial results -- the
+    squared error of the last iteration, the peak of the final iSTFT -- have one slot per run, and the last run of an utterance
+    zeroes the slots it does not have.  The mse against the oracle and the default cut; the peak-normalised waveform of
+    tts_synthesize bit for bit against the default cut."""
+    B, T, n_iter = 7, 120, 4
+    rng = np.random.default_rng(120)
+    mag = synth_mag(rng, B, T)
+    init = rng.random(mag.shape).astype(np.float32)
+    ids = np.zeros((B, 20), np.int32)
+    for b in range(B):
+        ids[b, :12 + b] = rng.integers(2, 39, 12 + b)
+        ids[b, 12 + b] = 1
+    res = {}
+    engine.set_option('debug_hooks', 1)
+    engine.set_option('pipeline', 0)
+    try:
+        for workers in (0, 17):
+            engine.set_option('gl_workers', workers)
+            wav, mse = engine.griffin_lim(mag, n_iter, WIN, HOP, N_FFT, init_phase=init, want_mse=True)
+            out = engine.synthesize(ids, T // 5, 6.02, 99.89, 1.3, n_iter, WIN, HOP, seed=9, peak_normalize=True)
+            engine.synchronize()
+            res[workers] = (wav.to_host().copy(), mse.to_host().copy(), out['wav'].to_host().copy())
+    finally:
+        engine.set_option('gl_workers', 0)
+        engine.set_option('debug_hooks', 0)
+        engine.set_option('pipeline', 1)
+    wav0, mse0, syn0 = res[0]
+    wav1, mse1, syn1 = res[17]
+    assert np.array_equal(wav0.view(np.uint32), wav1.view(np.uint32))
+    assert np.allclose(mse0, mse1, rtol=1e-5, atol=0)
+    assert np.array_equal(syn0.view(np.uint32), syn1.view(np.uint32))
+    assert np.allclose(np.abs(syn1).max(axis=1), 1.0, atol=1e-6)
+    for b in (0, B - 1):
+        _, ref_mse = A.griffin_lim_v2(mag[b], WIN, HOP, N_FFT, n_iter, init_phase=init[b])
+        assert abs(mse1[b] - ref_mse) <= 1e-3 * abs(ref_mse) + 1e-9
+
+
 # ---- every power-of-two n_fft / window / hop on the audio surface (csrc/griffin_lim_generic.hip): the reference passes
 # n_fft, win_length and hop_length as arguments (audio/synthesis.py:5-40, 43-125; audio/features.py:5-86, 116-145)
 @pytest.mark.parametrize('n_fft,win,hop,B,T', [
