@@ -2,17 +2,19 @@
 // whose workgroups keep their share of every layer's weights in REGISTERS for the whole loop.
 //
 // Same arithmetic as decoder.hip / decoder_persistent.hip (reference tacotron/model.py:191-331, wrappers.py:94-124,
-// helpers.py:83-110,161-205; TF-1.8 GRUCell form, global LuongAttention).  What changed against decoder_persistent.hip:
+// helpers.py:83-110,161-205): the TF-1.8 GRUCell form or the CudnnCompatibleGRUCell form (template CUDNN), global
+// LuongAttention or LocalLuongAttention with monotonic / predictive windows (template LOCAL; attention.py:20-265), 32 or 16
+// utterances per cluster (template M, same bits).  What changed against decoder_persistent.hip:
 // there a cluster of 8 workgroups x 16 utterances re-streamed its share of the 6 MB of weights from L2 in EVERY step
 // (128 KB per workgroup and phase: 101 M L2 read requests = 12.6 GB per launch for an algorithmic 44 MB, 20 of the 78 us of
 // a step by ablation: profiles/r04_decoder_l2_counters.txt, HISTORY.md part C).  Here
-//   * a CLUSTER is 16 workgroups (one per CU, 512 threads = 2 waves per SIMD, 256 registers per lane) x 32 utterances;
+//   * a CLUSTER is 16 workgroups (one per CU, 512 threads = 2 waves per SIMD, 256 registers per lane) x M = 32 or 16 utterances;
 //     workgroup j owns units [16 j, 16 j + 16) of every 256-unit layer (for a GRU its r AND u columns: the update gate
 //     and the cell state of its units never leave its LDS) and units [8 j, 8 j + 8) of pre-net 2;
 //   * its weights -- 5.25 MB / 16 = 336 KB, 172 registers per lane (WS_NREG) -- are loaded ONCE, from an image that
 //     tts_finalize_weights lays out in register order (decoder_ws_pack: lane (n, q) of wave w holds W[n][k(w, reg, q)]), and
 //     are the B operands of v_mfma_f32_16x16x4_f32 straight from the register file; K is split over the 8 waves (over 4 for
-//     the two gate tiles of a GRU), two 16-row blocks per wave;
+//     the two gate tiles of a GRU), M / 16 16-row blocks per wave;
 //   * the hand-off buffers are in BLOCK FORMAT [producer workgroup][row 0..31][its units]: a producer's epilogue writes
 //     whole 128-byte lines (two rows x 16 units, eight lanes of one store instruction), a consumer stages the cluster's
 //     A tile with a linear copy (sc1 16-byte loads, no address arithmetic, conflict-free ds_write_b128), and a 16-deep k
@@ -20,9 +22,9 @@
 //   * hand-off protocol as in decoder_persistent.hip (MI355X_MICROARCH.md, valid forms): every handed-off byte stored
 //     sc1, each storing wave waits vmcnt(0) and adds to the cluster's counter for itself, consumers poll the counter with
 //     an sc1 load in one lane, then a workgroup barrier, then sc1 loads.  No cache-wide release / acquire, no grid barrier;
-//   * attention: workgroup j scores, normalises and contracts rows 2 j and 2 j + 1 of its cluster (4 waves each).
+//   * attention: workgroup j scores, normalises and contracts rows (M / 16) j ... of its cluster (4 waves each).
 // Every wait is bounded; on a timeout the sticky status word is set and the grid drains.  All workgroups must be
-// co-resident: 16 * ceil(B / 32) compute units (api_stages.hip checks the budget).  Configurations this kernel does not cover
+// co-resident: 16 * ceil(B / M) compute units (api_stages.hip checks the budget).  Configurations this kernel does not cover
 // (other layer sizes or counts) run in decoder_persistent.hip / decoder.hip.
 #include "tts_common.h"
 #include "decoder.h"
