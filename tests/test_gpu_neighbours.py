@@ -104,3 +104,47 @@ def test_stage_beside_gemm_launches_of_another_handle(engine, neighbour, stage):
         engine.set_option('persistent_decoder', 1)
         for a in keep:
             a.free()
+
+
+@pytest.mark.parametrize('form', [(0, 1), (2, 1), (2, 0)], ids=['launch-per-layer', 'weight-stationary', 'streamed-weights'])
+@pytest.mark.parametrize('variant', ['local-attention', 'cudnn-gru'])
+def test_other_decoder_variants_beside_gemm_launches(hparams, weights, neighbour, variant, form):
+    """The decoder kernels of the configurations the session's engine does not run -- LocalLuongAttention (attention.py:109-342;
+    pd_attention_local has 139 packed-f32 instructions) and the CudnnCompatibleGRUCell form (layers.py:562-568) -- under the same
+    neighbour."""
+    import copy
+    eng2, launch = neighbour
+    hp = copy.deepcopy(hparams)
+    if variant == 'local-attention':
+        hp.attention.mechanism = 'LocalLuongAttention'
+        hp.attention.luong_local_window_D = 6
+        hp.attention.luong_force_gaussian = True
+        w = weights
+    else:
+        hp.force_cudnn = True
+        w = pkg('tacotron.weights').synthetic_weights(0, hp)
+    eng = pkg().Engine(hp)
+    eng.load_weights(w)
+    pd, pd_ws = form
+    eng.set_option('persistent_decoder', pd)
+    eng.set_option('debug_hooks', 1)
+    eng.set_option('pd_ws', pd_ws)
+    try:
+        mem = eng.to_device((np.random.default_rng(5).standard_normal((16, 60, 256)) * 0.5).astype(np.float32))
+        run = lambda: _first(eng.decoder_forward(mem, 10))
+        quiet = run()
+        eng.synchronize()
+        ref = quiet.to_host().copy()
+        assert np.isfinite(ref).all()
+        bad = n = 0
+        for _ in range(20):
+            launch()
+            outs = [run() for _ in range(2)]
+            eng.synchronize()
+            eng2.synchronize()
+            for o in outs:
+                n += 1
+                bad += not np.array_equal(o.to_host(), ref)
+        assert bad == 0, '%d of %d results differ from the quiet run' % (bad, n)
+    finally:
+        eng.close()
